@@ -1,0 +1,475 @@
+"""ORACLE — CPU restatement of the SINGA hot path (test infrastructure; see oracle/README.md).
+
+Pure PyTorch, functional, keyed by the reference's state-dict names.  Only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import this file; the product (singa_amd/) never does.
+
+Pinned against outputs of the reference itself, run in the build container by oracle/make_golden.py
+(tests/golden/*.npz; checked by tests/test_oracle_golden.py).  Third-party boundaries (e3nn S2 grids and
+angle conventions, PyG/torch_scatter helpers, dgl.lap_pe) are restated from their published definitions
+and are unpinned by any reference test.
+
+Citations: EF = /root/reference/model/EF_layers.py, EMB = model/Embedding.py, CP = model/CProMG.py,
+GAN = model/GAN.py.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import so3_tables as T
+
+PA, LA = "protein_atoms", "ligand_atoms"
+AVG_DEGREE = 23.395238876342773  # EMB:36
+
+
+# ----------------------------------------------------------------------------- small helpers
+def _t(a, dtype=torch.float32):
+    return torch.as_tensor(np.asarray(a), dtype=dtype)
+
+
+def lin(sd, p, x):
+    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+
+
+def layer_norm(sd, p, x):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
+
+
+def seg_softmax(x, index, n, eps):
+    """exp(x - segmax) / (segsum + eps); eps = 1e-16 for pyg.utils.softmax (EF:1180), 0 for scatter_softmax (CP:66)."""
+    idx = index.view(-1, *([1] * (x.dim() - 1))).expand_as(x)
+    mx = torch.full((n,) + tuple(x.shape[1:]), float("-inf"), dtype=x.dtype).scatter_reduce(
+        0, idx, x.detach(), reduce="amax", include_self=True)
+    ex = (x - mx[index]).exp()
+    den = torch.zeros_like(mx).index_add_(0, index, ex) + eps
+    return ex / den[index]
+
+
+def seg_sum(x, index, n):
+    return torch.zeros((n,) + tuple(x.shape[1:]), dtype=x.dtype).index_add_(0, index, x)
+
+
+# ----------------------------------------------------------------------------- a3/a4: edge frames, Wigner-D
+def edge_rot_mat(vec, rand):
+    """EF:2286-2351 with the `torch.rand_like` draw passed in explicitly."""
+    d = vec.norm(dim=1, keepdim=True)
+    nx = vec / d
+    r = rand - 0.5
+    r = r / r.norm(dim=1, keepdim=True)
+    rb = torch.stack([-r[:, 1], r[:, 0], r[:, 2]], 1)
+    rc = torch.stack([r[:, 0], -r[:, 2], r[:, 1]], 1)
+
+    def dot(a):
+        return (a * nx).sum(1, keepdim=True).abs()
+    r = torch.where(dot(r) > dot(rb), rb, r)
+    r = torch.where(dot(r) > dot(rc), rc, r)
+    assert float(dot(r).max()) < 0.99
+    nz = torch.cross(nx, r, dim=1)
+    nz = nz / nz.norm(dim=1, keepdim=True)
+    ny = torch.cross(nx, nz, dim=1)
+    ny = ny / ny.norm(dim=1, keepdim=True)
+    inv = torch.stack([nz, nx, -ny], dim=2)      # columns z | x | -y
+    return inv.transpose(1, 2).contiguous()
+
+
+def wigner_dense(rot, L):
+    """[E,K,K] block-diagonal Wigner-D from 3x3 frames. EF:508-528, 2207-2229; angle conventions: e3nn."""
+    x = rot @ rot.new_tensor([0.0, 1.0, 0.0])
+    x = F.normalize(x, dim=-1).clamp(-1, 1)
+    beta, alpha = torch.acos(x[:, 1]), torch.atan2(x[:, 0], x[:, 2])
+    ca, sa, cb, sb = alpha.cos(), alpha.sin(), beta.cos(), beta.sin()
+    o, z = torch.ones_like(ca), torch.zeros_like(ca)
+    ry = torch.stack([torch.stack([ca, z, sa], -1), torch.stack([z, o, z], -1), torch.stack([-sa, z, ca], -1)], -2)
+    rx = torch.stack([torch.stack([o, z, z], -1), torch.stack([z, cb, -sb], -1), torch.stack([z, sb, cb], -1)], -2)
+    rr = (ry @ rx).transpose(-1, -2) @ rot
+    gamma = torch.atan2(rr[:, 0, 2], rr[:, 0, 0])
+    K = (L + 1) ** 2
+    out = torch.zeros(rot.shape[0], K, K, dtype=rot.dtype)
+    for l in range(L + 1):
+        J = _t(T.jd(l)).to(rot.dtype)
+        f = torch.arange(l, -l - 1, -1, dtype=rot.dtype)
+
+        def zrot(ang):
+            m = ang.new_zeros(ang.shape[0], 2 * l + 1, 2 * l + 1)
+            i = torch.arange(2 * l + 1)
+            m[:, i, 2 * l - i] = torch.sin(f * ang[:, None])
+            m[:, i, i] = torch.cos(f * ang[:, None])
+            return m
+        out[:, l * l:(l + 1) ** 2, l * l:(l + 1) ** 2] = zrot(alpha) @ J @ zrot(beta) @ J @ zrot(gamma)
+    return out
+
+
+class Frame:
+    """Per-edge-type rotation state: what SO3_Rotation.set_wigner keeps (EF:485-505)."""
+
+    def __init__(self, rot, L, M):
+        self.L, self.M = L, M
+        red = torch.as_tensor(T.reduced_index(L, M))
+        w = wigner_dense(rot, L)
+        self.fwd = w[:, red, :]                                              # rotate: [E,Kr,K]
+        self.inv = w.transpose(1, 2)[:, :, red] * _t(T.rotate_inv_rescale(L, M))  # rotate_inv: [E,K,Kr]
+        perm, self.m_size = T.m_primary_perm(L, M)
+        self.to_m = torch.as_tensor(perm)
+        self.to_l = torch.argsort(self.to_m)
+
+
+# ----------------------------------------------------------------------------- a14, a7, a12, a10
+def rms_norm(sd, p, x, L):
+    """EquivariantRMSNormArraySphericalHarmonicsV2 as instantiated (Q3). EF:2155-2192."""
+    x0 = x[:, :1] - x[:, :1].mean(dim=2, keepdim=True)
+    x = torch.cat([x0, x[:, 1:]], 1)
+    lk = torch.as_tensor([l for (l, m) in T.full_lm(L)])
+    bal = (1.0 / ((2 * lk + 1).to(x.dtype) * (L + 1))).view(1, -1, 1)
+    s = (x.pow(2) * bal).sum(1, keepdim=True).mean(2, keepdim=True)
+    y = x * (s + 1e-5).pow(-0.5) * sd[p + ".affine_weight"][lk].unsqueeze(0)
+    return torch.cat([y[:, :1] + sd[p + ".affine_bias"].view(1, 1, -1), y[:, 1:]], 1)
+
+
+def radial(sd, p, x):
+    """RadialFunction: Linear-LN-SiLU-Linear-LN-SiLU-Linear. EF:1634-1657."""
+    x = F.silu(layer_norm(sd, p + ".net.1", lin(sd, p + ".net.0", x)))
+    x = F.silu(layer_norm(sd, p + ".net.4", lin(sd, p + ".net.3", x)))
+    return lin(sd, p + ".net.6", x)
+
+
+def so3_linear(sd, p, x, L):
+    """SO3_LinearV2. EF:655-671."""
+    lk = torch.as_tensor([l for (l, m) in T.full_lm(L)])
+    out = torch.einsum("bmi,moi->bmo", x, sd[p + ".weight"][lk])
+    return torch.cat([out[:, :1] + sd[p + ".bias"].view(1, 1, -1), out[:, 1:]], 1)
+
+
+def sep_s2_act(gate, x, L, M):
+    """SeparableS2Activation on grid [L][M]. EF:1736-1773."""
+    to, fr = (_t(a) for a in T.s2_grid_mats(L, M))
+    grid = F.silu(torch.einsum("bai,zic->zbac", to, x))
+    y = torch.einsum("bai,zbac->zic", fr, grid)
+    return torch.cat([F.silu(gate).unsqueeze(1), y[:, 1:]], 1)
+
+
+def gaussian(dist, stop, n, width):
+    off = torch.linspace(0.0, stop, n)
+    coeff = -0.5 / (width * (off[1] - off[0])).item() ** 2
+    return torch.exp(coeff * (dist.view(-1, 1) - off.view(1, -1)) ** 2)
+
+
+# ----------------------------------------------------------------------------- a9: SO(2) convolution
+def so2_conv(sd, p, x, rad, fr, cout, extra):
+    """x: [E,Kr,Cin] reduced l-primary -> ([E,Kr,cout] reduced l-primary, extra [E,extra] or None). EF:807-875, 721-729."""
+    E = x.shape[0]
+    xm = x[:, fr.to_m]
+    n0 = fr.m_size[0]
+    x0 = xm[:, :n0].reshape(E, -1)
+    off_r = 0
+    if rad is not None:
+        x0 = x0 * rad[:, :x0.shape[1]]
+    off_r = x0.shape[1]
+    y0 = lin(sd, p + ".fc_m0", x0)
+    ex = None
+    if extra:
+        ex, y0 = y0[:, :extra], y0[:, extra:]
+    outs = [y0.reshape(E, -1, cout)]
+    off = n0
+    for m in range(1, fr.M + 1):
+        sz = fr.m_size[m]
+        xx = xm[:, off:off + 2 * sz].reshape(E, 2, -1)
+        if rad is not None:
+            xx = xx * rad[:, off_r:off_r + xx.shape[2]].unsqueeze(1)
+        off_r += xx.shape[2]
+        y = F.linear(xx, sd[f"{p}.so2_m_conv.{m - 1}.fc.weight"])
+        h = y.shape[2] // 2
+        yr, yi = y[..., :h], y[..., h:]
+        outs.append(torch.stack([yr[:, 0] - yi[:, 1], yr[:, 1] + yi[:, 0]], 1).reshape(E, -1, cout))
+        off += 2 * sz
+    return torch.cat(outs, 1)[:, fr.to_l], ex
+
+
+# ----------------------------------------------------------------------------- a8, a11, a13, a15
+def edge_degree(sd, p, x_edge, dst, n_dst, fr, C):
+    """EdgeDegreeEmbedding. EF:86-149."""
+    E = x_edge.shape[0]
+    n0 = fr.m_size[0]
+    r = radial(sd, p + ".rad_func", x_edge).reshape(E, n0, C)
+    full = torch.cat([r, r.new_zeros(E, fr.to_m.numel() - n0, C)], 1)[:, fr.to_l]
+    return seg_sum(torch.bmm(fr.inv, full), dst, n_dst) / AVG_DEGREE
+
+
+def graph_attention(sd, p, x_src, x_dst, x_edge, src, dst, fr, hp):
+    """SO2EquivariantGraphAttention.forward. EF:1079-1204."""
+    heads, A, V, H = hp["heads"], hp["alpha"], hp["value"], hp["hidden"]
+    msg = torch.cat([x_src[src], x_dst[dst]], 2)
+    msg = torch.bmm(fr.fwd, msg)
+    rad = radial(sd, p + ".so2_conv_1.rad_func", x_edge)
+    msg, ex = so2_conv(sd, p + ".so2_conv_1", msg, rad, fr, H, heads * A + H)
+    a_in, gate = ex[:, :heads * A], ex[:, heads * A:]
+    msg = sep_s2_act(gate, msg, fr.L, fr.M)
+    msg, _ = so2_conv(sd, p + ".so2_conv_2", msg, None, fr, heads * V, 0)
+    a = layer_norm(sd, p + ".alpha_norm", a_in.reshape(-1, heads, A))
+    a = 0.6 * a + 0.4 * a * (2 * torch.sigmoid(a) - 1)                      # SmoothLeakyReLU(0.2), EF:1669-1677
+    logit = (a * sd[p + ".alpha_dot"]).sum(-1)
+    alpha = seg_softmax(logit, dst, x_dst.shape[0], 1e-16)
+    msg = (msg.reshape(msg.shape[0], msg.shape[1], heads, V) * alpha.view(-1, 1, heads, 1)).reshape(
+        msg.shape[0], msg.shape[1], heads * V)
+    agg = seg_sum(torch.bmm(fr.inv, msg), dst, x_dst.shape[0])
+    return so3_linear(sd, p + ".proj", agg, fr.L)
+
+
+def ffn(sd, p, x, L):
+    """FeedForwardNetwork with separable S2 activation on grid [L][L]. EF:234-270."""
+    gate = lin(sd, p + ".gating_linear", x[:, 0])
+    h = so3_linear(sd, p + ".so3_linear_1", x, L)
+    h = sep_s2_act(gate, h, L, L)
+    return so3_linear(sd, p + ".so3_linear_2", h, L)
+
+
+def block_tail(sd, p, ga_out, x_res, L):
+    y = ga_out + x_res
+    return ffn(sd, p + ".ffn", rms_norm(sd, p + ".norm_2", y, L), L) + y
+
+
+def block_homo(sd, p, x, x_edge, src, dst, fr, hp):
+    """TransBlockV2.forward, non-hetero branch. EF:1367-1410."""
+    xn = rms_norm(sd, p + ".norm_1", x, fr.L)
+    ga = graph_attention(sd, p + ".ga", xn, xn, x_edge, src, dst, fr, hp)
+    return block_tail(sd, p, ga, x, fr.L)
+
+
+def hetero_pass(sd, pre, x_s, x_t, x_edge, src, dst, fr, hp, n_layers):
+    """Three TransBlockV2 calls on the shared dict (Q4): every layer re-normalises both stores in place and
+    only the LAST layer's output survives (EF:1352-1366; EMB:415-428). Layers 0..n-2 contribute their norm_1
+    only - their attention/FFN results are discarded by the reference, so they are not computed here.
+    Returns (layer output, x_s after the pass, x_t after the pass)."""
+    for i in range(n_layers):
+        p = f"{pre}blocks.{i}"
+        res = x_t
+        x_s = rms_norm(sd, p + ".norm_1", x_s, fr.L)
+        x_t = rms_norm(sd, p + ".norm_1", x_t, fr.L)
+    ga = graph_attention(sd, p + ".ga", x_s, x_t, x_edge, src, dst, fr, hp)
+    return block_tail(sd, p, ga, res, fr.L), x_s, x_t
+
+
+# ----------------------------------------------------------------------------- a2: EquivariantEmbedding
+def barcode(x):
+    """EMB:250-253: last 15 feature columns truncated to ints, read as a binary number (Q2)."""
+    bits = x[:, -15:].to(torch.long)
+    w = 2 ** torch.arange(14, -1, -1, dtype=torch.long)
+    return (bits * w).sum(1)
+
+
+def hyper(sd, pre, L):
+    H = sd[pre + "blocks.0.ga.so2_conv_1.so2_m_conv.0.fc.weight"].shape[0] // (2 * (L - 1 + 1))
+    heads, A = sd[pre + "blocks.0.ga.alpha_dot"].shape
+    C = sd[pre + "sphere_embedding.weight"].shape[1]
+    V = sd[pre + "blocks.0.ga.proj.weight"].shape[2] // heads
+    n_layers = 1 + max(int(k[len(pre) + 7:].split(".")[0]) for k in sd if k.startswith(pre + "blocks."))
+    return dict(hidden=H, heads=heads, alpha=A, value=V, C=C, n_layers=n_layers)
+
+
+def embedding_forward(sd, g, rots, L, M=2, pre="", cutoff=10.0):
+    """EquivariantEmbedding.forward. EMB:205-480.  g: dict with x_p,pos_p,z_p,x_l,pos_l,z_l,ei_pp,ei_ll,ei_lp,ei_pl
+    (torch tensors); rots: dict pp/ll/lp of [E,3,3] frames (Part 4 reuses lp, Q5)."""
+    hp = hyper(sd, pre, L)
+    C, nl = hp["C"], hp["n_layers"]
+    K = (L + 1) ** 2
+    n_g = sd[pre + "edge_degree_embedding.rad_func.net.0.weight"].shape[1] - 2 * sd[pre + "source_embedding.weight"].shape[1]
+
+    def edge_feat(pos_s, pos_t, z_s, z_t, ei):
+        d = (pos_s[ei[0]] - pos_t[ei[1]]).norm(dim=-1)
+        return torch.cat([gaussian(d, cutoff, n_g, 20.0), sd[pre + "source_embedding.weight"][z_s[ei[0]]],
+                          sd[pre + "target_embedding.weight"][z_t[ei[1]]]], 1)
+
+    def homo(x_feat, pos, z, ei, rot):
+        fr = Frame(rot, L, M)
+        init = sd[pre + "sphere_embedding.weight"][z] + sd[pre + "sphere_embedding_2.weight"][barcode(x_feat)]
+        x = torch.zeros(z.shape[0], K, C)
+        x[:, 0] = init.detach().to(torch.long).to(torch.float32)       # Q1: long-typed store truncates, cuts autograd
+        xe = edge_feat(pos, pos, z, z, ei)
+        x = x + edge_degree(sd, pre + "edge_degree_embedding", xe, ei[1], z.shape[0], fr, C)
+        for i in range(nl):
+            x = block_homo(sd, f"{pre}blocks.{i}", x, xe, ei[0], ei[1], fr, hp)
+        return rms_norm(sd, pre + "norm", x, L)
+
+    P = homo(g["x_p"], g["pos_p"], g["z_p"], g["ei_pp"], rots["pp"])
+    Lg = homo(g["x_l"], g["pos_l"], g["z_l"], g["ei_ll"], rots["ll"])
+    fr = Frame(rots["lp"], L, M)
+    # Part 3: ligand -> protein
+    ei = g["ei_lp"]
+    xe = edge_feat(g["pos_l"], g["pos_p"], g["z_l"], g["z_p"], ei)
+    P = P + edge_degree(sd, pre + "edge_degree_embedding", xe, ei[1], P.shape[0], fr, C)
+    out, Lg, P = hetero_pass(sd, pre, Lg, P, xe, ei[0], ei[1], fr, hp, nl)
+    lp = rms_norm(sd, pre + "norm", out, L)
+    # Part 4: protein -> ligand (same Wigner matrices, Q5)
+    ei = g["ei_pl"]
+    xe = edge_feat(g["pos_p"], g["pos_l"], g["z_p"], g["z_l"], ei)
+    Lg = Lg + edge_degree(sd, pre + "edge_degree_embedding", xe, ei[1], Lg.shape[0], fr, C)
+    out, P, Lg = hetero_pass(sd, pre, P, Lg, xe, ei[0], ei[1], fr, hp, nl)
+    pl = rms_norm(sd, pre + "norm", out, L)
+    return {PA: P + lp, LA: Lg + pl, "lp_edge": lp, "pl_edge": pl}
+
+
+# ----------------------------------------------------------------------------- a17: CProMG transformer
+def ssp(x):
+    return F.softplus(x) - math.log(2.0)
+
+
+def graph_mha(sd, p, h, row, col, ea, heads=4):
+    """MultiHeadAttention over a sparse graph. CP:50-78."""
+    N = h.shape[0]
+
+    def gconv(name):  # grouped 1x1 Conv1d, CP:27-29,55-57
+        w = sd[f"{p}.{name}.weight"][:, :, 0]
+        og, ig = w.shape[0] // heads, w.shape[1]
+        return torch.einsum("ngi,goi->ngo", h.view(N, heads, ig), w.view(heads, og, ig))
+    hk, hq, hv = gconv("k_lin"), gconv("q_lin"), gconv("v_lin")
+    wk = lin(sd, p + ".weight_k_net.2", ssp(lin(sd, p + ".weight_k_net.0", ea)))
+    kj = lin(sd, p + ".weight_k_lin", wk.unsqueeze(1) * hk[col])
+    qk = (hq[row] * kj).sum(-1) / np.sqrt(kj.shape[-1])
+    alpha = seg_softmax(qk, row, N, 0.0)
+    wv = lin(sd, p + ".weight_v_net.2", ssp(lin(sd, p + ".weight_v_net.0", ea)))
+    mj = alpha.unsqueeze(-1) * lin(sd, p + ".weight_v_lin", wv.unsqueeze(1) * hv[col])
+    out = lin(sd, p + ".centroid_lin", h) + seg_sum(mj, row, N).view(N, -1)
+    return layer_norm(sd, p + ".layer_norm", lin(sd, p + ".out_transform", ssp(out)))
+
+
+def dense_mha(sd, p, Q, Kx, Vx, mask, heads=4):
+    """MultiHeadAttention2 / MultiHeadDeAttention. CP:94-158."""
+    B = Q.shape[0]
+    q = lin(sd, p + ".W_Q", Q).view(B, -1, heads, sd[p + ".W_Q.weight"].shape[0] // heads).transpose(1, 2)
+    k = lin(sd, p + ".W_K", Kx).view(B, -1, heads, q.shape[-1]).transpose(1, 2)
+    v = lin(sd, p + ".W_V", Vx).view(B, -1, heads, sd[p + ".W_V.weight"].shape[0] // heads).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) / np.sqrt(q.shape[-1])
+    s = s.masked_fill(mask.unsqueeze(1), -1e9)
+    ctx = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, -1, heads * v.shape[-1])
+    return layer_norm(sd, p + ".layer_norm", lin(sd, p + ".linear", ctx) + Q)
+
+
+def pos_ffn(sd, p, x):
+    """PoswiseFeedForward(De)Net: 1x1 Conv1d pair + residual LN. CP:170-191."""
+    h = F.relu(F.linear(x, sd[p + ".conv1.weight"][:, :, 0], sd[p + ".conv1.bias"]))
+    return layer_norm(sd, p + ".layer_norm", F.linear(h, sd[p + ".conv2.weight"][:, :, 0], sd[p + ".conv2.bias"]) + x)
+
+
+def to_dense(x, batch, B):
+    num = torch.bincount(batch, minlength=B)
+    mx = int(num.max())
+    start = torch.cat([num.new_zeros(1), num.cumsum(0)])[:-1]
+    idx = torch.arange(batch.numel()) - start[batch] + batch * mx
+    out = x.new_zeros(B * mx, x.shape[1])
+    out[idx] = x
+    mask = torch.zeros(B * mx, dtype=torch.bool)
+    mask[idx] = True
+    return out.view(B, mx, -1), mask.view(B, mx), idx
+
+
+def knn_edges(pos, knn_ei, stop, n_g):
+    """CP:295-298: lengths, to_undirected(mean), Gaussian smearing, get_laplacian."""
+    N = pos.shape[0]
+    ln = (pos[knn_ei[0]] - pos[knn_ei[1]]).norm(dim=1)
+    r = torch.cat([knn_ei[0], knn_ei[1]])
+    c = torch.cat([knn_ei[1], knn_ei[0]])
+    key, inv = torch.unique(r * N + c, sorted=True, return_inverse=True)
+    cnt = torch.zeros(key.numel()).index_add_(0, inv, torch.ones(inv.numel()))
+    ln = torch.zeros(key.numel()).index_add_(0, inv, torch.cat([ln, ln])) / cnt
+    row, col = key // N, key % N
+    ea = gaussian(ln, stop, n_g, 1.0)
+    deg = seg_sum(ea, row, N)
+    loop = torch.arange(N)
+    return torch.cat([row, loop]), torch.cat([col, loop]), torch.cat([-ea, deg], 0)
+
+
+def transformer_forward(sd, pre, feat_p, pos_p, batch_p, lap_p, knn_p, feat_l, pos_l, batch_l, lap_l, knn_l,
+                        tokens, prop, pad_id=110):
+    """Transformer.forward (Encoder, Encoder2, Decoder, projection). CP:289-343, 385-464."""
+    B = tokens.shape[0]
+    e1, e2, dc = pre + "encoder", pre + "encoder2", pre + "decoder"
+    n_g = sd[e1 + ".layers.0.enc_self_attn.weight_k_net.0.weight"].shape[1]
+    h = lin(sd, e1 + ".protein_atom_emb", feat_p) + lin(sd, e1 + ".laplacian_emb", lap_p)
+    row, col, ea = knn_edges(pos_p, knn_p, 15.0, n_g)
+    n_layers = 1 + max(int(k[len(e1) + 8:].split(".")[0]) for k in sd if k.startswith(e1 + ".layers."))
+    msa_dense = []
+    for j in range(n_layers):
+        msa = graph_mha(sd, f"{e1}.layers.{j}.enc_self_attn", h, row, col, ea)
+        h = pos_ffn(sd, f"{e1}.layers.{j}.pos_ffn", msa)
+        msa_dense.append(to_dense(msa, batch_p, B)[0])
+    enc1, m1, _ = to_dense(h, batch_p, B)
+    pad1 = ~m1.unsqueeze(1)
+    h = lin(sd, e2 + ".aa_emb", feat_l) + lin(sd, e2 + ".laplacian_emb", lap_l)
+    row, col, ea = knn_edges(pos_l, knn_l, 25.0, n_g)
+    for j in range(n_layers):
+        p = f"{e2}.layers.{j}"
+        msa = graph_mha(sd, p + ".enc_self_attn", h, row, col, ea)
+        if j in (2, 5):                                                       # CP:262
+            kv = lin(sd, p + ".proj", msa_dense[j])
+            qd, _, idx = to_dense(msa, batch_l, B)
+            cr = dense_mha(sd, p + ".cross_attn", qd, kv, kv, pad1)
+            msa = layer_norm(sd, p + ".layer_norm", msa + cr.reshape(-1, cr.shape[-1])[idx])
+        h = pos_ffn(sd, p + ".pos_ffn", msa)
+    enc2, m2, _ = to_dense(h, batch_l, B)
+    enc = torch.cat([enc1, enc2], 1)
+    pad = torch.cat([pad1, ~m2.unsqueeze(1)], 2)
+    # decoder, CP:385-423 (dropout off: eval mode)
+    Tn = tokens.shape[1]
+    x = sd[dc + ".mol_emb.weight"][tokens] + sd[dc + ".pos_emb.pe"][:Tn, 0].unsqueeze(0) + sd[dc + ".type_emb.weight"][1]
+    ptok = lin(sd, dc + ".prop_nn", prop.unsqueeze(1)) + sd[dc + ".type_emb.weight"][0]
+    x = torch.cat([ptok, x], 1)
+    ids = torch.cat([torch.ones(B, 1), tokens.to(torch.float32)], 1)
+    self_mask = ids.eq(pad_id).unsqueeze(1).expand(B, Tn + 1, Tn + 1) | torch.triu(
+        torch.ones(Tn + 1, Tn + 1, dtype=torch.bool), 1).unsqueeze(0)
+    cross_mask = pad.expand(B, Tn + 1, pad.shape[2])
+    for j in range(n_layers):
+        p = f"{dc}.layers.{j}"
+        x = dense_mha(sd, p + ".dec_self_attn", x, x, x, self_mask)
+        x = dense_mha(sd, p + ".dec_enc_attn", x, enc, enc, cross_mask)
+        x = pos_ffn(sd, p + ".pos_ffn", x)
+    logits = F.linear(x, sd[pre + "projection.weight"])[:, 1:]
+    return logits.reshape(-1, logits.shape[-1])
+
+
+def positional_table(d_model=256, max_len=5000):
+    """PositionalEncoding buffer `pe` [max_len,1,d]. CP:200-207."""
+    pe = torch.zeros(max_len, d_model)
+    pos = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.unsqueeze(1)
+
+
+# ----------------------------------------------------------------------------- a1: SINGA
+def singa_forward(sd, g, rots, L, knn_p, knn_l, lap_p, lap_l, M=2):
+    """SINGA.forward (GAN:25-81) on a collated batch dict `g` (keys of embedding_forward + ptr_p, ptr_l,
+    props [B,3] raw (vina, qed, sas), tok_in [B,200])."""
+    emb = embedding_forward(sd, g, rots, L, M, pre="embedding.")
+    K = (L + 1) ** 2
+    C = emb[PA].shape[2]
+    pr = g["props"]
+    prop = torch.stack([(pr[:, 0] < -7.5), (pr[:, 1] > 0.6), (pr[:, 2] < 4.0)], 1).to(torch.float32)  # GAN:38-42
+    bp = torch.repeat_interleave(torch.arange(len(g["ptr_p"]) - 1), g["ptr_p"][1:] - g["ptr_p"][:-1])
+    bl = torch.repeat_interleave(torch.arange(len(g["ptr_l"]) - 1), g["ptr_l"][1:] - g["ptr_l"][:-1])
+    sd = dict(sd)
+    sd.setdefault("model.decoder.pos_emb.pe", positional_table(sd["model.decoder.mol_emb.weight"].shape[1]))
+    return transformer_forward(sd, "model.", emb[PA].reshape(-1, K * C), g["pos_p"], bp, lap_p, knn_p,
+                               emb[LA].reshape(-1, K * C), g["pos_l"], bl, lap_l, knn_l, g["tok_in"], prop)
+
+
+def collate(graphs):
+    """PyG-style collate of per-graph dicts: concat nodes, offset edge_index, ptr vectors."""
+    out = {}
+    np_, nl_ = [g["z_p"].shape[0] for g in graphs], [g["z_l"].shape[0] for g in graphs]
+    op = np.concatenate([[0], np.cumsum(np_)])
+    ol = np.concatenate([[0], np.cumsum(nl_)])
+    for k in ("x_p", "pos_p", "z_p", "x_l", "pos_l", "z_l", "tok_in", "tok_tgt"):
+        out[k] = torch.cat([g[k] for g in graphs], 0)
+    for k, (a, b) in {"ei_pp": (op, op), "ei_ll": (ol, ol), "ei_lp": (ol, op), "ei_pl": (op, ol)}.items():
+        out[k] = torch.cat([g[k] + torch.tensor([[int(a[i])], [int(b[i])]]) for i, g in enumerate(graphs)], 1)
+    out["props"] = torch.stack([g["props"] for g in graphs], 0)
+    out["ptr_p"], out["ptr_l"] = torch.as_tensor(op), torch.as_tensor(ol)
+    return out
+
+
+def load_graph_npz(path):
+    z = np.load(path)
+    g = {k: torch.as_tensor(z[k]) for k in z.files}
+    g["props"] = g["props"].to(torch.float64)
+    return g
