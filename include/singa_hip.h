@@ -1,0 +1,127 @@
+/*
+ * singa_hip.h — C ABI of libsinga_hip.so: the MI355X (gfx950) kernels behind the SINGA hot path.
+ *
+ * The reference (Isomorpfishm/SINGA) is pure Python; the seam it offers for this path is the set of tensor
+ * operations inside model/EF_layers.py ("EF") and model/CProMG.py ("CP").  Each entry point below replaces one of
+ * those call sites (file:line cited) and is what a ctypes binding on the reference side would call
+ * (INTEGRATION.md shows the stub).  Conventions:
+ *   - every pointer is a DEVICE pointer to caller-owned, contiguous memory unless a leading dimension is given;
+ *     fp32 data, int32 indices; pointers are borrowed for the duration of the enqueue only;
+ *   - functions only ENQUEUE work on `stream` (a hipStream_t passed as void*); no allocation, no synchronisation,
+ *     no global mutable state after singa_init();
+ *   - return 0 on success, a negative SINGA_E* code for argument errors, a positive hipError_t for launch errors;
+ *     singa_last_error_string() describes the last failure of the calling thread;
+ *   - edges of one edge type are sorted by destination node: row_ptr[n]..row_ptr[n+1] are the edges into node n.
+ *
+ * Coefficient orderings: node tensors are [N, K=(L+1)^2, C] l-primary; edge tensors between the
+ * two rotations are "m-primary": [(l,0) l=0..L] ++ for m=1..M: [(l,+m) l=m..L] ++ [(l,-m) l=m..L], KR rows.
+ * Reduced Wigner rows Wr[E, WSZ]: for l=0..L the rows |m|<=min(l,M) of the l-th Wigner block, row-major
+ * [2*min(l,M)+1][2l+1]  (WSZ = 35 / 115 / 235 for L = 2 / 4 / 6 at M = 2).
+ */
+#ifndef SINGA_HIP_H
+#define SINGA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SINGA_OK 0
+#define SINGA_E_NULL (-1)        /* required pointer is null */
+#define SINGA_E_LMAX (-2)        /* unsupported (lmax, mmax): built for lmax in {2,4,6}, mmax = 2; EF:2208-2209 */
+#define SINGA_E_SHAPE (-3)       /* inconsistent or unsupported dimension */
+#define SINGA_E_NOINIT (-4)      /* singa_init() has not been called on this device */
+
+/* A strided view of `rows` coefficient rows of width `ch` floats per edge: row r of edge e starts at
+ * ptr + e*ld + r*ch.  Up to three segments make up one m-primary edge tensor (m = 0 | +-1 | +-2 GEMM outputs). */
+typedef struct {
+    const float* ptr;
+    int64_t ld;     /* floats between consecutive edges */
+    int32_t rows;   /* coefficient rows in this segment */
+} singa_seg_t;
+
+typedef struct {
+    float* ptr;
+    int64_t ld;
+    int32_t rows;
+} singa_seg_mut_t;
+
+int singa_version(void);
+const char* singa_last_error_string(void);
+
+/* Upload the J matrices (reference model/Jd.pt, EF:2195-2198) for l = 0..lmax_max (<= 11) to the current device.
+ * jd_flat: HOST pointer, blocks (2l+1)x(2l+1) row-major, concatenated. */
+int singa_init(const double* jd_flat, int lmax_max);
+
+/* Sizes the host needs to allocate buffers: KR, WSZ, RAD_ROWS for (lmax, mmax). */
+int singa_dims(int lmax, int mmax, int* kr, int* wsz, int* rad_rows);
+
+/* k2 — SO3_Rotation.set_wigner / RotationToWignerDMatrix / wigner_D (EF:485-528, 2207-2229):
+ * rot[E,3,3] edge frames -> Wr[E,WSZ] reduced Wigner rows. */
+int singa_wigner_rows(const float* rot, float* wr, int E, int lmax, int mmax, void* stream);
+
+/* k3-k6 — _expand_edge x2 + cat + SO3_Rotation.rotate + _m_primary + radial multiply (EF:326-328,1116-1119,494-497,
+ * 354-355,822-824,847-850).  x_src[Ns,K,C], x_dst[Nd,K,C]; out[E,KR,2C] m-primary, already multiplied by
+ * rad[E,RAD_ROWS,2C] (pass rad = NULL for no multiply). */
+int singa_gather_rotate_fwd(const float* x_src, const float* x_dst, const int32_t* src, const int32_t* dst,
+                            const float* wr, const float* rad, float* out, int E, int C, int lmax, int mmax,
+                            void* stream);
+/* backward: g_out[E,KR,2C] -> g_rad[E,RAD_ROWS,2C] (may be NULL), gx_dst[Nd,K,C] (segmented over row_ptr),
+ * gx_src[Ns,K,C] (segmented over col_ptr / eperm = edge ids sorted by source). */
+int singa_gather_rotate_bwd(const float* g_out, const float* x_src, const float* x_dst, const int32_t* src,
+                            const int32_t* dst, const float* wr, const float* rad, const int32_t* row_ptr,
+                            const int32_t* col_ptr, const int32_t* eperm, float* g_rad, float* gx_src, float* gx_dst,
+                            int E, int Ns, int Nd, int C, int lmax, int mmax, void* stream);
+
+/* k10 / k13 — alpha scaling + _l_primary + SO3_Rotation.rotate_inv (with rescale) + _reduce_edge (index_add_)
+ * (EF:1186-1199, 499-505, 342-351; EdgeDegreeEmbedding EF:116-147 when m0_only != 0).
+ * msg: m-primary edge tensor with CH channels in `nseg` segments; alpha[E,heads] or NULL; out[Nd,K,CH].
+ * Channel c belongs to head c / (CH/heads).  out is multiplied by out_scale (1/23.395... for k13). */
+int singa_rotate_back_scatter_fwd(const singa_seg_t* msg, int nseg, const float* alpha, const float* wr,
+                                  const int32_t* row_ptr, float* out, int Nd, int CH, int heads, int lmax, int mmax,
+                                  int m0_only, float out_scale, void* stream);
+/* backward: g_out[Nd,K,CH] -> g_msg (same segment layout as msg, contiguous per segment), g_alpha_part[E,CH]
+ * (per-channel partial of d/d alpha; the caller sums the CH/heads channels of each head; NULL if alpha is NULL). */
+int singa_rotate_back_scatter_bwd(const float* g_out, const singa_seg_t* msg, const singa_seg_mut_t* g_msg, int nseg,
+                                  const float* alpha, const float* wr, const int32_t* row_ptr, float* g_alpha_part,
+                                  int Nd, int CH, int heads, int lmax, int mmax, int m0_only, float out_scale,
+                                  void* stream);
+
+/* k9 (softmax part) — torch_geometric.utils.softmax / torch_scatter.scatter_softmax over destination segments
+ * (EF:1180; CP:66): out = exp(x - segmax) / (segsum + eps).  x, out: [E, H]. */
+int singa_segment_softmax_fwd(const float* x, const int32_t* row_ptr, float* out, int N, int H, float eps,
+                              void* stream);
+int singa_segment_softmax_bwd(const float* y, const float* gy, const int32_t* row_ptr, float* gx, int N, int H,
+                              void* stream);
+
+/* k15 — alpha-weighted scatter_sum of per-edge messages (CP:71-74): out[N,H,F] = sum_e w[e,H] * v[e,H,F]. */
+int singa_segment_wsum_fwd(const float* w, const float* v, const int32_t* row_ptr, float* out, int N, int H, int F,
+                           void* stream);
+int singa_segment_wsum_bwd(const float* g_out, const float* w, const float* v, const int32_t* row_ptr, float* gw,
+                           float* gv, int N, int H, int F, void* stream);
+
+/* k8 — SeparableS2Activation (EF:1736-1773): rows -> S2 grid (to_grid[G,KIN]) -> SiLU -> rows (from_grid[G,KIN]);
+ * row 0 of the output is SiLU(gate).  x: KIN rows of C channels in `nseg` segments; gate[E, ldg]; out[E,KIN,C].
+ * Grid matrices are given in the row order of x (the host permutes them for m-primary inputs). */
+int singa_s2act_fwd(const singa_seg_t* x, int nseg, const float* gate, int64_t ldg, const float* to_grid,
+                    const float* from_grid, float* out, int E, int C, int KIN, int G, void* stream);
+int singa_s2act_bwd(const singa_seg_t* x, int nseg, const float* gate, int64_t ldg, const float* to_grid,
+                    const float* from_grid, const float* g_out, float* gx, float* g_gate, int E, int C, int KIN,
+                    int G, void* stream);
+
+/* k12 — EquivariantRMSNormArraySphericalHarmonicsV2 as instantiated by get_normalization_layer (EF:2155-2192, 2273):
+ * x[N,K,C] -> y[N,K,C]; weight[L+1,C], bias[C]. */
+int singa_so3_rmsnorm_fwd(const float* x, const float* weight, const float* bias, float* y, int N, int C, int lmax,
+                          float eps, void* stream);
+/* backward: gx[N,K,C]; gw_part[nparts,K,C] and gb_part[nparts,C] are per-wave partial sums the caller reduces
+ * (nparts = singa_so3_rmsnorm_nparts(N)). */
+int singa_so3_rmsnorm_nparts(int N);
+int singa_so3_rmsnorm_bwd(const float* x, const float* weight, const float* gy, float* gx, float* gw_part,
+                          float* gb_part, int N, int C, int lmax, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SINGA_HIP_H */

@@ -1,0 +1,61 @@
+"""ctypes binding of the C ABI in include/singa_hip.h (one place, so that the GPU library and the test-only CPU
+emulation build are called through identical signatures)."""
+import ctypes as C
+
+P = C.c_void_p
+I32 = C.c_int
+I64 = C.c_int64
+F32 = C.c_float
+
+
+class Seg(C.Structure):
+    _fields_ = [("ptr", P), ("ld", I64), ("rows", C.c_int32)]
+
+
+SegArr = Seg * 3
+
+_SIGS = {
+    "singa_version": ([], I32),
+    "singa_last_error_string": ([], C.c_char_p),
+    "singa_init": ([P, I32], I32),
+    "singa_dims": ([I32, I32, C.POINTER(I32), C.POINTER(I32), C.POINTER(I32)], I32),
+    "singa_wigner_rows": ([P, P, I32, I32, I32, P], I32),
+    "singa_gather_rotate_fwd": ([P, P, P, P, P, P, P, I32, I32, I32, I32, P], I32),
+    "singa_gather_rotate_bwd": ([P] * 13 + [I32] * 6 + [P], I32),
+    "singa_rotate_back_scatter_fwd": ([C.POINTER(Seg), I32, P, P, P, P, I32, I32, I32, I32, I32, I32, F32, P], I32),
+    "singa_rotate_back_scatter_bwd": ([P, C.POINTER(Seg), C.POINTER(Seg), I32, P, P, P, P, I32, I32, I32, I32, I32,
+                                       I32, F32, P], I32),
+    "singa_segment_softmax_fwd": ([P, P, P, I32, I32, F32, P], I32),
+    "singa_segment_softmax_bwd": ([P, P, P, P, I32, I32, P], I32),
+    "singa_segment_wsum_fwd": ([P, P, P, P, I32, I32, I32, P], I32),
+    "singa_segment_wsum_bwd": ([P, P, P, P, P, P, I32, I32, I32, P], I32),
+    "singa_s2act_fwd": ([C.POINTER(Seg), I32, P, I64, P, P, P, I32, I32, I32, I32, P], I32),
+    "singa_s2act_bwd": ([C.POINTER(Seg), I32, P, I64, P, P, P, P, P, I32, I32, I32, I32, P], I32),
+    "singa_so3_rmsnorm_nparts": ([I32], I32),
+    "singa_so3_rmsnorm_fwd": ([P, P, P, P, I32, I32, I32, F32, P], I32),
+    "singa_so3_rmsnorm_bwd": ([P, P, P, P, P, P, I32, I32, I32, F32, P], I32),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+def bind(path):
+    lib = C.CDLL(path)
+    for name, (args, res) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
+        fn.argtypes = args
+        fn.restype = res
+    return lib
+
+
+def segs(items):
+    """items: list of (ptr:int, ld:int, rows:int) -> (ctypes array, n)."""
+    arr = SegArr()
+    for i, (p, ld, rows) in enumerate(items):
+        arr[i].ptr, arr[i].ld, arr[i].rows = p, ld, rows
+    return arr, len(items)
+
+
+def check(lib, code, what):
+    if code != 0:
+        raise RuntimeError(f"{what} failed ({code}): {lib.singa_last_error_string().decode()}")

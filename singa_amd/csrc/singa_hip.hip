@@ -1,0 +1,886 @@
+// libsinga_hip.so — hand-written gfx950 (MI355X / CDNA4) kernels for the SINGA equivariant message-passing
+// hot path, behind the C ABI declared in include/singa_hip.h.
+//
+// Design notes (DESIGN.md has the long form):
+//  * 64-wide wavefronts; one lane = one channel of one edge / node, so every global access of a wave is one
+//    contiguous run of channels (coalesced 64-448 B rows).
+//  * Edges are sorted by destination.  Aggregation kernels give one workgroup to one destination node and walk
+//    its edge segment with register accumulators: no atomics, no [E,K,CH] intermediate, bit-reproducible sums.
+//  * Per-edge Wigner rows are wave-uniform (edge index derives from blockIdx), so they are fetched with scalar
+//    loads and used as SGPR operands of v_fma: no LDS traffic and no per-lane operand fetch for the rotation.
+//  * Loops over (l, m, j) are fully unrolled against the constexpr tables of so3_index.h; accumulators live in
+//    statically indexed VGPRs.
+#include <hip/hip_runtime.h>
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/singa_hip.h"
+#include "so3_index.h"
+
+namespace {
+
+thread_local char g_err[256] = "ok";
+
+int fail(int code, const char* msg) {
+    snprintf(g_err, sizeof(g_err), "%s", msg);
+    return code;
+}
+
+int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return SINGA_OK;
+}
+
+constexpr int MAX_J = 2300;  // sum_{l<=11} (2l+1)^2
+__device__ float g_J[MAX_J];
+int g_lmax_init = -1;
+
+__host__ __device__ constexpr int j_off(int l) {
+    int s = 0;
+    for (int i = 0; i < l; ++i) s += (2 * i + 1) * (2 * i + 1);
+    return s;
+}
+
+struct Segs {
+    const float* p[3];
+    long long ld[3];
+    int rows[3];
+};
+struct SegsMut {
+    float* p[3];
+    long long ld[3];
+    int rows[3];
+};
+
+__device__ __forceinline__ float silu(float u) { return u / (1.0f + __expf(-u)); }
+__device__ __forceinline__ float silu_grad(float u) {
+    float s = 1.0f / (1.0f + __expf(-u));
+    return s * (1.0f + u * (1.0f - s));
+}
+
+// ------------------------------------------------------------------------------------------------ k2: Wigner rows
+// One thread per (edge, reduced row).  D_l = Za J Zb J Zc with Z(t) = diag cos(f t) + antidiag sin(f t),
+// f = l, l-1, .., -l (EF:2207-2229); angles from the 3x3 frame as e3nn's xyz_to_angles / angles_to_matrix do
+// (EF:508-517).  Only rows |m| <= M of each block are produced.
+template <int L, int M>
+__global__ void wigner_rows_kernel(const float* __restrict__ rot, float* __restrict__ wr, int E) {
+    using I = SO3Idx<L, M>;
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    int e = tid / I::KR;
+    int r = tid - e * I::KR;
+    if (e >= E) return;
+    const float* R = rot + (long long)e * 9;
+    // x = R * (0,1,0) = second column of R
+    float x0 = R[1], x1 = R[4], x2 = R[7];
+    float nrm = sqrtf(x0 * x0 + x1 * x1 + x2 * x2);
+    nrm = fmaxf(nrm, 1e-12f);
+    x0 = fminf(fmaxf(x0 / nrm, -1.f), 1.f);
+    x1 = fminf(fmaxf(x1 / nrm, -1.f), 1.f);
+    x2 = fminf(fmaxf(x2 / nrm, -1.f), 1.f);
+    float beta = acosf(x1), alpha = atan2f(x0, x2);
+    float ca = cosf(alpha), sa = sinf(alpha), cb = cosf(beta), sb = sinf(beta);
+    // first row of (Ry(alpha) Rx(beta))^T R  ->  gamma = atan2(R'[0][2], R'[0][0])
+    // (Ry Rx) column 0 = (ca, 0, -sa)
+    float r00 = ca * R[0] - sa * R[6];
+    float r02 = ca * R[2] - sa * R[8];
+    float gamma = atan2f(r02, r00);
+    (void)cb;
+    (void)sb;
+    // locate (l, mi) of reduced row r
+    int l = 0, base = 0;
+    while (base + I::nr(l) <= r) {
+        base += I::nr(l);
+        ++l;
+    }
+    int mi = r - base;
+    int n = 2 * l + 1;
+    int i = l - I::mm(l) + mi;  // row inside the (2l+1)x(2l+1) block
+    const float* J = g_J + j_off(l);
+    float fi = (float)(l - i);
+    float ci = cosf(fi * alpha), si = sinf(fi * alpha);
+    float B[2 * L + 1], Cc[2 * L + 1];
+    // A[i,k] = cos(f_i a) J[i,k] + sin(f_i a) J[n-1-i,k]   (centre row: cos term only)
+    // B[i,k] = A[i,k] cos(f_k b) + A[i,n-1-k] sin(f_{n-1-k} b)
+    for (int k = 0; k < n; ++k) {
+        int kk = n - 1 - k;
+        float a_k = ci * J[i * n + k] + ((i != n - 1 - i) ? si * J[(n - 1 - i) * n + k] : 0.f);
+        float a_kk = ci * J[i * n + kk] + ((i != n - 1 - i) ? si * J[(n - 1 - i) * n + kk] : 0.f);
+        float fk = (float)(l - k), fkk = (float)(l - kk);
+        B[k] = a_k * cosf(fk * beta) + ((k != kk) ? a_kk * sinf(fkk * beta) : 0.f);
+    }
+    for (int k = 0; k < n; ++k) {
+        float s = 0.f;
+        for (int j = 0; j < n; ++j) s += B[j] * J[j * n + k];
+        Cc[k] = s;
+    }
+    float* out = wr + (long long)e * I::WSZ + I::w_off(l) + mi * n;
+    for (int k = 0; k < n; ++k) {
+        int kk = n - 1 - k;
+        float fk = (float)(l - k), fkk = (float)(l - kk);
+        out[k] = Cc[k] * cosf(fk * gamma) + ((k != kk) ? Cc[kk] * sinf(fkk * gamma) : 0.f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k3-k6: gather+rotate
+// One wavefront per edge (grid-stride).  Lanes 0..2C-1: channel c of [x_src | x_dst].  MODE 0: forward (out = rotated *
+// rad).  MODE 1: backward w.r.t. rad (g_rad = sum over the +-m rows of g_out * rotated).
+template <int L, int M, int C, int MODE>
+__global__ void __launch_bounds__(64) gather_rotate_kernel(const float* __restrict__ x_src, const float* __restrict__ x_dst,
+                                     const int* __restrict__ src, const int* __restrict__ dst,
+                                     const float* __restrict__ wr, const float* __restrict__ rad,
+                                     const float* __restrict__ g_out, float* __restrict__ out, int E) {
+    using I = SO3Idx<L, M>;
+    const int lane = threadIdx.x;
+    if (lane >= 2 * C) return;
+    for (int e = blockIdx.x; e < E; e += gridDim.x) {
+        const float* W = wr + (long long)e * I::WSZ;
+        const int node = lane < C ? src[e] : dst[e];
+        const float* xin = (lane < C ? x_src : x_dst) + (long long)node * I::K * C + (lane & (C - 1));
+        const long long eo = (long long)e * I::KR * 2 * C + lane;
+        const long long ro = (long long)e * I::RAD_ROWS * 2 * C + lane;
+        float gr[I::RAD_ROWS];
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < I::RAD_ROWS; ++i) gr[i] = 0.f;
+        }
+#pragma unroll
+        for (int l = 0; l <= L; ++l) {
+            float xv[2 * L + 1];
+#pragma unroll
+            for (int j = 0; j < 2 * l + 1; ++j) xv[j] = xin[(l * l + j) * C];
+#pragma unroll
+            for (int mi = 0; mi < I::nr(l); ++mi) {
+                const int m = mi - I::mm(l);
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 2 * l + 1; ++j) acc = fmaf(W[I::w_off(l) + mi * (2 * l + 1) + j], xv[j], acc);
+                if (MODE == 0) {
+                    float rv = rad ? rad[ro + I::rad_row(l, m) * 2 * C] : 1.f;
+                    out[eo + I::mpos(l, m) * 2 * C] = acc * rv;
+                } else {
+                    gr[I::rad_row(l, m)] = fmaf(g_out[eo + I::mpos(l, m) * 2 * C], acc, gr[I::rad_row(l, m)]);
+                }
+            }
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < I::RAD_ROWS; ++i) out[ro + i * 2 * C] = gr[i];
+        }
+    }
+}
+
+// Backward of gather+rotate w.r.t. the node tensors: one wavefront per node, lanes 0..C-1 = channel.
+// SIDE 0: destination nodes, edges row_ptr[n]..row_ptr[n+1] (already contiguous).  SIDE 1: source nodes, edge ids
+// eperm[col_ptr[n]..col_ptr[n+1]].  gx[n, l^2+j, c] = sum_e sum_r W_e[r][j] * g_out[e, r, side*C + c] * rad[e, r, ..].
+template <int L, int M, int C, int SIDE>
+__global__ void __launch_bounds__(64) gather_rotate_bwd_node_kernel(const float* __restrict__ g_out, const float* __restrict__ wr,
+                                              const float* __restrict__ rad, const int* __restrict__ ptr,
+                                              const int* __restrict__ eperm, float* __restrict__ gx, int N) {
+    using I = SO3Idx<L, M>;
+    const int lane = threadIdx.x;
+    if (lane >= C) return;
+    const int co = SIDE == 0 ? C + lane : lane;  // dst half of the 2C channels is [C, 2C)
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        float acc[I::K];
+#pragma unroll
+        for (int k = 0; k < I::K; ++k) acc[k] = 0.f;
+        const int beg = ptr[n], end = ptr[n + 1];
+        for (int i = beg; i < end; ++i) {
+            const int e = SIDE == 0 ? i : eperm[i];
+            const float* W = wr + (long long)e * I::WSZ;
+            const long long eo = (long long)e * I::KR * 2 * C + co;
+            const long long ro = (long long)e * I::RAD_ROWS * 2 * C + co;
+#pragma unroll
+            for (int l = 0; l <= L; ++l) {
+#pragma unroll
+                for (int mi = 0; mi < I::nr(l); ++mi) {
+                    const int m = mi - I::mm(l);
+                    float g = g_out[eo + I::mpos(l, m) * 2 * C];
+                    if (rad) g *= rad[ro + I::rad_row(l, m) * 2 * C];
+#pragma unroll
+                    for (int j = 0; j < 2 * l + 1; ++j)
+                        acc[l * l + j] = fmaf(W[I::w_off(l) + mi * (2 * l + 1) + j], g, acc[l * l + j]);
+                }
+            }
+        }
+        float* o = gx + (long long)n * I::K * C + lane;
+#pragma unroll
+        for (int k = 0; k < I::K; ++k) o[k * C] = acc[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k10: rotate back + scatter
+__host__ __device__ constexpr float rescale_of(int l, int M) {
+    // sqrt((2l+1)/(2M+1)) for l > M, M = 2: sqrt(7/5), sqrt(9/5), sqrt(11/5), sqrt(13/5), ... (EF:1545)
+    return l <= M ? 1.0f
+                  : (l == 3 ? 1.1832159566199232f
+                            : (l == 4 ? 1.3416407864998738f
+                                      : (l == 5 ? 1.4832396974191326f : (l == 6 ? 1.6124515496597098f : 0.f))));
+}
+
+// One workgroup per destination node; thread = channel (blockDim = 64 or 128 >= CH).  Walks the node's edge
+// segment; per edge: m[r] = alpha * msg[e, r, c]; acc[l^2+j] += W_e[r][j] * m[r].  M0: only the m = 0 rows exist.
+template <int L, int M, bool M0>
+__global__ void rotate_back_scatter_kernel(Segs msg, const float* __restrict__ alpha, const float* __restrict__ wr,
+                                           const int* __restrict__ row_ptr, float* __restrict__ out, int N, int CH,
+                                           int vh, float out_scale) {
+    using I = SO3Idx<L, M>;
+    const int c = threadIdx.x;
+    if (c >= CH) return;
+    const int heads = CH / vh;
+    const int r0 = msg.rows[0], r01 = msg.rows[0] + msg.rows[1];
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        float acc[I::K];
+#pragma unroll
+        for (int k = 0; k < I::K; ++k) acc[k] = 0.f;
+        const int beg = row_ptr[n], end = row_ptr[n + 1];
+        for (int e = beg; e < end; ++e) {
+            const float* W = wr + (long long)e * I::WSZ;
+            const float a = alpha ? alpha[(long long)e * heads + c / vh] : 1.f;
+            const float* b0 = msg.p[0] + (long long)e * msg.ld[0] + c;
+            const float* b1 = M0 ? b0 : msg.p[1] + (long long)e * msg.ld[1] + c - (long long)r0 * CH;
+            const float* b2 = M0 ? b0 : msg.p[2] + (long long)e * msg.ld[2] + c - (long long)r01 * CH;
+#pragma unroll
+            for (int l = 0; l <= L; ++l) {
+#pragma unroll
+                for (int mi = 0; mi < I::nr(l); ++mi) {
+                    const int m = mi - I::mm(l);
+                    if (M0 && m != 0) continue;
+                    const int q = I::mpos(l, m);
+                    const float* bp = q < r0 ? b0 : (q < r01 ? b1 : b2);
+                    const float v = bp[(long long)q * CH] * a;
+#pragma unroll
+                    for (int j = 0; j < 2 * l + 1; ++j)
+                        acc[l * l + j] = fmaf(W[I::w_off(l) + mi * (2 * l + 1) + j], v, acc[l * l + j]);
+                }
+            }
+        }
+        float* o = out + (long long)n * I::K * CH + c;
+#pragma unroll
+        for (int l = 0; l <= L; ++l) {
+#pragma unroll
+            for (int j = 0; j < 2 * l + 1; ++j) o[(long long)(l * l + j) * CH] = acc[l * l + j] * (rescale_of(l, M) * out_scale);
+        }
+    }
+}
+
+// Backward: g[k] = g_out[n,k,c] * rescale * out_scale once per node; per edge t[r] = sum_j W_e[r][j] g[l^2+j];
+// g_msg[e,r,c] = alpha * t[r]; g_alpha_part[e,c] = sum_r msg[e,r,c] * t[r].
+template <int L, int M, bool M0>
+__global__ void rotate_back_scatter_bwd_kernel(const float* __restrict__ g_out, Segs msg, SegsMut gmsg,
+                                               const float* __restrict__ alpha, const float* __restrict__ wr,
+                                               const int* __restrict__ row_ptr, float* __restrict__ g_alpha_part, int N,
+                                               int CH, int vh, float out_scale) {
+    using I = SO3Idx<L, M>;
+    const int c = threadIdx.x;
+    if (c >= CH) return;
+    const int heads = CH / vh;
+    const int r0 = gmsg.rows[0], r01 = gmsg.rows[0] + gmsg.rows[1];
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        float g[I::K];
+        const float* gi = g_out + (long long)n * I::K * CH + c;
+#pragma unroll
+        for (int l = 0; l <= L; ++l) {
+#pragma unroll
+            for (int j = 0; j < 2 * l + 1; ++j) g[l * l + j] = gi[(long long)(l * l + j) * CH] * (rescale_of(l, M) * out_scale);
+        }
+        const int beg = row_ptr[n], end = row_ptr[n + 1];
+        for (int e = beg; e < end; ++e) {
+            const float* W = wr + (long long)e * I::WSZ;
+            const float a = alpha ? alpha[(long long)e * heads + c / vh] : 1.f;
+            const float* b0 = alpha ? msg.p[0] + (long long)e * msg.ld[0] + c : nullptr;
+            const float* b1 = (M0 || !alpha) ? b0 : msg.p[1] + (long long)e * msg.ld[1] + c - (long long)r0 * CH;
+            const float* b2 = (M0 || !alpha) ? b0 : msg.p[2] + (long long)e * msg.ld[2] + c - (long long)r01 * CH;
+            float* o0 = gmsg.p[0] + (long long)e * gmsg.ld[0] + c;
+            float* o1 = M0 ? o0 : gmsg.p[1] + (long long)e * gmsg.ld[1] + c - (long long)r0 * CH;
+            float* o2 = M0 ? o0 : gmsg.p[2] + (long long)e * gmsg.ld[2] + c - (long long)r01 * CH;
+            float part = 0.f;
+#pragma unroll
+            for (int l = 0; l <= L; ++l) {
+#pragma unroll
+                for (int mi = 0; mi < I::nr(l); ++mi) {
+                    const int m = mi - I::mm(l);
+                    if (M0 && m != 0) continue;
+                    const int q = I::mpos(l, m);
+                    float t = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 2 * l + 1; ++j) t = fmaf(W[I::w_off(l) + mi * (2 * l + 1) + j], g[l * l + j], t);
+                    float* op = q < r0 ? o0 : (q < r01 ? o1 : o2);
+                    op[(long long)q * CH] = a * t;
+                    if (alpha) {
+                        const float* bp = q < r0 ? b0 : (q < r01 ? b1 : b2);
+                        part = fmaf(bp[(long long)q * CH], t, part);
+                    }
+                }
+            }
+            if (alpha) g_alpha_part[(long long)e * CH + c] = part;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k9: segment softmax
+__global__ void segment_softmax_fwd_kernel(const float* __restrict__ x, const int* __restrict__ row_ptr,
+                                           float* __restrict__ y, int N, int H, float eps) {
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= N * H) return;
+    int n = tid / H, h = tid - n * H;
+    int beg = row_ptr[n], end = row_ptr[n + 1];
+    if (beg >= end) return;
+    float mx = -INFINITY;
+    for (int e = beg; e < end; ++e) mx = fmaxf(mx, x[(long long)e * H + h]);
+    float s = 0.f;
+    for (int e = beg; e < end; ++e) s += expf(x[(long long)e * H + h] - mx);
+    float inv = 1.0f / (s + eps);
+    for (int e = beg; e < end; ++e) y[(long long)e * H + h] = expf(x[(long long)e * H + h] - mx) * inv;
+}
+
+// y = ex / (S + eps);  dx = y * (gy - sum_seg(gy * y))   (exact for eps = 0; for eps = 1e-16 the ratio S/(S+eps)
+// differs from 1 by < 1e-16 since S >= 1, below fp32 resolution).
+__global__ void segment_softmax_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy,
+                                           const int* __restrict__ row_ptr, float* __restrict__ gx, int N, int H) {
+    int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= N * H) return;
+    int n = tid / H, h = tid - n * H;
+    int beg = row_ptr[n], end = row_ptr[n + 1];
+    float dot = 0.f;
+    for (int e = beg; e < end; ++e) dot = fmaf(gy[(long long)e * H + h], y[(long long)e * H + h], dot);
+    for (int e = beg; e < end; ++e) {
+        long long i = (long long)e * H + h;
+        gx[i] = y[i] * (gy[i] - dot);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k15: weighted segment sum
+// out[n, t] = sum_e w[e, t / F] * v[e, t];  one workgroup per node, thread t in [0, H*F).
+__global__ void segment_wsum_fwd_kernel(const float* __restrict__ w, const float* __restrict__ v,
+                                        const int* __restrict__ row_ptr, float* __restrict__ out, int N, int H, int F) {
+    const int t = threadIdx.x;
+    const int HF = H * F;
+    if (t >= HF) return;
+    const int h = t / F;
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        int beg = row_ptr[n], end = row_ptr[n + 1];
+        float acc = 0.f;
+        for (int e = beg; e < end; ++e) acc = fmaf(w[(long long)e * H + h], v[(long long)e * HF + t], acc);
+        out[(long long)n * HF + t] = acc;
+    }
+}
+
+// gv[e,t] = w[e,h] * g[n,t];  gw[e,h] = sum_{t in head h} v[e,t] * g[n,t]  (F = 64: one wavefront per head, reduced
+// with DPP/shuffle butterflies).
+__global__ void segment_wsum_bwd_kernel(const float* __restrict__ g_out, const float* __restrict__ w,
+                                        const float* __restrict__ v, const int* __restrict__ row_ptr,
+                                        float* __restrict__ gw, float* __restrict__ gv, int N, int H, int F) {
+    const int t = threadIdx.x;
+    const int HF = H * F;
+    const int h = t / F;
+    const bool act = t < HF;
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        int beg = row_ptr[n], end = row_ptr[n + 1];
+        float g = act ? g_out[(long long)n * HF + t] : 0.f;
+        for (int e = beg; e < end; ++e) {
+            float p = 0.f;
+            if (act) {
+                gv[(long long)e * HF + t] = w[(long long)e * H + h] * g;
+                p = v[(long long)e * HF + t] * g;
+            }
+            // reduce p over the F lanes of this head (F is a power of two <= 64 and divides 64)
+            for (int o = F >> 1; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
+            if (act && (t % F) == 0) gw[(long long)e * H + h] = p;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k8: S2 activation
+// thread = (edge-or-node e, channel c).  x rows in registers; loop over the G grid points with the two grid-matrix
+// rows as wave-uniform scalars: u = to[g,:].x, s = SiLU(u), y += from[g,:] * s.  Row 0 of the result is SiLU(gate).
+template <int KIN>
+__global__ void __launch_bounds__(256) s2act_fwd_kernel(Segs x, const float* __restrict__ gate, long long ldg,
+                                                        const float* __restrict__ to_grid,
+                                                        const float* __restrict__ from_grid, float* __restrict__ out,
+                                                        long long EC, int C, int G) {
+    long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= EC) return;
+    long long e = tid / C;
+    int c = (int)(tid - e * C);
+    const int r0 = x.rows[0], r01 = x.rows[0] + x.rows[1];
+    const float* b0 = x.p[0] + e * x.ld[0] + c;
+    const float* b1 = x.p[1] ? x.p[1] + e * x.ld[1] + c - (long long)r0 * C : b0;
+    const float* b2 = x.p[2] ? x.p[2] + e * x.ld[2] + c - (long long)r01 * C : b0;
+    float xv[KIN], yv[KIN];
+#pragma unroll
+    for (int i = 0; i < KIN; ++i) {
+        const float* bp = i < r0 ? b0 : (i < r01 ? b1 : b2);
+        xv[i] = bp[(long long)i * C];
+        yv[i] = 0.f;
+    }
+    for (int g = 0; g < G; ++g) {
+        const float* tg = to_grid + g * KIN;
+        const float* fg = from_grid + g * KIN;
+        float u = 0.f;
+#pragma unroll
+        for (int i = 0; i < KIN; ++i) u = fmaf(tg[i], xv[i], u);
+        float s = silu(u);
+#pragma unroll
+        for (int i = 1; i < KIN; ++i) yv[i] = fmaf(fg[i], s, yv[i]);
+    }
+    float* o = out + e * KIN * C + c;
+    o[0] = silu(gate[e * ldg + c]);
+#pragma unroll
+    for (int i = 1; i < KIN; ++i) o[(long long)i * C] = yv[i];
+}
+
+// Backward (recompute u): v = sum_{i>=1} from[g,i] gy[i];  w = v * SiLU'(u);  gx[i] += to[g,i] * w;
+// g_gate = gy[0] * SiLU'(gate).
+template <int KIN>
+__global__ void __launch_bounds__(256) s2act_bwd_kernel(Segs x, const float* __restrict__ gate, long long ldg,
+                                                        const float* __restrict__ to_grid,
+                                                        const float* __restrict__ from_grid,
+                                                        const float* __restrict__ g_out, float* __restrict__ gx,
+                                                        float* __restrict__ g_gate, long long EC, int C, int G) {
+    long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= EC) return;
+    long long e = tid / C;
+    int c = (int)(tid - e * C);
+    const int r0 = x.rows[0], r01 = x.rows[0] + x.rows[1];
+    const float* b0 = x.p[0] + e * x.ld[0] + c;
+    const float* b1 = x.p[1] ? x.p[1] + e * x.ld[1] + c - (long long)r0 * C : b0;
+    const float* b2 = x.p[2] ? x.p[2] + e * x.ld[2] + c - (long long)r01 * C : b0;
+    const float* gi = g_out + e * KIN * C + c;
+    float xv[KIN], gy[KIN], ga[KIN];
+#pragma unroll
+    for (int i = 0; i < KIN; ++i) {
+        const float* bp = i < r0 ? b0 : (i < r01 ? b1 : b2);
+        xv[i] = bp[(long long)i * C];
+        gy[i] = gi[(long long)i * C];
+        ga[i] = 0.f;
+    }
+    for (int g = 0; g < G; ++g) {
+        const float* tg = to_grid + g * KIN;
+        const float* fg = from_grid + g * KIN;
+        float u = 0.f, v = 0.f;
+#pragma unroll
+        for (int i = 0; i < KIN; ++i) u = fmaf(tg[i], xv[i], u);
+#pragma unroll
+        for (int i = 1; i < KIN; ++i) v = fmaf(fg[i], gy[i], v);
+        float w = v * silu_grad(u);
+#pragma unroll
+        for (int i = 0; i < KIN; ++i) ga[i] = fmaf(tg[i], w, ga[i]);
+    }
+    float* o = gx + e * KIN * C + c;
+#pragma unroll
+    for (int i = 0; i < KIN; ++i) o[(long long)i * C] = ga[i];
+    g_gate[e * C + c] = gy[0] * silu_grad(gate[e * ldg + c]);
+}
+
+// ------------------------------------------------------------------------------------------------ k12: equivariant RMS norm
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ int degree_of(int k) {
+    int l = 0;
+    while ((l + 1) * (l + 1) <= k) ++l;
+    return l;
+}
+
+// One wavefront per node (grid-stride), C = 16.  Elements idx = lane + 64 t  ->  (k = idx / C, c = idx % C).
+template <int L>
+__global__ void __launch_bounds__(64) rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ weight,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int N,
+                                                         float eps) {
+    constexpr int C = 16, K = (L + 1) * (L + 1), KC = K * C, NT = (KC + 63) / 64;
+    const int lane = threadIdx.x;
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        const float* xi = x + (long long)n * KC;
+        float v[NT];
+        float s0 = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int idx = lane + 64 * t;
+            v[t] = idx < KC ? xi[idx] : 0.f;
+        }
+        if (lane < C) s0 = v[0];
+        float mean0 = wave_sum(s0) * (1.0f / C);
+        if (lane < C) v[0] -= mean0;
+        float ss = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int idx = lane + 64 * t;
+            if (idx < KC) {
+                int l = degree_of(idx / C);
+                ss = fmaf(v[t] * v[t], 1.0f / (float)((2 * l + 1) * (L + 1)), ss);
+            }
+        }
+        float r = rsqrtf(wave_sum(ss) * (1.0f / C) + eps);
+        float* yo = y + (long long)n * KC;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int idx = lane + 64 * t;
+            if (idx < KC) {
+                int k = idx / C, c = idx - k * C;
+                float o = v[t] * r * weight[degree_of(k) * C + c];
+                if (k == 0) o += bias[c];
+                yo[idx] = o;
+            }
+        }
+    }
+}
+
+// gx~ = r w g - r^3 S b_k x~ / C  with S = sum(g w x~);  row 0 then loses its channel mean (centering).
+// Per-wave partial parameter grads: gw_part[part, k, c] += g x~ r,  gb_part[part, c] += g[0, c].
+template <int L>
+__global__ void __launch_bounds__(64) rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ weight,
+                                                         const float* __restrict__ gy, float* __restrict__ gx,
+                                                         float* __restrict__ gw_part, float* __restrict__ gb_part, int N,
+                                                         float eps) {
+    constexpr int C = 16, K = (L + 1) * (L + 1), KC = K * C, NT = (KC + 63) / 64;
+    const int lane = threadIdx.x;
+    float gwp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) gwp[t] = 0.f;
+    float gbp = 0.f;
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        const float* xi = x + (long long)n * KC;
+        const float* gi = gy + (long long)n * KC;
+        float v[NT], g[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int idx = lane + 64 * t;
+            v[t] = idx < KC ? xi[idx] : 0.f;
+            g[t] = idx < KC ? gi[idx] : 0.f;
+        }
+        float mean0 = wave_sum(lane < C ? v[0] : 0.f) * (1.0f / C);
+        if (lane < C) v[0] -= mean0;
+        float ss = 0.f, S = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int idx = lane + 64 * t;
+            if (idx < KC) {
+                int k = idx / C, c = idx - k * C;
+                int l = degree_of(k);
+                ss = fmaf(v[t] * v[t], 1.0f / (float)((2 * l + 1) * (L + 1)), ss);
+                S = fmaf(g[t] * weight[l * C + c], v[t], S);
+            }
+        }
+        float r = rsqrtf(wave_sum(ss) * (1.0f / C) + eps);
+        S = wave_sum(S);
+        float r3s = r * r * r * S * (1.0f / C);
+        float d0 = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int idx = lane + 64 * t;
+            if (idx < KC) {
+                int k = idx / C, c = idx - k * C;
+                int l = degree_of(k);
+                float bk = 1.0f / (float)((2 * l + 1) * (L + 1));
+                gwp[t] = fmaf(g[t] * v[t], r, gwp[t]);
+                float d = r * weight[l * C + c] * g[t] - r3s * bk * v[t];
+                if (t == 0 && lane < C) {
+                    d0 = d;
+                    gbp += g[t];
+                }
+                g[t] = d;
+            }
+        }
+        float dm = wave_sum(lane < C ? d0 : 0.f) * (1.0f / C);
+        if (lane < C) g[0] -= dm;
+        float* go = gx + (long long)n * KC;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int idx = lane + 64 * t;
+            if (idx < KC) go[idx] = g[t];
+        }
+    }
+    float* wp = gw_part + (long long)blockIdx.x * KC;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int idx = lane + 64 * t;
+        if (idx < KC) wp[idx] = gwp[t];
+    }
+    if (lane < C) gb_part[(long long)blockIdx.x * C + lane] = gbp;
+}
+
+// ------------------------------------------------------------------------------------------------ host helpers
+int grid_for(long long work, int cap = 256 * 32) {
+    long long g = work < 1 ? 1 : work;
+    return (int)(g > cap ? cap : g);
+}
+
+bool pack(const singa_seg_t* s, int nseg, Segs* out) {
+    if (!s || nseg < 1 || nseg > 3) return false;
+    for (int i = 0; i < 3; ++i) {
+        out->p[i] = i < nseg ? s[i].ptr : nullptr;
+        out->ld[i] = i < nseg ? s[i].ld : 0;
+        out->rows[i] = i < nseg ? s[i].rows : 0;
+        if (i < nseg && !s[i].ptr) return false;
+    }
+    return true;
+}
+
+bool pack_mut(const singa_seg_mut_t* s, int nseg, SegsMut* out) {
+    if (!s || nseg < 1 || nseg > 3) return false;
+    for (int i = 0; i < 3; ++i) {
+        out->p[i] = i < nseg ? s[i].ptr : nullptr;
+        out->ld[i] = i < nseg ? s[i].ld : 0;
+        out->rows[i] = i < nseg ? s[i].rows : 0;
+        if (i < nseg && !s[i].ptr) return false;
+    }
+    return true;
+}
+
+#define SINGA_DISPATCH_L(lmax, mmax, ...)                                             \
+    do {                                                                                \
+        if ((mmax) != 2) return fail(SINGA_E_LMAX, "only mmax = 2 is built");           \
+        switch (lmax) {                                                                 \
+            case 2: { constexpr int L_ = 2; __VA_ARGS__; } break;                              \
+            case 4: { constexpr int L_ = 4; __VA_ARGS__; } break;                              \
+            case 6: { constexpr int L_ = 6; __VA_ARGS__; } break;                              \
+            default: return fail(SINGA_E_LMAX, "lmax must be 2, 4 or 6");               \
+        }                                                                               \
+    } while (0)
+
+}  // namespace
+
+// ================================================================================================= C ABI
+extern "C" {
+
+int singa_version(void) { return 100; }
+
+const char* singa_last_error_string(void) { return g_err; }
+
+int singa_init(const double* jd_flat, int lmax_max) {
+    if (!jd_flat) return fail(SINGA_E_NULL, "singa_init: jd_flat is null");
+    if (lmax_max < 0 || lmax_max > 11) return fail(SINGA_E_LMAX, "singa_init: lmax_max must be in [0, 11]");
+    static float host[MAX_J];
+    int n = j_off(lmax_max + 1);
+    for (int i = 0; i < n; ++i) host[i] = (float)jd_flat[i];
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_J), host, n * sizeof(float), 0, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "singa_init: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    g_lmax_init = lmax_max;
+    return SINGA_OK;
+}
+
+int singa_dims(int lmax, int mmax, int* kr, int* wsz, int* rad_rows) {
+    SINGA_DISPATCH_L(lmax, mmax, {
+        using I = SO3Idx<L_, 2>;
+        if (kr) *kr = I::KR;
+        if (wsz) *wsz = I::WSZ;
+        if (rad_rows) *rad_rows = I::RAD_ROWS;
+    });
+    return SINGA_OK;
+}
+
+int singa_wigner_rows(const float* rot, float* wr, int E, int lmax, int mmax, void* stream) {
+    if (!rot || !wr) return fail(SINGA_E_NULL, "wigner_rows: null pointer");
+    if (g_lmax_init < lmax) return fail(SINGA_E_NOINIT, "wigner_rows: singa_init not called for this lmax");
+    if (E <= 0) return SINGA_OK;
+    SINGA_DISPATCH_L(lmax, mmax, {
+        using I = SO3Idx<L_, 2>;
+        long long total = (long long)E * I::KR;
+        int blocks = (int)((total + 255) / 256);
+        hipLaunchKernelGGL((wigner_rows_kernel<L_, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, rot, wr, E);
+    });
+    return check_launch("wigner_rows");
+}
+
+int singa_gather_rotate_fwd(const float* x_src, const float* x_dst, const int32_t* src, const int32_t* dst,
+                            const float* wr, const float* rad, float* out, int E, int C, int lmax, int mmax,
+                            void* stream) {
+    if (!x_src || !x_dst || !src || !dst || !wr || !out) return fail(SINGA_E_NULL, "gather_rotate_fwd: null pointer");
+    if (C != 16) return fail(SINGA_E_SHAPE, "gather_rotate: built for C = 16 sphere channels");
+    if (E <= 0) return SINGA_OK;
+    SINGA_DISPATCH_L(lmax, mmax, {
+        hipLaunchKernelGGL((gather_rotate_kernel<L_, 2, 16, 0>), dim3(grid_for(E)), dim3(64), 0, (hipStream_t)stream,
+                           x_src, x_dst, src, dst, wr, rad, (const float*)nullptr, out, E);
+    });
+    return check_launch("gather_rotate_fwd");
+}
+
+int singa_gather_rotate_bwd(const float* g_out, const float* x_src, const float* x_dst, const int32_t* src,
+                            const int32_t* dst, const float* wr, const float* rad, const int32_t* row_ptr,
+                            const int32_t* col_ptr, const int32_t* eperm, float* g_rad, float* gx_src, float* gx_dst,
+                            int E, int Ns, int Nd, int C, int lmax, int mmax, void* stream) {
+    if (!g_out || !x_src || !x_dst || !src || !dst || !wr || !row_ptr || !col_ptr || !eperm || !gx_src || !gx_dst)
+        return fail(SINGA_E_NULL, "gather_rotate_bwd: null pointer");
+    if (g_rad && !rad) return fail(SINGA_E_NULL, "gather_rotate_bwd: g_rad requested without rad");
+    if (C != 16) return fail(SINGA_E_SHAPE, "gather_rotate: built for C = 16 sphere channels");
+    SINGA_DISPATCH_L(lmax, mmax, {
+        hipStream_t st = (hipStream_t)stream;
+        if (g_rad && E > 0)
+            hipLaunchKernelGGL((gather_rotate_kernel<L_, 2, 16, 1>), dim3(grid_for(E)), dim3(64), 0, st, x_src, x_dst,
+                               src, dst, wr, rad, g_out, g_rad, E);
+        if (Nd > 0)
+            hipLaunchKernelGGL((gather_rotate_bwd_node_kernel<L_, 2, 16, 0>), dim3(grid_for(Nd)), dim3(64), 0, st,
+                               g_out, wr, rad, row_ptr, (const int*)nullptr, gx_dst, Nd);
+        if (Ns > 0)
+            hipLaunchKernelGGL((gather_rotate_bwd_node_kernel<L_, 2, 16, 1>), dim3(grid_for(Ns)), dim3(64), 0, st,
+                               g_out, wr, rad, col_ptr, eperm, gx_src, Ns);
+    });
+    return check_launch("gather_rotate_bwd");
+}
+
+int singa_rotate_back_scatter_fwd(const singa_seg_t* msg, int nseg, const float* alpha, const float* wr,
+                                  const int32_t* row_ptr, float* out, int Nd, int CH, int heads, int lmax, int mmax,
+                                  int m0_only, float out_scale, void* stream) {
+    Segs s;
+    if (!pack(msg, nseg, &s) || !wr || !row_ptr || !out) return fail(SINGA_E_NULL, "rotate_back_scatter_fwd: null pointer");
+    if (CH < 1 || CH > 128 || heads < 1 || CH % heads) return fail(SINGA_E_SHAPE, "rotate_back_scatter: CH must be <= 128 and divisible by heads");
+    if (!m0_only && nseg != 3) return fail(SINGA_E_SHAPE, "rotate_back_scatter: full mode takes the 3 per-m segments");
+    if (Nd <= 0) return SINGA_OK;
+    int bs = CH <= 64 ? 64 : 128;
+    SINGA_DISPATCH_L(lmax, mmax, {
+        if (!m0_only && (s.rows[0] != L_ + 1 || s.rows[1] != 2 * L_ || s.rows[2] != 2 * (L_ - 1)))
+            return fail(SINGA_E_SHAPE, "rotate_back_scatter: segment row counts must be L+1, 2L, 2(L-1)");
+        if (m0_only)
+            hipLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, true>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
+                               (hipStream_t)stream, s, alpha, wr, row_ptr, out, Nd, CH, CH / heads, out_scale);
+        else
+            hipLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, false>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
+                               (hipStream_t)stream, s, alpha, wr, row_ptr, out, Nd, CH, CH / heads, out_scale);
+    });
+    return check_launch("rotate_back_scatter_fwd");
+}
+
+int singa_rotate_back_scatter_bwd(const float* g_out, const singa_seg_t* msg, const singa_seg_mut_t* g_msg, int nseg,
+                                  const float* alpha, const float* wr, const int32_t* row_ptr, float* g_alpha_part,
+                                  int Nd, int CH, int heads, int lmax, int mmax, int m0_only, float out_scale,
+                                  void* stream) {
+    Segs s;
+    SegsMut gm;
+    memset(&s, 0, sizeof(s));
+    if (!g_out || !pack_mut(g_msg, nseg, &gm) || !wr || !row_ptr) return fail(SINGA_E_NULL, "rotate_back_scatter_bwd: null pointer");
+    if (alpha && (!pack(msg, nseg, &s) || !g_alpha_part)) return fail(SINGA_E_NULL, "rotate_back_scatter_bwd: alpha given without msg / g_alpha_part");
+    if (CH < 1 || CH > 128 || heads < 1 || CH % heads) return fail(SINGA_E_SHAPE, "rotate_back_scatter: CH must be <= 128 and divisible by heads");
+    if (!m0_only && nseg != 3) return fail(SINGA_E_SHAPE, "rotate_back_scatter: full mode takes the 3 per-m segments");
+    if (Nd <= 0) return SINGA_OK;
+    int bs = CH <= 64 ? 64 : 128;
+    SINGA_DISPATCH_L(lmax, mmax, {
+        if (!m0_only && (gm.rows[0] != L_ + 1 || gm.rows[1] != 2 * L_ || gm.rows[2] != 2 * (L_ - 1)))
+            return fail(SINGA_E_SHAPE, "rotate_back_scatter: segment row counts must be L+1, 2L, 2(L-1)");
+        if (m0_only)
+            hipLaunchKernelGGL((rotate_back_scatter_bwd_kernel<L_, 2, true>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
+                               (hipStream_t)stream, g_out, s, gm, alpha, wr, row_ptr, g_alpha_part, Nd, CH, CH / heads,
+                               out_scale);
+        else
+            hipLaunchKernelGGL((rotate_back_scatter_bwd_kernel<L_, 2, false>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
+                               (hipStream_t)stream, g_out, s, gm, alpha, wr, row_ptr, g_alpha_part, Nd, CH, CH / heads,
+                               out_scale);
+    });
+    return check_launch("rotate_back_scatter_bwd");
+}
+
+int singa_segment_softmax_fwd(const float* x, const int32_t* row_ptr, float* out, int N, int H, float eps,
+                              void* stream) {
+    if (!x || !row_ptr || !out) return fail(SINGA_E_NULL, "segment_softmax_fwd: null pointer");
+    if (N <= 0 || H <= 0) return SINGA_OK;
+    int blocks = (int)(((long long)N * H + 255) / 256);
+    hipLaunchKernelGGL(segment_softmax_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, row_ptr, out, N,
+                       H, eps);
+    return check_launch("segment_softmax_fwd");
+}
+
+int singa_segment_softmax_bwd(const float* y, const float* gy, const int32_t* row_ptr, float* gx, int N, int H,
+                              void* stream) {
+    if (!y || !gy || !row_ptr || !gx) return fail(SINGA_E_NULL, "segment_softmax_bwd: null pointer");
+    if (N <= 0 || H <= 0) return SINGA_OK;
+    int blocks = (int)(((long long)N * H + 255) / 256);
+    hipLaunchKernelGGL(segment_softmax_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, gy, row_ptr, gx,
+                       N, H);
+    return check_launch("segment_softmax_bwd");
+}
+
+int singa_segment_wsum_fwd(const float* w, const float* v, const int32_t* row_ptr, float* out, int N, int H, int F,
+                           void* stream) {
+    if (!w || !v || !row_ptr || !out) return fail(SINGA_E_NULL, "segment_wsum_fwd: null pointer");
+    if (H * F > 1024 || H < 1 || F < 1) return fail(SINGA_E_SHAPE, "segment_wsum: H*F must be <= 1024");
+    if (N <= 0) return SINGA_OK;
+    int bs = ((H * F + 63) / 64) * 64;
+    hipLaunchKernelGGL(segment_wsum_fwd_kernel, dim3(grid_for(N, 1 << 20)), dim3(bs), 0, (hipStream_t)stream, w, v,
+                       row_ptr, out, N, H, F);
+    return check_launch("segment_wsum_fwd");
+}
+
+int singa_segment_wsum_bwd(const float* g_out, const float* w, const float* v, const int32_t* row_ptr, float* gw,
+                           float* gv, int N, int H, int F, void* stream) {
+    if (!g_out || !w || !v || !row_ptr || !gw || !gv) return fail(SINGA_E_NULL, "segment_wsum_bwd: null pointer");
+    if (H * F > 1024 || H < 1 || F < 1 || F > 64 || (F & (F - 1))) return fail(SINGA_E_SHAPE, "segment_wsum_bwd: F must be a power of two <= 64");
+    if (N <= 0) return SINGA_OK;
+    int bs = ((H * F + 63) / 64) * 64;
+    hipLaunchKernelGGL(segment_wsum_bwd_kernel, dim3(grid_for(N, 1 << 20)), dim3(bs), 0, (hipStream_t)stream, g_out, w,
+                       v, row_ptr, gw, gv, N, H, F);
+    return check_launch("segment_wsum_bwd");
+}
+
+#define SINGA_DISPATCH_KIN(kin, ...)                                                        \
+    switch (kin) {                                                                            \
+        case 9: { constexpr int KIN_ = 9; __VA_ARGS__; } break;                                      \
+        case 19: { constexpr int KIN_ = 19; __VA_ARGS__; } break;                                    \
+        case 25: { constexpr int KIN_ = 25; __VA_ARGS__; } break;                                    \
+        case 29: { constexpr int KIN_ = 29; __VA_ARGS__; } break;                                    \
+        case 49: { constexpr int KIN_ = 49; __VA_ARGS__; } break;                                    \
+        default: return fail(SINGA_E_SHAPE, "s2act: KIN must be one of 9, 19, 25, 29, 49");   \
+    }
+
+int singa_s2act_fwd(const singa_seg_t* x, int nseg, const float* gate, int64_t ldg, const float* to_grid,
+                    const float* from_grid, float* out, int E, int C, int KIN, int G, void* stream) {
+    Segs s;
+    if (!pack(x, nseg, &s) || !gate || !to_grid || !from_grid || !out) return fail(SINGA_E_NULL, "s2act_fwd: null pointer");
+    if (s.rows[0] + s.rows[1] + s.rows[2] != KIN) return fail(SINGA_E_SHAPE, "s2act: segment rows must sum to KIN");
+    if (E <= 0) return SINGA_OK;
+    long long EC = (long long)E * C;
+    int blocks = (int)((EC + 255) / 256);
+    SINGA_DISPATCH_KIN(KIN, hipLaunchKernelGGL((s2act_fwd_kernel<KIN_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                                               s, gate, (long long)ldg, to_grid, from_grid, out, EC, C, G));
+    return check_launch("s2act_fwd");
+}
+
+int singa_s2act_bwd(const singa_seg_t* x, int nseg, const float* gate, int64_t ldg, const float* to_grid,
+                    const float* from_grid, const float* g_out, float* gx, float* g_gate, int E, int C, int KIN,
+                    int G, void* stream) {
+    Segs s;
+    if (!pack(x, nseg, &s) || !gate || !to_grid || !from_grid || !g_out || !gx || !g_gate)
+        return fail(SINGA_E_NULL, "s2act_bwd: null pointer");
+    if (s.rows[0] + s.rows[1] + s.rows[2] != KIN) return fail(SINGA_E_SHAPE, "s2act: segment rows must sum to KIN");
+    if (E <= 0) return SINGA_OK;
+    long long EC = (long long)E * C;
+    int blocks = (int)((EC + 255) / 256);
+    SINGA_DISPATCH_KIN(KIN, hipLaunchKernelGGL((s2act_bwd_kernel<KIN_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                                               s, gate, (long long)ldg, to_grid, from_grid, g_out, gx, g_gate, EC, C, G));
+    return check_launch("s2act_bwd");
+}
+
+int singa_so3_rmsnorm_nparts(int N) { return grid_for(N, 2048); }
+
+int singa_so3_rmsnorm_fwd(const float* x, const float* weight, const float* bias, float* y, int N, int C, int lmax,
+                          float eps, void* stream) {
+    if (!x || !weight || !bias || !y) return fail(SINGA_E_NULL, "so3_rmsnorm_fwd: null pointer");
+    if (C != 16) return fail(SINGA_E_SHAPE, "so3_rmsnorm: built for C = 16 sphere channels");
+    if (N <= 0) return SINGA_OK;
+    SINGA_DISPATCH_L(lmax, 2, hipLaunchKernelGGL((rmsnorm_fwd_kernel<L_>), dim3(grid_for(N)), dim3(64), 0,
+                                                 (hipStream_t)stream, x, weight, bias, y, N, eps));
+    return check_launch("so3_rmsnorm_fwd");
+}
+
+int singa_so3_rmsnorm_bwd(const float* x, const float* weight, const float* gy, float* gx, float* gw_part,
+                          float* gb_part, int N, int C, int lmax, float eps, void* stream) {
+    if (!x || !weight || !gy || !gx || !gw_part || !gb_part) return fail(SINGA_E_NULL, "so3_rmsnorm_bwd: null pointer");
+    if (C != 16) return fail(SINGA_E_SHAPE, "so3_rmsnorm: built for C = 16 sphere channels");
+    if (N <= 0) return SINGA_OK;
+    SINGA_DISPATCH_L(lmax, 2, hipLaunchKernelGGL((rmsnorm_bwd_kernel<L_>), dim3(singa_so3_rmsnorm_nparts(N)), dim3(64),
+                                                 0, (hipStream_t)stream, x, weight, gy, gx, gw_part, gb_part, N, eps));
+    return check_launch("so3_rmsnorm_bwd");
+}
+
+}  // extern "C"

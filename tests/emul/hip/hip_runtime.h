@@ -1,0 +1,53 @@
+// TEST-ONLY stand-in for <hip/hip_runtime.h>: lets tests/test_kernels_emul.py compile singa_amd/csrc/singa_hip.hip with
+// g++ (-I tests/emul) and run each kernel's exact source on the CPU, thread by thread, so that index algebra and
+// bounds can be checked (and sanitised) in the GPU-less build container.  Never part of the product: the shipped
+// library is built by hipcc for gfx950 only.  Kernels that use cross-lane intrinsics (__shfl_xor) cannot be emulated
+// sequentially and abort here; they are covered by the -m gpu tests.
+#pragma once
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define HIP_SYMBOL(x) x
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}
+};
+static thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipMemcpyHostToDevice = 1 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "emul"; }
+template <class T>
+static inline hipError_t hipMemcpyToSymbol(T& sym, const void* src, size_t n, size_t off, int) {
+    memcpy((char*)&sym + off, src, n);
+    return hipSuccess;
+}
+#define __expf(x) expf(x)
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline float __shfl_xor(float, int, int) {
+    fprintf(stderr, "emul: cross-lane kernel cannot be emulated sequentially\n");
+    abort();
+}
+
+#define hipLaunchKernelGGL(kern, g, b, shmem, stream, ...)                  \
+    do {                                                                    \
+        dim3 _g = (g), _b = (b);                                            \
+        gridDim = _g;                                                       \
+        blockDim = _b;                                                      \
+        for (unsigned _bx = 0; _bx < _g.x; ++_bx)                           \
+            for (unsigned _tx = 0; _tx < _b.x; ++_tx) {                     \
+                blockIdx.x = _bx;                                           \
+                threadIdx.x = _tx;                                          \
+                kern(__VA_ARGS__);                                          \
+            }                                                               \
+    } while (0)

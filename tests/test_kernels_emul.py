@@ -1,0 +1,244 @@
+"""CPU pre-flight of the HIP kernels: singa_amd/csrc/singa_hip.hip is compiled with g++ against tests/emul (a
+sequential stand-in for the HIP runtime) and every kernel without cross-lane intrinsics is run thread by thread and
+compared with the oracle.  This checks index algebra, segment handling and bounds in the GPU-less container; the
+same comparisons run against the real gfx950 build in tests/test_kernels_gpu.py (-m gpu)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import singa_oracle as O
+from oracle import so3_tables as T
+from singa_amd import _capi, so3
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emul(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("emul") / "libsinga_emul.so")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-x", "c++", "-I",
+                           os.path.join(ROOT, "tests", "emul"), "-o", out,
+                           os.path.join(ROOT, "singa_amd", "csrc", "singa_hip.hip")])
+    lib = _capi.bind(out)
+    jd = np.ascontiguousarray(so3.jd_flat(6))
+    assert lib.singa_init(jd.ctypes.data_as(ctypes.c_void_p), 6) == 0
+    return lib
+
+
+def ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None else None
+
+
+def iptr(a):
+    return a.ctypes.data
+
+
+def rand_graph(rs, n_src, n_dst, E):
+    dst = np.sort(rs.randint(0, n_dst, E)).astype(np.int32)
+    src = rs.randint(0, n_src, E).astype(np.int32)
+    row_ptr = np.zeros(n_dst + 1, np.int32)
+    np.add.at(row_ptr, dst + 1, 1)
+    row_ptr = np.cumsum(row_ptr).astype(np.int32)
+    eperm = np.argsort(src, kind="stable").astype(np.int32)
+    col_ptr = np.zeros(n_src + 1, np.int32)
+    np.add.at(col_ptr, src + 1, 1)
+    col_ptr = np.cumsum(col_ptr).astype(np.int32)
+    return src, dst, row_ptr, col_ptr, eperm
+
+
+def rand_rot(rs, E):
+    v = torch.tensor(rs.randn(E, 3), dtype=torch.float32)
+    return O.edge_rot_mat(v, torch.tensor(rs.rand(E, 3), dtype=torch.float32))
+
+
+def reduced_rows(w, L, M=2):
+    """dense [E,K,K] Wigner -> [E,WSZ] reduced-row records."""
+    out = []
+    for l in range(L + 1):
+        mm = min(l, M)
+        out.append(w[:, l * l + l - mm: l * l + l + mm + 1, l * l:(l + 1) ** 2].reshape(w.shape[0], -1))
+    return torch.cat(out, 1)
+
+
+def rad_row_index(lay):
+    idx, off = [np.arange(lay.m_size[0])], lay.m_size[0]
+    for s in lay.m_size[1:]:
+        idx += [off + np.arange(s), off + np.arange(s)]
+        off += s
+    return np.concatenate(idx)
+
+
+@pytest.mark.parametrize("L", [2, 4, 6])
+def test_wigner_rows(emul, L):
+    rs = np.random.RandomState(L)
+    E = 23
+    rot = rand_rot(rs, E)
+    lay = so3.layout(L, 2)
+    wr = np.zeros((E, lay.WSZ), np.float32)
+    assert emul.singa_wigner_rows(ptr(rot.numpy()), ptr(wr), E, L, 2, None) == 0
+    ref = reduced_rows(O.wigner_dense(rot, L), L).numpy()
+    assert np.abs(wr - ref).max() < 2e-5
+
+
+@pytest.mark.parametrize("L", [2, 4, 6])
+def test_gather_rotate(emul, L):
+    rs = np.random.RandomState(10 + L)
+    C, Ns, Nd, E = 16, 9, 7, 31
+    lay = so3.layout(L, 2)
+    src, dst, row_ptr, col_ptr, eperm = rand_graph(rs, Ns, Nd, E)
+    rot = rand_rot(rs, E)
+    fr = O.Frame(rot, L, 2)
+    wr = reduced_rows(O.wigner_dense(rot, L), L).numpy().copy()
+    xs = torch.tensor(rs.randn(Ns, lay.K, C), dtype=torch.float32, requires_grad=True)
+    xd = torch.tensor(rs.randn(Nd, lay.K, C), dtype=torch.float32, requires_grad=True)
+    rad = torch.tensor(rs.randn(E, lay.rad_rows, 2 * C), dtype=torch.float32, requires_grad=True)
+    ridx = torch.as_tensor(rad_row_index(lay))
+    ref = torch.bmm(fr.fwd, torch.cat([xs[src.astype(np.int64)], xd[dst.astype(np.int64)]], 2))[:, fr.to_m] * rad[:, ridx]
+    out = np.zeros((E, lay.KR, 2 * C), np.float32)
+    assert emul.singa_gather_rotate_fwd(ptr(xs.detach().numpy()), ptr(xd.detach().numpy()), ptr(src), ptr(dst), ptr(wr),
+                                        ptr(rad.detach().numpy()), ptr(out), E, C, L, 2, None) == 0
+    assert np.abs(out - ref.detach().numpy()).max() < 1e-4
+    g = torch.tensor(rs.randn(*out.shape), dtype=torch.float32)
+    ref.backward(g)
+    g_rad = np.zeros((E, lay.rad_rows, 2 * C), np.float32)
+    gxs = np.full((Ns, lay.K, C), np.nan, np.float32)
+    gxd = np.full((Nd, lay.K, C), np.nan, np.float32)
+    code = emul.singa_gather_rotate_bwd(ptr(g.numpy()), ptr(xs.detach().numpy()), ptr(xd.detach().numpy()), ptr(src),
+                                        ptr(dst), ptr(wr), ptr(rad.detach().numpy()), ptr(row_ptr), ptr(col_ptr),
+                                        ptr(eperm), ptr(g_rad), ptr(gxs), ptr(gxd), E, Ns, Nd, C, L, 2, None)
+    assert code == 0
+    assert np.abs(g_rad - rad.grad.numpy()).max() < 2e-4
+    assert np.abs(gxs - xs.grad.numpy()).max() < 2e-4
+    assert np.abs(gxd - xd.grad.numpy()).max() < 2e-4
+
+
+@pytest.mark.parametrize("L,CH,heads,m0", [(2, 112, 7, 0), (4, 112, 7, 0), (6, 112, 7, 0), (6, 16, 1, 1), (2, 16, 1, 1)])
+def test_rotate_back_scatter(emul, L, CH, heads, m0):
+    rs = np.random.RandomState(20 + L + m0)
+    Nd, E = 8, 29
+    lay = so3.layout(L, 2)
+    _, dst, row_ptr, _, _ = rand_graph(rs, 5, Nd, E)
+    rot = rand_rot(rs, E)
+    fr = O.Frame(rot, L, 2)
+    wr = reduced_rows(O.wigner_dense(rot, L), L).numpy().copy()
+    scale = 0.37 if m0 else 1.0
+    rows = lay.seg_rows if not m0 else [lay.m_size[0]]
+    parts = [torch.tensor(rs.randn(E, r * CH), dtype=torch.float32, requires_grad=True) for r in rows]
+    alpha = None if m0 else torch.tensor(rs.rand(E, heads), dtype=torch.float32, requires_grad=True)
+    msg_m = torch.cat([p.view(E, -1, CH) for p in parts], 1)
+    if m0:
+        msg_m = torch.cat([msg_m, msg_m.new_zeros(E, lay.KR - rows[0], CH)], 1)
+    msg_l = msg_m[:, fr.to_l]
+    if alpha is not None:
+        msg_l = (msg_l.view(E, lay.KR, heads, CH // heads) * alpha.view(E, 1, heads, 1)).reshape(E, lay.KR, CH)
+    ref = O.seg_sum(torch.bmm(fr.inv, msg_l), torch.as_tensor(dst.astype(np.int64)), Nd) * scale
+    seg_in, n = _capi.segs([(iptr(p.detach().numpy()), r * CH, r) for p, r in zip(parts, rows)])
+    out = np.full((Nd, lay.K, CH), np.nan, np.float32)
+    code = emul.singa_rotate_back_scatter_fwd(seg_in, n, ptr(alpha.detach().numpy()) if alpha is not None else None,
+                                              ptr(wr), ptr(row_ptr), ptr(out), Nd, CH, heads, L, 2, m0, scale, None)
+    assert code == 0, emul.singa_last_error_string()
+    assert np.abs(out - ref.detach().numpy()).max() < 2e-4
+    g = torch.tensor(rs.randn(*out.shape), dtype=torch.float32)
+    ref.backward(g)
+    gparts = [np.full((E, r * CH), np.nan, np.float32) for r in rows]
+    seg_out, _ = _capi.segs([(iptr(p), r * CH, r) for p, r in zip(gparts, rows)])
+    gap = np.zeros((E, CH), np.float32)
+    code = emul.singa_rotate_back_scatter_bwd(ptr(g.numpy()), seg_in, seg_out, n,
+                                              ptr(alpha.detach().numpy()) if alpha is not None else None, ptr(wr),
+                                              ptr(row_ptr), ptr(gap) if alpha is not None else None, Nd, CH, heads, L, 2,
+                                              m0, scale, None)
+    assert code == 0, emul.singa_last_error_string()
+    for gp, p in zip(gparts, parts):
+        assert np.abs(gp - p.grad.numpy()).max() < 2e-4
+    if alpha is not None:
+        assert np.abs(gap.reshape(E, heads, -1).sum(-1) - alpha.grad.numpy()).max() < 5e-4
+
+
+@pytest.mark.parametrize("H,eps", [(7, 1e-16), (4, 0.0)])
+def test_segment_softmax(emul, H, eps):
+    rs = np.random.RandomState(3)
+    N, E = 9, 40
+    _, dst, row_ptr, _, _ = rand_graph(rs, 3, N, E)
+    x = torch.tensor(rs.randn(E, H) * 3, dtype=torch.float32, requires_grad=True)
+    ref = O.seg_softmax(x, torch.as_tensor(dst.astype(np.int64)), N, eps)
+    y = np.zeros((E, H), np.float32)
+    assert emul.singa_segment_softmax_fwd(ptr(x.detach().numpy()), ptr(row_ptr), ptr(y), N, H, eps, None) == 0
+    assert np.abs(y - ref.detach().numpy()).max() < 1e-6
+    g = torch.tensor(rs.randn(E, H), dtype=torch.float32)
+    ref.backward(g)
+    gx = np.zeros((E, H), np.float32)
+    assert emul.singa_segment_softmax_bwd(ptr(y), ptr(g.numpy()), ptr(row_ptr), ptr(gx), N, H, None) == 0
+    assert np.abs(gx - x.grad.numpy()).max() < 1e-5
+
+
+@pytest.mark.parametrize("L,M,C,edge", [(2, 2, 128, True), (4, 2, 128, True), (6, 2, 128, True), (4, 4, 512, False),
+                                        (6, 6, 512, False), (2, 2, 512, False)])
+def test_s2act(emul, L, M, C, edge):
+    """attention flavour: m-primary rows in three strided segments (the SO(2)-conv GEMM outputs, gate inside the
+    m=0 buffer); FFN flavour: one contiguous l-primary [N,K,C] tensor."""
+    rs = np.random.RandomState(L * 10 + M)
+    E = 5
+    lay = so3.layout(L, M)
+    to, fr_ = so3.s2_grid(L, M)
+    G, KIN = to.shape
+    if edge:
+        to_k, fr_k = to[:, lay.to_m], fr_[:, lay.to_m]
+        extra = 96
+        h0 = torch.tensor(rs.randn(E, extra + C + lay.seg_rows[0] * C), dtype=torch.float32, requires_grad=True)
+        h1 = torch.tensor(rs.randn(E, lay.seg_rows[1] * C), dtype=torch.float32, requires_grad=True)
+        h2 = torch.tensor(rs.randn(E, lay.seg_rows[2] * C), dtype=torch.float32, requires_grad=True)
+        gate = h0[:, extra:extra + C]
+        xm = torch.cat([h0[:, extra + C:].view(E, -1, C), h1.view(E, -1, C), h2.view(E, -1, C)], 1)
+        to_l = torch.as_tensor(np.argsort(lay.to_m))
+        ref = O.sep_s2_act(gate, xm[:, to_l], L, M)[:, torch.as_tensor(lay.to_m)]
+        base = h0.detach().numpy()
+        items = [(iptr(base) + 4 * (extra + C), base.shape[1], lay.seg_rows[0]),
+                 (iptr(h1.detach().numpy()), h1.shape[1], lay.seg_rows[1]),
+                 (iptr(h2.detach().numpy()), h2.shape[1], lay.seg_rows[2])]
+        gate_ptr, ldg = iptr(base) + 4 * extra, base.shape[1]
+    else:
+        to_k, fr_k = to, fr_
+        x = torch.tensor(rs.randn(E, KIN, C), dtype=torch.float32, requires_grad=True)
+        gt = torch.tensor(rs.randn(E, C), dtype=torch.float32, requires_grad=True)
+        ref = O.sep_s2_act(gt, x, L, M)
+        items = [(iptr(x.detach().numpy()), KIN * C, KIN)]
+        gate_ptr, ldg = iptr(gt.detach().numpy()), C
+    to32 = np.ascontiguousarray(to_k, np.float32)
+    fr32 = np.ascontiguousarray(fr_k, np.float32)
+    seg, n = _capi.segs(items)
+    out = np.full((E, KIN, C), np.nan, np.float32)
+    code = emul.singa_s2act_fwd(seg, n, gate_ptr, ldg, ptr(to32), ptr(fr32), ptr(out), E, C, KIN, G, None)
+    assert code == 0, emul.singa_last_error_string()
+    assert np.abs(out - ref.detach().numpy()).max() < 3e-5 * max(1.0, float(ref.abs().max()))
+    g = torch.tensor(rs.randn(E, KIN, C), dtype=torch.float32)
+    ref.backward(g)
+    gx = np.full((E, KIN, C), np.nan, np.float32)
+    gg = np.full((E, C), np.nan, np.float32)
+    code = emul.singa_s2act_bwd(seg, n, gate_ptr, ldg, ptr(to32), ptr(fr32), ptr(g.numpy()), ptr(gx), ptr(gg), E, C, KIN,
+                                G, None)
+    assert code == 0
+    if edge:
+        want = torch.cat([h0.grad[:, extra + C:].view(E, -1, C), h1.grad.view(E, -1, C), h2.grad.view(E, -1, C)], 1)
+        want_g = h0.grad[:, extra:extra + C]
+    else:
+        want, want_g = x.grad, gt.grad
+    tol = 1e-4 * max(1.0, float(want.abs().max()))
+    assert np.abs(gx - want.numpy()).max() < tol
+    assert np.abs(gg - want_g.numpy()).max() < 1e-5
+
+
+def test_argument_errors(emul):
+    assert emul.singa_wigner_rows(None, None, 4, 6, 2, None) == -1
+    a = np.zeros(16, np.float32)
+    assert emul.singa_wigner_rows(ptr(a), ptr(a), 1, 5, 2, None) == -2
+    assert emul.singa_wigner_rows(ptr(a), ptr(a), 1, 6, 3, None) == -2
+    assert b"lmax" in emul.singa_last_error_string() or b"mmax" in emul.singa_last_error_string()
+    kr, wsz, rr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    for L in (2, 4, 6):
+        assert emul.singa_dims(L, 2, ctypes.byref(kr), ctypes.byref(wsz), ctypes.byref(rr)) == 0
+        lay = so3.layout(L, 2)
+        assert (kr.value, wsz.value, rr.value) == (lay.KR, lay.WSZ, lay.rad_rows)
