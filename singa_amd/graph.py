@@ -1,0 +1,209 @@
+"""Protein-ligand hetero-graph containers for the hot path, with the PyG `HeteroData` access pattern the reference
+uses (`g['protein_atoms']['x']`, `g[('protein_atoms','linked_to','protein_atoms')]['edge_index']`,
+`g['atomicnum'][...]`, `g['ligand_data'][...]`; reference model/Embedding.py:227-230, model/GAN.py:26-49) but without
+torch_geometric.  Also: PyG-style collate, the synthetic CrossDocked-like generator of SURVEY.md §8d,
+a deterministic per-graph Laplacian positional encoding, and a loader for the golden graph fixtures.
+"""
+import numpy as np
+import torch
+
+PA, LA = "protein_atoms", "ligand_atoms"
+E_PP, E_LL = (PA, "linked_to", PA), (LA, "linked_to", LA)
+E_LP, E_PL = (LA, "interact_with", PA), (PA, "interact_with", LA)
+PAD_TOKEN, START_TOKEN, END_TOKEN = 110, 2, 1
+
+
+class _Store(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+def _map(v, fn):
+    if torch.is_tensor(v):
+        return fn(v)
+    if isinstance(v, dict):
+        return type(v)((k, _map(x, fn)) for k, x in v.items())
+    return v
+
+
+class HeteroGraph:
+    """One graph or a collated batch.  Node stores: x [N,59], pos [N,3] (+ ptr, batch, lap_pe after collate);
+    edge stores: edge_index [2,E] int64; globals: atomicnum {type: [N] int64}, ligand_data {...}.
+    Optional inputs pinned for parity: `rot_rand[(etype)]` = the uniform draws of init_edge_rot_mat (Q6) or
+    `edge_rot_mat[...]`, and `knn[node_type]` = the raw kNN edge lists of the CProMG encoders (tie order)."""
+
+    def __init__(self):
+        self.nodes = {PA: _Store(), LA: _Store()}
+        self.edges = {E_PP: _Store(), E_LL: _Store(), E_LP: _Store(), E_PL: _Store()}
+        self.globals = _Store(atomicnum={}, ligand_data={})
+        self.extras = _Store()
+        self.num_graphs = 1
+
+    def __getitem__(self, key):
+        if isinstance(key, tuple):
+            return self.edges[key]
+        if key in self.nodes:
+            return self.nodes[key]
+        return self.globals[key]
+
+    def to(self, device):
+        fn = lambda t: t.to(device, non_blocking=True)
+        self.nodes = {k: _map(v, fn) for k, v in self.nodes.items()}
+        self.edges = {k: _map(v, fn) for k, v in self.edges.items()}
+        self.globals = _map(self.globals, fn)
+        self.extras = _map(self.extras, fn)
+        return self
+
+
+def collate(graphs):
+    """PyG collate of HeteroData: concat node tensors, offset edge_index by the cumulative node counts
+    of (source type, destination type), `ptr`/`batch` per node type, ligand_data floats -> 1-D tensors."""
+    out = HeteroGraph()
+    out.num_graphs = len(graphs)
+    ptr = {}
+    for nt in (PA, LA):
+        sizes = [g[nt]["x"].shape[0] for g in graphs]
+        ptr[nt] = torch.tensor([0] + sizes).cumsum(0)
+        for k in graphs[0][nt]:
+            out.nodes[nt][k] = torch.cat([g[nt][k] for g in graphs], 0)
+        out.nodes[nt]["ptr"] = ptr[nt]
+        out.nodes[nt]["batch"] = torch.repeat_interleave(torch.arange(len(graphs)), torch.tensor(sizes))
+        out.globals["atomicnum"][nt] = torch.cat([g["atomicnum"][nt] for g in graphs], 0)
+    for et in (E_PP, E_LL, E_LP, E_PL):
+        off = [torch.stack([ptr[et[0]][i], ptr[et[2]][i]]).view(2, 1) for i in range(len(graphs))]
+        out.edges[et]["edge_index"] = torch.cat([g[et]["edge_index"] + off[i] for i, g in enumerate(graphs)], 1)
+    ld0 = graphs[0]["ligand_data"]
+    for k in ld0:
+        vals = [g["ligand_data"][k] for g in graphs]
+        out.globals["ligand_data"][k] = torch.cat(vals, 0) if torch.is_tensor(vals[0]) else torch.tensor(
+            vals, dtype=torch.float64)
+    for name in ("rot_rand", "edge_rot_mat"):
+        if name in graphs[0].extras:
+            out.extras[name] = {k: torch.cat([g.extras[name][k] for g in graphs], 0) for k in graphs[0].extras[name]}
+    return out
+
+
+def laplacian_pe(edge_index, n, k=8):
+    """Deterministic Laplacian positional encoding of ONE graph: the k eigenvectors after the smallest of
+    I - D^-1/2 A D^-1/2 (in-degree clipped at 1), symmetric eigensolver, sign fixed by making the entry of largest
+    magnitude positive.  (dgl.lap_pe, reference model/CProMG.py:562-571, uses random signs on the whole batched
+    graph - not reproducible, so at our boundary the encoding is an input)"""
+    a = np.zeros((n, n))
+    ei = np.asarray(edge_index)
+    a[ei[0], ei[1]] = 1.0
+    dinv = np.clip(a.sum(0), 1, None) ** -0.5
+    lap = np.eye(n) - dinv[:, None] * a * dinv[None, :]
+    _, v = np.linalg.eigh(0.5 * (lap + lap.T))
+    v = v[:, 1:k + 1]
+    if v.shape[1] < k:
+        v = np.concatenate([v, np.zeros((n, k - v.shape[1]))], 1)
+    idx = np.argmax(np.abs(v), axis=0)
+    sign = np.where(v[idx, np.arange(v.shape[1])] < 0, -1.0, 1.0)
+    return torch.tensor(v * sign, dtype=torch.float32)
+
+
+def from_arrays(d, with_lap=True):
+    """Build a HeteroGraph from the arrays of a tests/golden/graph_*.npz fixture (or the synthetic generator)."""
+    g = HeteroGraph()
+    t = lambda a, dt=None: torch.as_tensor(np.asarray(a), dtype=dt)
+    for nt, s in ((PA, "p"), (LA, "l")):
+        g.nodes[nt]["x"] = t(d[f"x_{s}"], torch.float32)
+        g.nodes[nt]["pos"] = t(d[f"pos_{s}"], torch.float32)
+        g.globals["atomicnum"][nt] = t(d[f"z_{s}"], torch.int64)
+    for et, s in ((E_PP, "pp"), (E_LL, "ll"), (E_LP, "lp"), (E_PL, "pl")):
+        g.edges[et]["edge_index"] = t(d[f"ei_{s}"], torch.int64)
+    vina, qed, sas = (float(v) for v in np.asarray(d["props"]))
+    g.globals["ligand_data"] = dict(vina_score=vina, qed=qed, sas=sas, logP=0.0, weight=0.0, tpsa=0.0,
+                                    smiIndices_input=t(d["tok_in"], torch.int64).view(1, -1),
+                                    smiIndices_tgt=t(d["tok_tgt"], torch.int64).view(1, -1))
+    if with_lap:
+        g.nodes[PA]["lap_pe"] = laplacian_pe(g.edges[E_PP]["edge_index"].numpy(), g.nodes[PA]["x"].shape[0])
+        g.nodes[LA]["lap_pe"] = laplacian_pe(g.edges[E_LL]["edge_index"].numpy(), g.nodes[LA]["x"].shape[0])
+    return g
+
+
+def load_npz(path, with_lap=True):
+    z = np.load(path)
+    return from_arrays({k: z[k] for k in z.files}, with_lap)
+
+
+# ----------------------------------------------------------------------------------------------- synthetic graphs
+def _closest_pairs(pa, pb, count, same):
+    d = np.linalg.norm(pa[:, None, :] - pb[None, :, :], axis=-1)
+    if same:
+        iu = np.triu_indices(pa.shape[0], 1)
+        order = np.argsort(d[iu], kind="stable")[:count]
+        return iu[0][order], iu[1][order]
+    flat = np.argsort(d.reshape(-1), kind="stable")[:count]
+    return flat // pb.shape[0], flat % pb.shape[0]
+
+
+def synthetic_graph(graph_id, n_protein=200, n_ligand=30, e_pp=1700, e_ll=64, e_x=118, tgt_len=200):
+    """One random protein-ligand hetero-graph with the bundled files' schema (SURVEY.md §8d 'Synthetic generator'):
+    rng = default_rng(1000 + graph_id); protein atoms uniform in a cube of density 0.05 A^-3 with min pair distance
+    1.0 A; ligand atoms inside a 6 A sphere at the centre; linked_to = the e/2 closest pairs in both directions;
+    interact_with = the e_x closest ligand-protein pairs, PL = LP mirrored in the same order (Q5)."""
+    rng = np.random.default_rng(1000 + graph_id)
+    side = (n_protein / 0.05) ** (1.0 / 3.0)
+
+    def place(n, draw, others):
+        pts = []
+        while len(pts) < n:
+            cand = draw()
+            ref = pts + others
+            if not ref or np.min(np.linalg.norm(np.asarray(ref) - cand, axis=1)) >= 1.0:
+                pts.append(cand)
+        return pts
+
+    def lig_draw():
+        while True:
+            c = rng.uniform(-6, 6, 3)
+            if np.linalg.norm(c) <= 6.0:
+                return c + side / 2
+    lig = place(n_ligand, lig_draw, [])
+    pro = place(n_protein, lambda: rng.uniform(0, side, 3), lig)
+    pos_p, pos_l = np.asarray(pro, np.float32), np.asarray(lig, np.float32)
+
+    def feats(n):
+        x = np.zeros((n, 59), np.float32)
+        z = rng.choice([6, 7, 8, 16], size=n, p=[0.65, 0.15, 0.17, 0.03])
+        x[np.arange(n), rng.integers(0, 44, n)] = 1.0
+        x[:, -15:] = (rng.random((n, 15)) < 0.2).astype(np.float32)
+        x[:, 51] = rng.uniform(-0.3, 0.3, n)
+        return x, z.astype(np.int64)
+    x_p, z_p = feats(n_protein)
+    x_l, z_l = feats(n_ligand)
+    a, b = _closest_pairs(pos_p, pos_p, e_pp // 2, True)
+    ei_pp = np.stack([np.concatenate([a, b]), np.concatenate([b, a])])
+    a, b = _closest_pairs(pos_l, pos_l, e_ll // 2, True)
+    ei_ll = np.stack([np.concatenate([a, b]), np.concatenate([b, a])])
+    li, pj = _closest_pairs(pos_l, pos_p, e_x, False)
+    ei_lp = np.stack([li, pj])
+    ei_pl = np.stack([pj, li])
+    n_tok = int(rng.integers(20, 61))
+    body = rng.integers(3, 116, n_tok)
+    tok_in = np.full(tgt_len, PAD_TOKEN, np.int64)
+    tok_tgt = np.full(tgt_len, PAD_TOKEN, np.int64)
+    tok_in[0], tok_in[1:1 + n_tok] = START_TOKEN, body
+    tok_tgt[:n_tok], tok_tgt[n_tok] = body, END_TOKEN
+    props = np.array([rng.uniform(-10, -5), rng.uniform(0.3, 0.9), rng.uniform(2, 6)])
+    g = from_arrays(dict(x_p=x_p, pos_p=pos_p, z_p=z_p, x_l=x_l, pos_l=pos_l, z_l=z_l, ei_pp=ei_pp, ei_ll=ei_ll,
+                         ei_lp=ei_lp, ei_pl=ei_pl, props=props, tok_in=tok_in, tok_tgt=tok_tgt))
+    g.extras["rot_rand"] = {k: torch.tensor(rng.random((n, 3)), dtype=torch.float32)
+                            for k, n in (("pp", ei_pp.shape[1]), ("ll", ei_ll.shape[1]), ("lp", ei_lp.shape[1]))}
+    return g
+
+
+WORKLOADS = {
+    # SURVEY.md §8d configs 2, 3 (fixed-size variant), 5
+    "cfg2_b32_l2": dict(n_graphs=32, lmax=2, n_protein=200, n_ligand=30, e_pp=1700, e_ll=64, e_x=118),
+    "cfg3_b128_l4": dict(n_graphs=128, lmax=4, n_protein=350, n_ligand=30, e_pp=700, e_ll=66, e_x=80),
+    "cfg5_l6": dict(n_graphs=64, lmax=6, n_protein=800, n_ligand=40, e_pp=7600, e_ll=88, e_x=156),
+}
+
+
+def synthetic_batch(n_graphs, first_id=0, **kw):
+    return collate([synthetic_graph(first_id + i, **kw) for i in range(n_graphs)])

@@ -1,0 +1,380 @@
+"""CProMG transformer for MI355X (reference model/CProMG.py = "CP"): kNN-graph attention encoders for protein and
+ligand atoms, cross-attention at layers 2 and 5, causal SMILES decoder, vocabulary projection.
+
+Same class names, constructor arguments and parameter names as the reference.  Differences inside:
+  * graph construction (kNN, to_undirected(mean), Gaussian smearing, get_laplacian; CP:293-298) is done with
+    batched tensor ops on the GPU and the edges are kept sorted by centre node, so that
+  * scatter_softmax / scatter_sum (CP:66,74) are the segmented HIP kernels (ops.segment_softmax / segment_wsum);
+  * grouped 1x1 Conv1d and position-wise Conv1d layers are evaluated as GEMMs on their own weights;
+  * the causal mask is built on the device (the reference builds it with numpy on the host, CP:507-514).
+Dense projections and attention matmuls are library GEMMs (MFMA via hipBLASLt).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn import BatchNorm1d, Conv1d, Dropout, Embedding, LayerNorm, Linear, Sequential
+
+from .. import ops
+
+
+class ShiftedSoftplus(nn.Module):
+    def __init__(self, device="cuda"):
+        super().__init__()
+        self.shift = math.log(2.0)
+
+    def forward(self, x):
+        return F.softplus(x) - self.shift
+
+
+class GaussianSmearing(nn.Module):
+    def __init__(self, start=0.0, stop=10.0, num_gaussians=50, device="cuda"):
+        super().__init__()
+        offset = torch.linspace(start, stop, num_gaussians, device=device)
+        self.coeff = -0.5 / (offset[1] - offset[0]).item() ** 2
+        self.register_buffer("offset", offset)
+
+    def forward(self, dist):
+        dist = dist.view(-1, 1) - self.offset.view(1, -1)
+        return torch.exp(self.coeff * torch.pow(dist, 2))
+
+
+# ----------------------------------------------------------------------------------------------- graph helpers (GPU)
+def to_dense_batch(x, batch, batch_size):
+    num = torch.bincount(batch, minlength=batch_size)
+    mx = int(num.max())
+    start = num.cumsum(0) - num
+    idx = torch.arange(batch.numel(), device=x.device) - start[batch] + batch * mx
+    out = x.new_zeros((batch_size * mx,) + tuple(x.shape[1:]))
+    out[idx] = x
+    mask = torch.zeros(batch_size * mx, dtype=torch.bool, device=x.device)
+    mask[idx] = True
+    return out.view(batch_size, mx, *x.shape[1:]), mask.view(batch_size, mx), idx
+
+
+def knn_graph(pos, k, batch, batch_size):
+    """For every node its k nearest other nodes of the same graph, row = centre (torch_cluster.knn_graph with
+    flow='target_to_source', CP:293,330).  Dense per-graph distance matrices on the GPU."""
+    dense, mask, idx = to_dense_batch(pos, batch, batch_size)
+    mx = dense.shape[1]
+    d = torch.cdist(dense, dense)
+    d = d.masked_fill(~mask.unsqueeze(1), float("inf"))
+    d = d + torch.diag_embed(torch.full((mx,), float("inf"), device=pos.device)).unsqueeze(0)
+    kk = min(k, mx - 1)
+    dist, nb = d.topk(kk, dim=2, largest=False)
+    node_of = torch.full((batch_size * mx,), -1, dtype=torch.long, device=pos.device)
+    node_of[idx] = torch.arange(pos.shape[0], device=pos.device)
+    node_of = node_of.view(batch_size, mx)
+    centre = node_of.unsqueeze(2).expand(-1, -1, kk)
+    neigh = torch.gather(node_of.unsqueeze(1).expand(-1, mx, -1), 2, nb)
+    ok = torch.isfinite(dist) & (centre >= 0)
+    return torch.stack([centre[ok], neigh[ok]], 0)
+
+
+class KnnEdges:
+    """CP:295-298 on a raw kNN edge list: edge lengths, to_undirected(reduce='mean'), Gaussian smearing and
+    get_laplacian (self-loops appended; 2-D weights, Q12), then sorted by centre node -> CSR row_ptr."""
+
+    def __init__(self, pos, knn_ei, smear):
+        N = pos.shape[0]
+        ln = (pos[knn_ei[0]] - pos[knn_ei[1]]).norm(dim=1)
+        r = torch.cat([knn_ei[0], knn_ei[1]])
+        c = torch.cat([knn_ei[1], knn_ei[0]])
+        key, inv, cnt = torch.unique(r * N + c, sorted=True, return_inverse=True, return_counts=True)
+        ln = torch.zeros(key.numel(), device=pos.device).index_add_(0, inv, torch.cat([ln, ln])) / cnt
+        row, col = key // N, key % N
+        ea = smear(ln)
+        deg = torch.zeros(N, ea.shape[1], device=pos.device).index_add_(0, row, ea)
+        loop = torch.arange(N, device=pos.device)
+        row, col = torch.cat([row, loop]), torch.cat([col, loop])
+        attr = torch.cat([-ea, deg], 0)
+        order = torch.argsort(row, stable=True)
+        self.row, self.col, self.attr = row[order], col[order], attr[order]
+        rp = torch.zeros(N + 1, dtype=torch.int64, device=pos.device)
+        rp[1:] = torch.bincount(self.row, minlength=N).cumsum(0)
+        self.row_ptr = rp.to(torch.int32)
+        self.N = N
+
+
+# ----------------------------------------------------------------------------------------------- attention modules
+class MultiHeadAttention(nn.Module):
+    """Graph attention over the kNN edges (CP:19-78)."""
+
+    def __init__(self, hidden_channels, edge_channels, key_channels, num_heads=1, device="cuda"):
+        super().__init__()
+        assert hidden_channels % num_heads == 0 and key_channels % num_heads == 0
+        self.num_heads = num_heads
+        self.k_lin = Conv1d(hidden_channels, key_channels, 1, groups=num_heads, bias=False, device=device)
+        self.q_lin = Conv1d(hidden_channels, key_channels, 1, groups=num_heads, bias=False, device=device)
+        self.v_lin = Conv1d(hidden_channels, hidden_channels, 1, groups=num_heads, bias=False, device=device)
+        kh, vh = key_channels // num_heads, hidden_channels // num_heads
+        self.weight_k_net = Sequential(Linear(edge_channels, kh, device=device), ShiftedSoftplus(), Linear(kh, kh, device=device))
+        self.weight_k_lin = Linear(kh, kh, device=device)
+        self.weight_v_net = Sequential(Linear(edge_channels, vh, device=device), ShiftedSoftplus(), Linear(vh, vh, device=device))
+        self.weight_v_lin = Linear(vh, vh, device=device)
+        self.centroid_lin = Linear(hidden_channels, hidden_channels, device=device)
+        self.act = ShiftedSoftplus()
+        self.out_transform = Linear(hidden_channels, hidden_channels, device=device)
+        self.layer_norm = LayerNorm(hidden_channels, device=device)
+
+    def _grouped(self, conv, h):
+        N, heads = h.shape[0], self.num_heads
+        w = conv.weight[:, :, 0]
+        og, ig = w.shape[0] // heads, w.shape[1]
+        return torch.bmm(h.view(N, heads, ig).transpose(0, 1), w.view(heads, og, ig).transpose(1, 2)).transpose(0, 1)
+
+    def forward(self, node_attr, edges: KnnEdges):
+        N = node_attr.size(0)
+        h_keys, h_queries, h_values = (self._grouped(c, node_attr) for c in (self.k_lin, self.q_lin, self.v_lin))
+        W_k = self.weight_k_net(edges.attr)
+        keys_j = self.weight_k_lin(W_k.unsqueeze(1) * h_keys[edges.col])
+        qk_ij = (h_queries[edges.row] * keys_j).sum(-1) / np.sqrt(keys_j.size(-1))
+        alpha = ops.segment_softmax(qk_ij, edges.row_ptr, 0.0)
+        W_v = self.weight_v_net(edges.attr)
+        msg_j = self.weight_v_lin(W_v.unsqueeze(1) * h_values[edges.col])
+        aggr_msg = ops.segment_wsum(alpha, msg_j, edges.row_ptr).view(N, -1)
+        out = self.centroid_lin(node_attr) + aggr_msg
+        return self.layer_norm(self.out_transform(self.act(out)))
+
+
+def _dense_attention(module, Q, K, V, attn_mask, key_channels, hidden_channels):
+    B, heads = Q.size(0), module.num_heads
+    q_s = module.W_Q(Q).view(B, -1, heads, key_channels // heads).transpose(1, 2)
+    k_s = module.W_K(K).view(B, -1, heads, key_channels // heads).transpose(1, 2)
+    v_s = module.W_V(V).view(B, -1, heads, hidden_channels // heads).transpose(1, 2)
+    scores = torch.matmul(q_s, k_s.transpose(-1, -2)) / np.sqrt(q_s.size(-1))
+    scores = scores.masked_fill(attn_mask.unsqueeze(1), -1e9)
+    context = torch.matmul(torch.softmax(scores, dim=-1), v_s)
+    context = context.transpose(1, 2).contiguous().view(B, -1, hidden_channels)
+    return module.layer_norm(module.linear(context) + Q)
+
+
+class MultiHeadAttention2(nn.Module):
+    """Dense cross-attention ligand atoms -> protein atoms (CP:81-105)."""
+
+    def __init__(self, hidden_channels, key_channels, num_heads, device="cuda"):
+        super().__init__()
+        self.hidden_channls, self.keys_channels, self.num_heads = hidden_channels, key_channels, num_heads
+        self.W_Q = Linear(hidden_channels, key_channels, device=device)
+        self.W_K = Linear(hidden_channels, key_channels, device=device)
+        self.W_V = Linear(hidden_channels, hidden_channels, device=device)
+        self.linear = Linear(hidden_channels, hidden_channels, device=device)
+        self.layer_norm = LayerNorm(hidden_channels, device=device)
+
+    def forward(self, Q, K, V, attn_mask):
+        return _dense_attention(self, Q, K, V, attn_mask, self.keys_channels, self.hidden_channls)
+
+
+class MultiHeadDeAttention(nn.Module):
+    """Decoder self / encoder-decoder attention (CP:134-158)."""
+
+    def __init__(self, hidden_channels, key_channels, num_heads, device="cuda"):
+        super().__init__()
+        self.hidden_channels, self.key_channels, self.num_heads = hidden_channels, key_channels, num_heads
+        self.W_Q = Linear(hidden_channels, key_channels, device=device)
+        self.W_K = Linear(hidden_channels, key_channels, device=device)
+        self.W_V = Linear(hidden_channels, hidden_channels, device=device)
+        self.linear = Linear(hidden_channels, hidden_channels, device=device)
+        self.layer_norm = LayerNorm(hidden_channels, device=device)
+
+    def forward(self, Q, K, V, attn_mask):
+        return _dense_attention(self, Q, K, V, attn_mask, self.key_channels, self.hidden_channels)
+
+
+class PoswiseFeedForwardNet(nn.Module):
+    """1x1 Conv1d pair + residual LayerNorm on node rows (CP:161-176); batch_norm exists but is never called (Q10)."""
+
+    def __init__(self, hidden_channels, device="cuda"):
+        super().__init__()
+        self.conv1 = Conv1d(hidden_channels, 1024, 1, device=device)
+        self.conv2 = Conv1d(1024, hidden_channels, 1, device=device)
+        self.layer_norm = LayerNorm(hidden_channels, device=device)
+        self.batch_norm = BatchNorm1d(hidden_channels, device=device)
+
+    def forward(self, inputs):
+        h = F.relu(F.linear(inputs, self.conv1.weight[:, :, 0], self.conv1.bias))
+        return self.layer_norm(F.linear(h, self.conv2.weight[:, :, 0], self.conv2.bias) + inputs)
+
+
+class PoswiseFeedForwardDeNet(nn.Module):
+    def __init__(self, hidden_channels, device="cuda"):
+        super().__init__()
+        self.conv1 = Conv1d(hidden_channels, 1024, 1, device=device)
+        self.conv2 = Conv1d(1024, hidden_channels, 1, device=device)
+        self.layer_norm = LayerNorm(hidden_channels, device=device)
+
+    def forward(self, inputs):
+        h = F.relu(F.linear(inputs, self.conv1.weight[:, :, 0], self.conv1.bias))
+        return self.layer_norm(F.linear(h, self.conv2.weight[:, :, 0], self.conv2.bias) + inputs)
+
+
+class PositionalEncoding(nn.Module):
+    def __init__(self, d_model, dropout=0.1, max_len=5000, device="cuda"):
+        super().__init__()
+        self.dropout = Dropout(p=dropout)
+        pe = torch.zeros(max_len, d_model)
+        position = torch.arange(0, max_len, dtype=torch.float).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2).float() * (-math.log(10000.0) / d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe.unsqueeze(0).transpose(0, 1).to(device))
+
+    def forward(self, x):
+        """x: [seq_len, batch, d_model]"""
+        return self.dropout(x + self.pe[: x.size(0), :])
+
+
+# ----------------------------------------------------------------------------------------------- encoder / decoder
+class EncoderLayer(nn.Module):
+    def __init__(self, config, device="cuda"):
+        super().__init__()
+        self.enc_self_attn = MultiHeadAttention(config.hidden_channels, config.edge_channels, config.key_channels,
+                                                config.num_heads, device=device)
+        self.pos_ffn = PoswiseFeedForwardNet(config.hidden_channels, device=device)
+
+    def forward(self, node_attr, edges):
+        msa_outputs = self.enc_self_attn(node_attr, edges)
+        return msa_outputs, self.pos_ffn(msa_outputs)
+
+
+class EncoderLayer2(nn.Module):
+    def __init__(self, config, device="cuda"):
+        super().__init__()
+        self.enc_self_attn = MultiHeadAttention(config.hidden_channels, config.edge_channels, config.key_channels,
+                                                config.num_heads, device=device)
+        self.proj = Linear(config.hidden_channels, config.hidden_channels, device=device)
+        self.cross_attn = MultiHeadAttention2(config.hidden_channels, config.key_channels, config.num_heads, device=device)
+        self.layer_norm = LayerNorm(config.hidden_channels, device=device)
+        self.pos_ffn = PoswiseFeedForwardNet(config.hidden_channels, device=device)
+
+    def forward(self, node_attr, edges, idx, atom_msa_outputs, atom_mask, batch, batch_size):
+        msa_outputs = self.enc_self_attn(node_attr, edges)
+        if idx == 2 or idx == 5:                                                   # CP:262
+            kv = self.proj(atom_msa_outputs[idx])
+            dense, _, flat_idx = to_dense_batch(msa_outputs, batch, batch_size)
+            cross = self.cross_attn(dense, kv, kv, atom_mask)
+            msa_outputs = self.layer_norm(msa_outputs + cross.reshape(-1, cross.size(-1))[flat_idx])
+        return self.pos_ffn(msa_outputs)
+
+
+class Encoder(nn.Module):
+    def __init__(self, config, protein_atom_feature_dim, device="cuda"):
+        super().__init__()
+        self.config = config
+        self.protein_atom_emb = Linear(protein_atom_feature_dim, config.hidden_channels, device=device)
+        self.laplacian_emb = Linear(config.lap_dim, config.hidden_channels, device=device)
+        self.layers = nn.ModuleList([EncoderLayer(config, device=device) for _ in range(config.num_interactions)])
+        self.distance_expansion = GaussianSmearing(stop=15, num_gaussians=config.edge_channels, device=device)
+        self.out = Linear(config.hidden_channels, config.hidden_channels, device=device)       # unused (Q10)
+        self.layer_norm = LayerNorm(config.hidden_channels, device=device)                      # unused (Q10)
+
+    def forward(self, protein_atom_feature, pos, batch, atom_laplacian, batch_size=None, knn=None):
+        B = int(batch.max()) + 1 if batch_size is None else batch_size
+        node_attr = self.protein_atom_emb(protein_atom_feature) + self.laplacian_emb(atom_laplacian)
+        if knn is None:
+            knn = knn_graph(pos, self.config.knn, batch, B)
+        edges = KnnEdges(pos, knn, self.distance_expansion)
+        msa_outputs1 = []
+        for layer in self.layers:
+            msa_outputs, node_attr = layer(node_attr, edges)
+            msa_outputs1.append(to_dense_batch(msa_outputs, batch, B)[0])
+        enc_outputs1, mask, _ = to_dense_batch(node_attr, batch, B)
+        return enc_outputs1, ~mask.unsqueeze(1), msa_outputs1
+
+
+class Encoder2(nn.Module):
+    def __init__(self, config, aa_feature_dim, device="cuda"):
+        super().__init__()
+        self.config = config
+        self.aa_emb = Linear(aa_feature_dim, config.hidden_channels, device=device)
+        self.laplacian_emb = Linear(config.lap_dim, config.hidden_channels, device=device)
+        self.layers = nn.ModuleList([EncoderLayer2(config, device=device) for _ in range(config.num_interactions)])
+        self.distance_expansion = GaussianSmearing(stop=25, num_gaussians=config.edge_channels, device=device)
+        self.out = Linear(config.hidden_channels, config.hidden_channels, device=device)       # unused (Q10)
+        self.layer_norm = LayerNorm(config.hidden_channels, device=device)                      # unused (Q10)
+
+    def forward(self, aa_feature, aa_pos, aa_batch, aa_laplacian, atom_mask, atom_msa_outputs, batch_size=None, knn=None):
+        B = int(aa_batch.max()) + 1 if batch_size is None else batch_size
+        node_attr = self.aa_emb(aa_feature) + self.laplacian_emb(aa_laplacian)
+        if knn is None:
+            knn = knn_graph(aa_pos, 30, aa_batch, B)                               # CP:330
+        edges = KnnEdges(aa_pos, knn, self.distance_expansion)
+        for idx, layer in enumerate(self.layers):
+            node_attr = layer(node_attr, edges, idx, atom_msa_outputs, atom_mask, aa_batch, B)
+        enc_outputs1, mask, _ = to_dense_batch(node_attr, aa_batch, B)
+        return enc_outputs1, ~mask.unsqueeze(1)
+
+
+class DecoderLayer(nn.Module):
+    def __init__(self, config, device="cuda"):
+        super().__init__()
+        self.dec_self_attn = MultiHeadDeAttention(config.hidden_channels, config.key_channels, config.num_heads, device=device)
+        self.dec_enc_attn = MultiHeadDeAttention(config.hidden_channels, config.key_channels, config.num_heads, device=device)
+        self.pos_ffn = PoswiseFeedForwardDeNet(config.hidden_channels, device=device)
+
+    def forward(self, dec_inputs, enc_outputs, dec_self_attn_mask, dec_enc_attn_mask):
+        dec_outputs = self.dec_self_attn(dec_inputs, dec_inputs, dec_inputs, dec_self_attn_mask)
+        dec_outputs = self.dec_enc_attn(dec_outputs, enc_outputs, enc_outputs, dec_enc_attn_mask)
+        return self.pos_ffn(dec_outputs)
+
+
+class Decoder(nn.Module):
+    def __init__(self, config, num_props=None, device="cuda"):
+        super().__init__()
+        self.config, self.device, self.num_props = config, device, num_props
+        self.mol_emb = Embedding(len(config.smiVoc), config.hidden_channels, 0, device=device)
+        self.pos_emb = PositionalEncoding(config.hidden_channels, device=device)
+        self.type_emb = Embedding(2, config.hidden_channels, device=device)
+        if self.num_props:
+            self.prop_nn = Linear(self.num_props, config.hidden_channels, device=device)
+        self.layers = nn.ModuleList([DecoderLayer(config, device=device) for _ in range(config.num_interactions)])
+        self.pad_id = list(config.smiVoc).index("^")
+
+    def forward(self, smiles_index, enc_outputs, enc_pad_mask, tgt_len, prop=None):
+        b, t = smiles_index.size()
+        dev = smiles_index.device
+        dec_inputs = self.mol_emb(smiles_index)
+        dec_inputs = self.pos_emb(dec_inputs.transpose(0, 1)).transpose(0, 1)
+        ids = smiles_index
+        num = 0
+        if self.num_props:
+            assert prop.shape[-1] == self.num_props
+            dec_inputs = dec_inputs + self.type_emb.weight[1]
+            p = self.prop_nn(prop.unsqueeze(1)) + self.type_emb.weight[0]
+            dec_inputs = torch.cat([p, dec_inputs], 1)
+            ids = torch.cat([torch.ones(b, 1, dtype=ids.dtype, device=dev), ids], 1)    # property token: id 1, never pad (Q9)
+            num = 1
+        n = t + num
+        pad = ids.eq(self.pad_id).unsqueeze(1).expand(b, n, n)
+        causal = torch.triu(torch.ones(n, n, dtype=torch.bool, device=dev), diagonal=1)
+        dec_self_attn_mask = pad | causal.unsqueeze(0)
+        dec_enc_attn_mask = enc_pad_mask.expand(b, tgt_len + num, enc_pad_mask.size(2))
+        for layer in self.layers:
+            dec_inputs = layer(dec_inputs, enc_outputs, dec_self_attn_mask, dec_enc_attn_mask)
+        return dec_inputs
+
+
+class Transformer(nn.Module):
+    def __init__(self, config, protein_atom_feature_dim, num_props=None, device="cuda"):
+        super().__init__()
+        self.config, self.num_props, self.device = config, num_props, device
+        self.encoder = Encoder(config.encoder, protein_atom_feature_dim, device=device)
+        self.encoder2 = Encoder2(config.encoder, protein_atom_feature_dim, device=device)
+        self.decoder = Decoder(config.decoder, self.num_props, device=device)
+        self.projection = nn.Linear(config.hidden_channels, len(config.decoder.smiVoc), bias=False, device=device)
+
+    def forward(self, node_attr, pos, batch, atom_laplacian, smiles_index, tgt_len, aa_node_attr, aa_pos, aa_batch,
+                aa_laplacian, prop=None, knn=None, aa_knn=None):
+        B = smiles_index.shape[0]
+        enc_outputs1, enc_pad_mask1, msa_outputs = self.encoder(node_attr, pos, batch, atom_laplacian, B, knn)
+        enc_outputs2, enc_pad_mask2 = self.encoder2(aa_node_attr, aa_pos, aa_batch, aa_laplacian, enc_pad_mask1,
+                                                    msa_outputs, B, aa_knn)
+        enc_outputs = torch.cat([enc_outputs1, enc_outputs2], dim=1)
+        enc_pad_mask = torch.cat([enc_pad_mask1, enc_pad_mask2], dim=2)
+        dec_outputs = self.decoder(smiles_index, enc_outputs, enc_pad_mask, tgt_len, prop)
+        dec_logits = self.projection(dec_outputs)
+        num = 1 if self.num_props else 0
+        dec_logits = dec_logits[:, num:, :]
+        return dec_logits.reshape(-1, dec_logits.size(-1))

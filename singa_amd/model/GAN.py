@@ -1,0 +1,48 @@
+"""SINGA generator assembly for MI355X (reference model/GAN.py:12-81): EquivariantEmbedding + CProMG Transformer.
+
+`SINGA(config, device)(g)` returns logits [B*tgt_len, vocab] exactly as the reference; `g` is a
+singa_amd.graph.HeteroGraph batch with the reference's HeteroData field names.  The per-graph Python loops of the
+reference (ptr -> batch vectors, GAN:49-55; zip of property lists, GAN:42) are tensor ops; the Laplacian positional
+encodings (dgl.lap_pe inside the reference forward, GAN:71,77) are inputs carried by the batch (`lap_pe` on each
+node store; SURVEY.md §8c: unpinnable in the reference, computed deterministically per graph by the data pipeline).
+"""
+import torch
+import torch.nn as nn
+
+from ..graph import LA, PA
+from .CProMG import Transformer
+from .Embedding import EquivariantEmbedding
+
+
+def lap_pe(data, node_type: str):
+    assert node_type in (PA, LA), "Node type not accepted"
+    return data[node_type]["lap_pe"]
+
+
+class SINGA(nn.Module):
+    def __init__(self, config, device="cuda"):
+        super().__init__()
+        self.device = device
+        self.config = config
+        self.embedding = EquivariantEmbedding(config=self.config.embedding, device=self.device)
+        self.model = Transformer(config=self.config.model, protein_atom_feature_dim=self.config.model.featurizer_feat_dim,
+                                 num_props=self.config.train.num_props, device=self.device)
+
+    def forward(self, g):
+        ld = g["ligand_data"]
+        if self.config.train.num_props:
+            cols = {"vina_score": torch.lt(ld["vina_score"], -7.5), "qed": torch.gt(ld["qed"], 0.6),
+                    "sas": torch.lt(ld["sas"], 4.0)}                                         # GAN:38-40
+            prop = torch.stack([(cols[p] if p in cols else ld[p]).to(torch.float32) for p in self.config.train.prop], 1)
+        else:
+            prop = None
+        batch, batch_aa = g[PA]["batch"], g[LA]["batch"]
+        embed = self.embedding(g)
+        feat = self.config.model.featurizer_feat_dim
+        knn = getattr(g, "extras", {}).get("knn", {})
+        return self.model(
+            node_attr=embed[PA].embedding.reshape(-1, feat), pos=g[PA]["pos"], batch=batch,
+            atom_laplacian=lap_pe(g, PA), smiles_index=ld["smiIndices_input"],
+            tgt_len=self.config.model.decoder.tgt_len, aa_node_attr=embed[LA].embedding.reshape(-1, feat),
+            aa_pos=g[LA]["pos"], aa_batch=batch_aa, aa_laplacian=lap_pe(g, LA), prop=prop,
+            knn=knn.get(PA), aa_knn=knn.get(LA))

@@ -1,0 +1,372 @@
+"""torch.autograd.Function wrappers around the C ABI of libsinga_hip.so.
+
+Every op takes CUDA (ROCm) fp32 tensors, hands raw device pointers plus the current HIP stream to the library and
+returns tensors allocated by PyTorch.  There is NO CPU path: CPU tensors raise.  Rotations are non-differentiable
+inputs exactly as in the reference (`.detach()` at EF:490-491, 2351); backward kernels recompute instead of saving
+rotated intermediates.
+"""
+import ctypes
+
+import torch
+
+from . import _capi, _lib, so3
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _chk(code, what):
+    _capi.check(_lib.lib(), code, what)
+
+
+def _dev(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("singa_amd ops run on the GPU only (no CPU fallback); got a CPU tensor")
+        if t.dtype not in (torch.float32, torch.int32):
+            raise RuntimeError(f"singa_amd ops take float32 / int32 tensors, got {t.dtype}")
+    _lib.ensure_init(ts[0].device.index if ts[0].device.index is not None else torch.cuda.current_device())
+
+
+class EdgeSet:
+    """Edges of one edge type sorted by destination (CSR) plus the source-sorted permutation used by backward.
+
+    order: the permutation that was applied to the caller's edge list (edge i here = original edge order[i])."""
+
+    def __init__(self, edge_index, n_src, n_dst):
+        ei = edge_index.to(torch.int64)
+        dev = ei.device
+        self.n_src, self.n_dst, self.E = int(n_src), int(n_dst), int(ei.shape[1])
+        order = torch.argsort(ei[1], stable=True)
+        self.order = order
+        self.src64, self.dst64 = ei[0][order].contiguous(), ei[1][order].contiguous()
+        self.src, self.dst = self.src64.to(torch.int32), self.dst64.to(torch.int32)
+        self.row_ptr = torch.zeros(self.n_dst + 1, dtype=torch.int64, device=dev)
+        self.row_ptr[1:] = torch.bincount(self.dst64, minlength=self.n_dst).cumsum(0)
+        self.row_ptr = self.row_ptr.to(torch.int32)
+        self.eperm = torch.argsort(self.src64, stable=True).to(torch.int32)
+        self.col_ptr = torch.zeros(self.n_src + 1, dtype=torch.int64, device=dev)
+        self.col_ptr[1:] = torch.bincount(self.src64, minlength=self.n_src).cumsum(0)
+        self.col_ptr = self.col_ptr.to(torch.int32)
+
+
+def wigner_rows(rot, L, M=2):
+    """k2: rot [E,3,3] -> reduced Wigner rows [E, WSZ] (no gradient, EF:485-528)."""
+    rot = rot.detach().contiguous().float()
+    _dev(rot)
+    lay = so3.layout(L, M)
+    E = rot.shape[0]
+    wr = torch.empty(E, lay.WSZ, device=rot.device, dtype=torch.float32)
+    _chk(_lib.lib().singa_wigner_rows(_p(rot), _p(wr), E, L, M, _stream()), "singa_wigner_rows")
+    return wr
+
+
+class _GatherRotate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x_src, x_dst, rad, wr, es, L, M):
+        x_src, x_dst, rad = x_src.contiguous(), x_dst.contiguous(), rad.contiguous()
+        _dev(x_src, x_dst, rad, wr)
+        lay = so3.layout(L, M)
+        C = x_src.shape[2]
+        assert x_src.shape[1] == lay.K and x_dst.shape[1] == lay.K and wr.shape == (es.E, lay.WSZ)
+        assert x_src.shape[0] == es.n_src and x_dst.shape[0] == es.n_dst and rad.shape == (es.E, lay.rad_rows * 2 * C)
+        out = torch.empty(es.E, lay.KR * 2 * C, device=x_src.device, dtype=torch.float32)
+        _chk(_lib.lib().singa_gather_rotate_fwd(_p(x_src), _p(x_dst), _p(es.src), _p(es.dst), _p(wr), _p(rad), _p(out),
+                                                es.E, C, L, M, _stream()), "singa_gather_rotate_fwd")
+        ctx.save_for_backward(x_src, x_dst, rad, wr)
+        ctx.es, ctx.L, ctx.M = es, L, M
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x_src, x_dst, rad, wr = ctx.saved_tensors
+        es, L, M = ctx.es, ctx.L, ctx.M
+        g = g.contiguous()
+        C = x_src.shape[2]
+        g_rad = torch.empty_like(rad)
+        gx_src, gx_dst = torch.empty_like(x_src), torch.empty_like(x_dst)
+        _chk(_lib.lib().singa_gather_rotate_bwd(_p(g), _p(x_src), _p(x_dst), _p(es.src), _p(es.dst), _p(wr), _p(rad),
+                                                _p(es.row_ptr), _p(es.col_ptr), _p(es.eperm), _p(g_rad), _p(gx_src),
+                                                _p(gx_dst), es.E, es.n_src, es.n_dst, C, L, M, _stream()),
+             "singa_gather_rotate_bwd")
+        return gx_src, gx_dst, g_rad, None, None, None, None
+
+
+def gather_rotate(x_src, x_dst, rad, wr, es, L, M=2):
+    """k3-k6: [N,K,C] node tensors -> m-primary edge tensor [E, KR*2C], multiplied by rad [E, RAD_ROWS*2C]."""
+    return _GatherRotate.apply(x_src, x_dst, rad, wr, es, L, M)
+
+
+def _segs3(ts, rows, CH):
+    return _capi.segs([(t.data_ptr(), t.stride(0), r) for t, r in zip(ts, rows)])
+
+
+class _RotateBackScatter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y0, y1, y2, alpha, wr, es, heads, L, M):
+        y0, y1, y2, alpha = y0.contiguous(), y1.contiguous(), y2.contiguous(), alpha.contiguous()
+        _dev(y0, y1, y2, alpha, wr)
+        lay = so3.layout(L, M)
+        CH = y0.shape[1] // lay.seg_rows[0]
+        assert y1.shape[1] == lay.seg_rows[1] * CH and y2.shape[1] == lay.seg_rows[2] * CH
+        assert alpha.shape == (es.E, heads) and wr.shape == (es.E, lay.WSZ)
+        out = torch.empty(es.n_dst, lay.K, CH, device=y0.device, dtype=torch.float32)
+        seg, n = _segs3((y0, y1, y2), lay.seg_rows, CH)
+        _chk(_lib.lib().singa_rotate_back_scatter_fwd(seg, n, _p(alpha), _p(wr), _p(es.row_ptr), _p(out), es.n_dst, CH,
+                                                      heads, L, M, 0, 1.0, _stream()), "singa_rotate_back_scatter_fwd")
+        ctx.save_for_backward(y0, y1, y2, alpha, wr)
+        ctx.es, ctx.heads, ctx.L, ctx.M, ctx.CH = es, heads, L, M, CH
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        y0, y1, y2, alpha, wr = ctx.saved_tensors
+        es, heads, L, M, CH = ctx.es, ctx.heads, ctx.L, ctx.M, ctx.CH
+        lay = so3.layout(L, M)
+        g = g.contiguous()
+        gy = [torch.empty_like(y0), torch.empty_like(y1), torch.empty_like(y2)]
+        gap = torch.empty(es.E, CH, device=g.device, dtype=torch.float32)
+        seg, n = _segs3((y0, y1, y2), lay.seg_rows, CH)
+        gseg, _ = _segs3(gy, lay.seg_rows, CH)
+        _chk(_lib.lib().singa_rotate_back_scatter_bwd(_p(g), seg, gseg, n, _p(alpha), _p(wr), _p(es.row_ptr), _p(gap),
+                                                      es.n_dst, CH, heads, L, M, 0, 1.0, _stream()),
+             "singa_rotate_back_scatter_bwd")
+        g_alpha = gap.view(es.E, heads, CH // heads).sum(-1)
+        return gy[0], gy[1], gy[2], g_alpha, None, None, None, None, None
+
+
+def rotate_back_scatter(y0, y1, y2, alpha, wr, es, heads, L, M=2):
+    """k10: per-m SO(2)-conv outputs (m-primary) * alpha -> rotate back -> sum into destination nodes [Nd,K,CH]."""
+    return _RotateBackScatter.apply(y0, y1, y2, alpha, wr, es, heads, L, M)
+
+
+class _EdgeDegreeScatter(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, r, wr, es, L, M, scale):
+        r = r.contiguous()
+        _dev(r, wr)
+        lay = so3.layout(L, M)
+        C = r.shape[1] // lay.m_size[0]
+        out = torch.empty(es.n_dst, lay.K, C, device=r.device, dtype=torch.float32)
+        seg, n = _capi.segs([(r.data_ptr(), r.stride(0), lay.m_size[0])])
+        _chk(_lib.lib().singa_rotate_back_scatter_fwd(seg, n, None, _p(wr), _p(es.row_ptr), _p(out), es.n_dst, C, 1, L, M,
+                                                      1, scale, _stream()), "singa_rotate_back_scatter_fwd(m0)")
+        ctx.save_for_backward(wr)
+        ctx.es, ctx.L, ctx.M, ctx.scale, ctx.shape, ctx.C = es, L, M, scale, r.shape, C
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (wr,) = ctx.saved_tensors
+        es, L, M = ctx.es, ctx.L, ctx.M
+        lay = so3.layout(L, M)
+        g = g.contiguous()
+        gr = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        gseg, n = _capi.segs([(gr.data_ptr(), gr.stride(0), lay.m_size[0])])
+        _chk(_lib.lib().singa_rotate_back_scatter_bwd(_p(g), None, gseg, n, None, _p(wr), _p(es.row_ptr), None, es.n_dst,
+                                                      ctx.C, 1, L, M, 1, ctx.scale, _stream()),
+             "singa_rotate_back_scatter_bwd(m0)")
+        return gr, None, None, None, None, None
+
+
+def edge_degree_scatter(r, wr, es, L, M=2, scale=1.0):
+    """k13: m=0 radial output [E,(L+1)*C] -> rotate back (m=0 Wigner columns only) -> node sum * scale."""
+    return _EdgeDegreeScatter.apply(r, wr, es, L, M, scale)
+
+
+class _SegmentSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, row_ptr, eps):
+        x = x.contiguous()
+        _dev(x, row_ptr)
+        y = torch.empty_like(x)
+        N = row_ptr.numel() - 1
+        _chk(_lib.lib().singa_segment_softmax_fwd(_p(x), _p(row_ptr), _p(y), N, x.shape[1], eps, _stream()),
+             "singa_segment_softmax_fwd")
+        ctx.save_for_backward(y, row_ptr)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, row_ptr = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(y)
+        N = row_ptr.numel() - 1
+        _chk(_lib.lib().singa_segment_softmax_bwd(_p(y), _p(gy), _p(row_ptr), _p(gx), N, y.shape[1], _stream()),
+             "singa_segment_softmax_bwd")
+        return gx, None, None
+
+
+def segment_softmax(x, row_ptr, eps):
+    """k9: softmax of x[E,H] over the edge segments of row_ptr (edges sorted by segment)."""
+    return _SegmentSoftmax.apply(x, row_ptr, eps)
+
+
+class _SegmentWSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, w, v, row_ptr):
+        w, v = w.contiguous(), v.contiguous()
+        _dev(w, v, row_ptr)
+        E, H, F = v.shape
+        N = row_ptr.numel() - 1
+        out = torch.empty(N, H, F, device=v.device, dtype=torch.float32)
+        _chk(_lib.lib().singa_segment_wsum_fwd(_p(w), _p(v), _p(row_ptr), _p(out), N, H, F, _stream()),
+             "singa_segment_wsum_fwd")
+        ctx.save_for_backward(w, v, row_ptr)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        w, v, row_ptr = ctx.saved_tensors
+        g = g.contiguous()
+        E, H, F = v.shape
+        N = row_ptr.numel() - 1
+        gw, gv = torch.empty_like(w), torch.empty_like(v)
+        _chk(_lib.lib().singa_segment_wsum_bwd(_p(g), _p(w), _p(v), _p(row_ptr), _p(gw), _p(gv), N, H, F, _stream()),
+             "singa_segment_wsum_bwd")
+        return gw, gv, None
+
+
+def segment_wsum(w, v, row_ptr):
+    """k15: out[n,H,F] = sum over the segment of w[e,H] * v[e,H,F]."""
+    return _SegmentWSum.apply(w, v, row_ptr)
+
+
+_grid_cache = {}
+
+
+def _grids(L, M, m_primary, device):
+    key = (L, M, m_primary, str(device))
+    if key not in _grid_cache:
+        to, fr = so3.s2_grid(L, M)
+        if m_primary:
+            perm = so3.layout(L, M).to_m
+            to, fr = to[:, perm], fr[:, perm]
+        _grid_cache[key] = (torch.tensor(to, dtype=torch.float32, device=device).contiguous(),
+                            torch.tensor(fr, dtype=torch.float32, device=device).contiguous())
+    return _grid_cache[key]
+
+
+class _S2ActEdge(torch.autograd.Function):
+    """SeparableS2Activation on the attention grid [L][M] applied directly to the three SO(2)-conv GEMM outputs
+    (m-primary).  h0 = [alpha inputs | gate | m=0 rows]; returns the activated m-primary tensor [E, KR*C]."""
+
+    @staticmethod
+    def forward(ctx, h0, h1, h2, gate_off, x_off, C, L, M):
+        h0, h1, h2 = h0.contiguous(), h1.contiguous(), h2.contiguous()
+        _dev(h0, h1, h2)
+        lay = so3.layout(L, M)
+        to, fr = _grids(L, M, True, h0.device)
+        E = h0.shape[0]
+        out = torch.empty(E, lay.KR * C, device=h0.device, dtype=torch.float32)
+        seg, n = _capi.segs([(h0.data_ptr() + 4 * x_off, h0.stride(0), lay.seg_rows[0]),
+                             (h1.data_ptr(), h1.stride(0), lay.seg_rows[1]),
+                             (h2.data_ptr(), h2.stride(0), lay.seg_rows[2])])
+        _chk(_lib.lib().singa_s2act_fwd(seg, n, ctypes.c_void_p(h0.data_ptr() + 4 * gate_off), h0.stride(0), _p(to),
+                                        _p(fr), _p(out), E, C, lay.KR, to.shape[0], _stream()), "singa_s2act_fwd")
+        ctx.save_for_backward(h0, h1, h2)
+        ctx.cfg = (gate_off, x_off, C, L, M)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h0, h1, h2 = ctx.saved_tensors
+        gate_off, x_off, C, L, M = ctx.cfg
+        lay = so3.layout(L, M)
+        to, fr = _grids(L, M, True, h0.device)
+        g = g.contiguous()
+        E = h0.shape[0]
+        gx = torch.empty(E, lay.KR * C, device=g.device, dtype=torch.float32)
+        gg = torch.empty(E, C, device=g.device, dtype=torch.float32)
+        seg, n = _capi.segs([(h0.data_ptr() + 4 * x_off, h0.stride(0), lay.seg_rows[0]),
+                             (h1.data_ptr(), h1.stride(0), lay.seg_rows[1]),
+                             (h2.data_ptr(), h2.stride(0), lay.seg_rows[2])])
+        _chk(_lib.lib().singa_s2act_bwd(seg, n, ctypes.c_void_p(h0.data_ptr() + 4 * gate_off), h0.stride(0), _p(to),
+                                        _p(fr), _p(g), _p(gx), _p(gg), E, C, lay.KR, to.shape[0], _stream()),
+             "singa_s2act_bwd")
+        n0, n1 = lay.seg_rows[0] * C, lay.seg_rows[1] * C
+        g0 = torch.zeros_like(h0)
+        g0[:, gate_off:gate_off + C] = gg
+        g0[:, x_off:] = gx[:, :n0]
+        return g0, gx[:, n0:n0 + n1], gx[:, n0 + n1:], None, None, None, None, None
+
+
+def s2act_edge(h0, h1, h2, gate_off, x_off, C, L, M=2):
+    return _S2ActEdge.apply(h0, h1, h2, gate_off, x_off, C, L, M)
+
+
+class _S2ActNode(torch.autograd.Function):
+    """SeparableS2Activation on the FFN grid [L][L] for an l-primary node tensor [N,K,C] and gate [N,C]."""
+
+    @staticmethod
+    def forward(ctx, x, gate, L):
+        x, gate = x.contiguous(), gate.contiguous()
+        _dev(x, gate)
+        to, fr = _grids(L, L, False, x.device)
+        N, K, C = x.shape
+        out = torch.empty_like(x)
+        seg, n = _capi.segs([(x.data_ptr(), K * C, K)])
+        _chk(_lib.lib().singa_s2act_fwd(seg, n, _p(gate), gate.stride(0), _p(to), _p(fr), _p(out), N, C, K, to.shape[0],
+                                        _stream()), "singa_s2act_fwd(node)")
+        ctx.save_for_backward(x, gate)
+        ctx.L = L
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gate = ctx.saved_tensors
+        L = ctx.L
+        to, fr = _grids(L, L, False, x.device)
+        g = g.contiguous()
+        N, K, C = x.shape
+        gx, gg = torch.empty_like(x), torch.empty_like(gate)
+        seg, n = _capi.segs([(x.data_ptr(), K * C, K)])
+        _chk(_lib.lib().singa_s2act_bwd(seg, n, _p(gate), gate.stride(0), _p(to), _p(fr), _p(g), _p(gx), _p(gg), N, C, K,
+                                        to.shape[0], _stream()), "singa_s2act_bwd(node)")
+        return gx, gg, None
+
+
+def s2act_node(x, gate, L):
+    return _S2ActNode.apply(x, gate, L)
+
+
+class _SO3RMSNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, L, eps):
+        x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
+        _dev(x, weight, bias)
+        N, K, C = x.shape
+        y = torch.empty_like(x)
+        _chk(_lib.lib().singa_so3_rmsnorm_fwd(_p(x), _p(weight), _p(bias), _p(y), N, C, L, eps, _stream()),
+             "singa_so3_rmsnorm_fwd")
+        ctx.save_for_backward(x, weight)
+        ctx.L, ctx.eps = L, eps
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        L, eps = ctx.L, ctx.eps
+        gy = gy.contiguous()
+        N, K, C = x.shape
+        nparts = _lib.lib().singa_so3_rmsnorm_nparts(N)
+        gx = torch.empty_like(x)
+        gwp = torch.empty(nparts, K, C, device=x.device, dtype=torch.float32)
+        gbp = torch.empty(nparts, C, device=x.device, dtype=torch.float32)
+        _chk(_lib.lib().singa_so3_rmsnorm_bwd(_p(x), _p(weight), _p(gy), _p(gx), _p(gwp), _p(gbp), N, C, L, eps,
+                                              _stream()), "singa_so3_rmsnorm_bwd")
+        deg = torch.as_tensor(so3.layout(L, L).degree, device=x.device, dtype=torch.int64)
+        gw = torch.zeros(L + 1, C, device=x.device, dtype=torch.float32).index_add_(0, deg, gwp.sum(0))
+        return gx, gw, gbp.sum(0), None, None
+
+
+def so3_rmsnorm(x, weight, bias, L, eps=1e-5):
+    """k12: centred, degree-balanced RMS norm with per-degree affine weight and l=0 bias (EF:2155-2192, Q3)."""
+    return _SO3RMSNorm.apply(x, weight, bias, L, eps)

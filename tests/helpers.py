@@ -24,3 +24,17 @@ def golden(name):
 def rel_err(a, b):
     a, b = torch.as_tensor(a, dtype=torch.float64), torch.as_tensor(b, dtype=torch.float64)
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def product_batch(names, z=None, device="cuda", with_lap=False):
+    """Golden graphs as a singa_amd HeteroGraph batch; `z` (a golden npz) pins rot-mats / kNN lists / lap-PE."""
+    import os as _os
+
+    from singa_amd import graph as G
+    b = G.collate([G.load_npz(_os.path.join(GOLDEN, f"graph_{n}.npz"), with_lap=with_lap) for n in names])
+    if z is not None:
+        b.extras["edge_rot_mat"] = {k: torch.tensor(z[f"rot_{k}"]) for k in ("pp", "ll", "lp")}
+        if "knn_p" in z.files:
+            b.extras["knn"] = {G.PA: torch.tensor(z["knn_p"]), G.LA: torch.tensor(z["knn_l"])}
+            b.nodes[G.PA]["lap_pe"], b.nodes[G.LA]["lap_pe"] = torch.tensor(z["lap_p"]), torch.tensor(z["lap_l"])
+    return b.to(device)

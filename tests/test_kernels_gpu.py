@@ -1,0 +1,255 @@
+"""-m gpu: every HIP kernel, called through the C ABI (singa_amd.ops) on the real gfx950 build, against the CPU
+oracle on the same seeded inputs.  fp32 tolerance: 1e-4 relative (north_star), tighter where the op is exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import singa_oracle as O
+from singa_amd import so3
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _ops():
+    from singa_amd import ops
+    return ops
+
+
+def rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def rand_edges(rs, n_src, n_dst, E):
+    return torch.tensor(np.stack([rs.randint(0, n_src, E), rs.randint(0, n_dst, E)]), dtype=torch.int64)
+
+
+def rand_rot(rs, E):
+    v = torch.tensor(rs.randn(E, 3), dtype=torch.float32)
+    return O.edge_rot_mat(v, torch.tensor(rs.rand(E, 3), dtype=torch.float32))
+
+
+def reduced_rows(w, L, M=2):
+    out = []
+    for l in range(L + 1):
+        mm = min(l, M)
+        out.append(w[:, l * l + l - mm: l * l + l + mm + 1, l * l:(l + 1) ** 2].reshape(w.shape[0], -1))
+    return torch.cat(out, 1)
+
+
+def rad_row_index(lay):
+    idx, off = [np.arange(lay.m_size[0])], lay.m_size[0]
+    for s in lay.m_size[1:]:
+        idx += [off + np.arange(s), off + np.arange(s)]
+        off += s
+    return torch.as_tensor(np.concatenate(idx))
+
+
+def test_library_loaded_and_no_cpu_path():
+    ops = _ops()
+    from singa_amd import _lib
+    assert _lib.lib().singa_version() >= 100
+    with pytest.raises(RuntimeError):
+        ops.so3_rmsnorm(torch.zeros(2, 9, 16), torch.ones(3, 16), torch.zeros(16), 2)
+
+
+@pytest.mark.parametrize("L", [2, 4, 6])
+def test_wigner_rows(L):
+    ops = _ops()
+    rs = np.random.RandomState(L)
+    rot = rand_rot(rs, 1000)
+    wr = ops.wigner_rows(rot.to(DEV), L)
+    ref = reduced_rows(O.wigner_dense(rot, L), L)
+    assert float((wr.cpu() - ref).abs().max()) < 3e-5
+    # orthogonality of full blocks l <= 2: rows of D_l are orthonormal
+    blk = wr[:, 1:10].view(-1, 3, 3)
+    assert float((blk @ blk.transpose(1, 2) - torch.eye(3, device=DEV)).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("L", [2, 4, 6])
+@pytest.mark.parametrize("homo", [True, False])
+def test_gather_rotate_fwd_bwd(L, homo):
+    ops = _ops()
+    rs = np.random.RandomState(100 + L)
+    C, Ns, Nd, E = 16, (60 if not homo else 80), 80, 700
+    lay = so3.layout(L, 2)
+    ei = rand_edges(rs, Ns, Nd, E)
+    rot = rand_rot(rs, E)
+    xs = torch.tensor(rs.randn(Ns, lay.K, C), dtype=torch.float32, requires_grad=True)
+    xd = xs if homo else torch.tensor(rs.randn(Nd, lay.K, C), dtype=torch.float32, requires_grad=True)
+    rad = torch.tensor(rs.randn(E, lay.rad_rows * 2 * C), dtype=torch.float32, requires_grad=True)
+    g = torch.tensor(rs.randn(E, lay.KR * 2 * C), dtype=torch.float32)
+    # oracle (original edge order)
+    fr = O.Frame(rot, L, 2)
+    ref = (torch.bmm(fr.fwd, torch.cat([xs[ei[0]], xd[ei[1]]], 2))[:, fr.to_m]
+           * rad.view(E, lay.rad_rows, 2 * C)[:, rad_row_index(lay)]).reshape(E, -1)
+    ref.backward(g)
+    # HIP path (destination-sorted order)
+    es = ops.EdgeSet(ei.to(DEV), Ns, Nd)
+    order = es.order.cpu()
+    wr = ops.wigner_rows(rot[order].to(DEV), L)
+    xs_g = xs.detach().to(DEV).requires_grad_(True)
+    xd_g = xs_g if homo else xd.detach().to(DEV).requires_grad_(True)
+    rad_g = rad.detach()[order].to(DEV).requires_grad_(True)
+    out = ops.gather_rotate(xs_g, xd_g, rad_g, wr, es, L)
+    assert rel(out, ref[order]) < 2e-5
+    out.backward(g[order].to(DEV))
+    assert rel(xs_g.grad, xs.grad) < 2e-5
+    if not homo:
+        assert rel(xd_g.grad, xd.grad) < 2e-5
+    assert rel(rad_g.grad, rad.grad[order]) < 2e-5
+
+
+@pytest.mark.parametrize("L", [2, 4, 6])
+def test_rotate_back_scatter_fwd_bwd(L):
+    ops = _ops()
+    rs = np.random.RandomState(200 + L)
+    CH, heads, Nd, E = 112, 7, 90, 800
+    lay = so3.layout(L, 2)
+    ei = rand_edges(rs, 50, Nd, E)
+    ei[1, :40] = 3                                    # one heavy destination; some nodes stay empty
+    rot = rand_rot(rs, E)
+    fr = O.Frame(rot, L, 2)
+    parts = [torch.tensor(rs.randn(E, r * CH), dtype=torch.float32, requires_grad=True) for r in lay.seg_rows]
+    alpha = torch.tensor(rs.rand(E, heads), dtype=torch.float32, requires_grad=True)
+    msg_l = torch.cat([p.view(E, -1, CH) for p in parts], 1)[:, fr.to_l]
+    msg_l = (msg_l.view(E, lay.KR, heads, CH // heads) * alpha.view(E, 1, heads, 1)).reshape(E, lay.KR, CH)
+    ref = O.seg_sum(torch.bmm(fr.inv, msg_l), ei[1], Nd)
+    g = torch.tensor(rs.randn(Nd, lay.K, CH), dtype=torch.float32)
+    ref.backward(g)
+    es = ops.EdgeSet(ei.to(DEV), 50, Nd)
+    order = es.order.cpu()
+    wr = ops.wigner_rows(rot[order].to(DEV), L)
+    ys = [p.detach()[order].to(DEV).requires_grad_(True) for p in parts]
+    al = alpha.detach()[order].to(DEV).requires_grad_(True)
+    out = ops.rotate_back_scatter(ys[0], ys[1], ys[2], al, wr, es, heads, L)
+    assert rel(out, ref) < 2e-5
+    out.backward(g.to(DEV))
+    for y, p in zip(ys, parts):
+        assert rel(y.grad, p.grad[order]) < 2e-5
+    assert rel(al.grad, alpha.grad[order]) < 5e-5
+
+
+@pytest.mark.parametrize("L", [2, 6])
+def test_edge_degree_scatter(L):
+    ops = _ops()
+    rs = np.random.RandomState(300 + L)
+    C, Nd, E = 16, 70, 500
+    lay = so3.layout(L, 2)
+    ei = rand_edges(rs, 40, Nd, E)
+    rot = rand_rot(rs, E)
+    fr = O.Frame(rot, L, 2)
+    r = torch.tensor(rs.randn(E, lay.m_size[0] * C), dtype=torch.float32, requires_grad=True)
+    full = torch.cat([r.view(E, -1, C), torch.zeros(E, lay.KR - lay.m_size[0], C)], 1)[:, fr.to_l]
+    ref = O.seg_sum(torch.bmm(fr.inv, full), ei[1], Nd) / O.AVG_DEGREE
+    g = torch.tensor(rs.randn(Nd, lay.K, C), dtype=torch.float32)
+    ref.backward(g)
+    es = ops.EdgeSet(ei.to(DEV), 40, Nd)
+    order = es.order.cpu()
+    wr = ops.wigner_rows(rot[order].to(DEV), L)
+    rg = r.detach()[order].to(DEV).requires_grad_(True)
+    out = ops.edge_degree_scatter(rg, wr, es, L, 2, 1.0 / O.AVG_DEGREE)
+    assert rel(out, ref) < 2e-5
+    out.backward(g.to(DEV))
+    assert rel(rg.grad, r.grad[order]) < 2e-5
+
+
+@pytest.mark.parametrize("H,eps", [(7, 1e-16), (4, 0.0)])
+def test_segment_softmax(H, eps):
+    ops = _ops()
+    rs = np.random.RandomState(5)
+    N, E = 300, 5000
+    dst = torch.tensor(np.sort(rs.randint(0, N, E)), dtype=torch.int64)
+    rp = torch.zeros(N + 1, dtype=torch.int64)
+    rp[1:] = torch.bincount(dst, minlength=N).cumsum(0)
+    x = torch.tensor(rs.randn(E, H) * 4, dtype=torch.float32, requires_grad=True)
+    ref = O.seg_softmax(x, dst, N, eps)
+    g = torch.tensor(rs.randn(E, H), dtype=torch.float32)
+    ref.backward(g)
+    xg = x.detach().to(DEV).requires_grad_(True)
+    y = ops.segment_softmax(xg, rp.to(torch.int32).to(DEV), eps)
+    assert float((y.cpu() - ref.detach()).abs().max()) < 1e-6
+    y.backward(g.to(DEV))
+    assert rel(xg.grad, x.grad) < 1e-5
+    sums = torch.zeros(N, H).index_add_(0, dst, y.detach().cpu())
+    assert float((sums[torch.bincount(dst, minlength=N) > 0] - 1).abs().max()) < 1e-5
+
+
+def test_segment_wsum():
+    ops = _ops()
+    rs = np.random.RandomState(6)
+    N, E, H, F = 200, 6000, 4, 64
+    dst = torch.tensor(np.sort(rs.randint(0, N, E)), dtype=torch.int64)
+    rp = torch.zeros(N + 1, dtype=torch.int64)
+    rp[1:] = torch.bincount(dst, minlength=N).cumsum(0)
+    w = torch.tensor(rs.rand(E, H), dtype=torch.float32, requires_grad=True)
+    v = torch.tensor(rs.randn(E, H, F), dtype=torch.float32, requires_grad=True)
+    ref = O.seg_sum(w.unsqueeze(-1) * v, dst, N)
+    g = torch.tensor(rs.randn(N, H, F), dtype=torch.float32)
+    ref.backward(g)
+    wg, vg = w.detach().to(DEV).requires_grad_(True), v.detach().to(DEV).requires_grad_(True)
+    out = ops.segment_wsum(wg, vg, rp.to(torch.int32).to(DEV))
+    assert rel(out, ref) < 1e-5
+    out.backward(g.to(DEV))
+    assert rel(wg.grad, w.grad) < 1e-5 and rel(vg.grad, v.grad) < 1e-6
+
+
+@pytest.mark.parametrize("L", [2, 4, 6])
+def test_s2act_edge_and_node(L):
+    ops = _ops()
+    rs = np.random.RandomState(400 + L)
+    lay = so3.layout(L, 2)
+    E, C, extra = 300, 128, 224
+    h0 = torch.tensor(rs.randn(E, extra + C + lay.seg_rows[0] * C), dtype=torch.float32, requires_grad=True)
+    h1 = torch.tensor(rs.randn(E, lay.seg_rows[1] * C), dtype=torch.float32, requires_grad=True)
+    h2 = torch.tensor(rs.randn(E, lay.seg_rows[2] * C), dtype=torch.float32, requires_grad=True)
+    xm = torch.cat([h0[:, extra + C:].view(E, -1, C), h1.view(E, -1, C), h2.view(E, -1, C)], 1)
+    to_m = torch.as_tensor(lay.to_m)
+    ref = O.sep_s2_act(h0[:, extra:extra + C], xm[:, torch.argsort(to_m)], L, 2)[:, to_m].reshape(E, -1)
+    g = torch.tensor(rs.randn(*ref.shape), dtype=torch.float32)
+    ref.backward(g)
+    hs = [h.detach().to(DEV).requires_grad_(True) for h in (h0, h1, h2)]
+    out = ops.s2act_edge(hs[0], hs[1], hs[2], extra, extra + C, C, L)
+    assert rel(out, ref) < 2e-5
+    out.backward(g.to(DEV))
+    for a, b in zip(hs, (h0, h1, h2)):
+        assert rel(a.grad, b.grad) < 5e-5
+    # node / FFN flavour on the [L][L] grid
+    N, Cn = 64, 512
+    K = (L + 1) ** 2
+    x = torch.tensor(rs.randn(N, K, Cn), dtype=torch.float32, requires_grad=True)
+    gt = torch.tensor(rs.randn(N, Cn), dtype=torch.float32, requires_grad=True)
+    ref = O.sep_s2_act(gt, x, L, L)
+    g = torch.tensor(rs.randn(N, K, Cn), dtype=torch.float32)
+    ref.backward(g)
+    xg, gg = x.detach().to(DEV).requires_grad_(True), gt.detach().to(DEV).requires_grad_(True)
+    out = ops.s2act_node(xg, gg, L)
+    assert rel(out, ref) < 2e-5
+    out.backward(g.to(DEV))
+    assert rel(xg.grad, x.grad) < 5e-5 and rel(gg.grad, gt.grad) < 1e-5
+
+
+@pytest.mark.parametrize("L", [2, 4, 6])
+def test_so3_rmsnorm(L):
+    ops = _ops()
+    rs = np.random.RandomState(500 + L)
+    N, C, K = 777, 16, (L + 1) ** 2
+    x = torch.tensor(rs.randn(N, K, C) * 2 + 0.3, dtype=torch.float32, requires_grad=True)
+    w = torch.tensor(1 + 0.1 * rs.randn(L + 1, C), dtype=torch.float32, requires_grad=True)
+    b = torch.tensor(0.1 * rs.randn(C), dtype=torch.float32, requires_grad=True)
+    sd = {"n.affine_weight": w, "n.affine_bias": b}
+    ref = O.rms_norm(sd, "n", x, L)
+    g = torch.tensor(rs.randn(N, K, C), dtype=torch.float32)
+    ref.backward(g)
+    xg, wg, bg = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, b))
+    y = ops.so3_rmsnorm(xg, wg, bg, L)
+    assert rel(y, ref) < 1e-5
+    y.backward(g.to(DEV))
+    assert rel(xg.grad, x.grad) < 2e-5
+    assert rel(wg.grad, w.grad) < 2e-5 and rel(bg.grad, b.grad) < 2e-5
+    # identity property: affine = identity -> balanced RMS of the output is 1
+    y1 = ops.so3_rmsnorm(xg.detach(), torch.ones_like(wg), torch.zeros_like(bg), L).cpu()
+    lk = torch.as_tensor(so3.layout(L, L).degree)
+    bal = (1.0 / ((2 * lk + 1).float() * (L + 1))).view(1, -1, 1)
+    assert float((((y1 ** 2) * bal).sum(1).mean(1) - 1).abs().max()) < 1e-3
