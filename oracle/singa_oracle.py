@@ -473,3 +473,29 @@ def load_graph_npz(path):
     g = {k: torch.as_tensor(z[k]) for k in z.files}
     g["props"] = g["props"].to(torch.float64)
     return g
+
+
+def knn_graph(pos, k, batch):
+    """torch_cluster.knn_graph(pos, k, batch, flow='target_to_source') restated (CP:293,330): row = centre."""
+    rows, cols = [], []
+    for b in range(int(batch.max()) + 1):
+        ids = (batch == b).nonzero().view(-1)
+        d = torch.cdist(pos[ids].double(), pos[ids].double())
+        d.fill_diagonal_(float("inf"))
+        kk = min(k, ids.numel() - 1)
+        nb = d.topk(kk, dim=1, largest=False).indices
+        rows.append(ids.view(-1, 1).expand(-1, kk).reshape(-1))
+        cols.append(ids[nb].reshape(-1))
+    return torch.stack([torch.cat(rows), torch.cat(cols)], 0)
+
+
+def train_step_loss(sd, g, rots, L, lap_p, lap_l, knn_p=None, knn_l=None):
+    """One reference training step up to the loss (train.py:119-123): forward + CrossEntropy (dropout off)."""
+    bp = torch.repeat_interleave(torch.arange(len(g["ptr_p"]) - 1), g["ptr_p"][1:] - g["ptr_p"][:-1])
+    bl = torch.repeat_interleave(torch.arange(len(g["ptr_l"]) - 1), g["ptr_l"][1:] - g["ptr_l"][:-1])
+    if knn_p is None:
+        knn_p = knn_graph(g["pos_p"], 48, bp)
+    if knn_l is None:
+        knn_l = knn_graph(g["pos_l"], 30, bl)
+    logits = singa_forward(sd, g, rots, L, knn_p, knn_l, lap_p, lap_l)
+    return F.cross_entropy(logits, g["tok_tgt"].reshape(-1))

@@ -1,0 +1,68 @@
+"""Data-parallel gradient averaging: one process per GPU, graphs sharded across ranks, one bucketed all-reduce of
+the generator's gradients per step over RCCL/xGMI (torch.distributed backend "nccl" on ROCm; "gloo" in CPU tests).
+
+The reference has no distributed code; the path shards by graph with no other exchange
+(SURVEY.md §8e).  Parameters that never receive a gradient (Q10: 90 tensors) are excluded statically from the
+buckets after the first backward, so no unused-parameter scan runs per step.  Buckets follow reverse execution
+order (decoder -> encoders -> equivariant blocks) and are launched asynchronously so that the first reductions
+overlap the flattening of the later ones.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradAllReducer:
+    def __init__(self, module, bucket_mb=32.0, group=None):
+        self.module, self.group = module, group
+        self.bucket_bytes = int(bucket_mb * (1 << 20))
+        self.buckets = None
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def _build(self):
+        params = [p for p in reversed(list(self.module.parameters())) if p.grad is not None]
+        self.buckets, cur, size = [], [], 0
+        for p in params:
+            cur.append(p)
+            size += p.numel() * p.element_size()
+            if size >= self.bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.flat = [torch.empty(sum(p.numel() for p in b), dtype=b[0].dtype, device=b[0].device) for b in self.buckets]
+
+    def check_same_init(self):
+        """Same-seed initialisation replaces a parameter broadcast; verify it with one checksum exchange."""
+        if self.world == 1:
+            return
+        s = torch.stack([p.detach().double().sum() for p in self.module.parameters()]).sum().reshape(1)
+        lo, hi = s.clone(), s.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        assert float(hi - lo) == 0.0, "ranks were not initialised with identical parameters"
+
+    def reduce(self):
+        """Average .grad over ranks in place. Call after backward(), before the optimizer step."""
+        if self.world == 1:
+            return
+        if self.buckets is None:
+            self._build()
+        works = []
+        for flat, bucket in zip(self.flat, self.buckets):
+            torch._foreach_copy_(list(flat.split([p.numel() for p in bucket])), [p.grad.reshape(-1) for p in bucket])
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w, flat, bucket in zip(works, self.flat, self.buckets):
+            w.wait()
+            flat.div_(self.world)
+            torch._foreach_copy_([p.grad.reshape(-1) for p in bucket], list(flat.split([p.numel() for p in bucket])))
+
+    @property
+    def payload_bytes(self):
+        return 0 if self.buckets is None else sum(f.numel() * f.element_size() for f in self.flat)
+
+
+def shard_range(n_items, rank, world):
+    """Contiguous balanced shard [lo, hi) of n_items units for `rank`."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)

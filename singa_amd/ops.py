@@ -12,8 +12,33 @@ import torch
 from . import _capi, _lib, so3
 
 
+# Optional per-launch timing (bench.py): when PROFILE_ON, selected launches are bracketed by HIP events recorded on
+# the stream the kernel is enqueued on (torch's current stream) and appended to PROFILE[name] as
+# (start_event, end_event, n_edges, n_dst_nodes).
+PROFILE = {}
+PROFILE_ON = False
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _timed:
+    def __init__(self, name, E, N):
+        self.name, self.E, self.N = name, E, N
+
+    def __enter__(self):
+        if PROFILE_ON:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE_ON:
+            self.b.record()
+            PROFILE.setdefault(self.name, []).append((self.a, self.b, self.E, self.N))
+        return False
 
 
 def _p(t):
@@ -78,8 +103,9 @@ class _GatherRotate(torch.autograd.Function):
         assert x_src.shape[1] == lay.K and x_dst.shape[1] == lay.K and wr.shape == (es.E, lay.WSZ)
         assert x_src.shape[0] == es.n_src and x_dst.shape[0] == es.n_dst and rad.shape == (es.E, lay.rad_rows * 2 * C)
         out = torch.empty(es.E, lay.KR * 2 * C, device=x_src.device, dtype=torch.float32)
-        _chk(_lib.lib().singa_gather_rotate_fwd(_p(x_src), _p(x_dst), _p(es.src), _p(es.dst), _p(wr), _p(rad), _p(out),
-                                                es.E, C, L, M, _stream()), "singa_gather_rotate_fwd")
+        with _timed("gather_rotate_fwd", es.E, es.n_dst):
+            _chk(_lib.lib().singa_gather_rotate_fwd(_p(x_src), _p(x_dst), _p(es.src), _p(es.dst), _p(wr), _p(rad),
+                                                    _p(out), es.E, C, L, M, _stream()), "singa_gather_rotate_fwd")
         ctx.save_for_backward(x_src, x_dst, rad, wr)
         ctx.es, ctx.L, ctx.M = es, L, M
         return out
@@ -119,8 +145,10 @@ class _RotateBackScatter(torch.autograd.Function):
         assert alpha.shape == (es.E, heads) and wr.shape == (es.E, lay.WSZ)
         out = torch.empty(es.n_dst, lay.K, CH, device=y0.device, dtype=torch.float32)
         seg, n = _segs3((y0, y1, y2), lay.seg_rows, CH)
-        _chk(_lib.lib().singa_rotate_back_scatter_fwd(seg, n, _p(alpha), _p(wr), _p(es.row_ptr), _p(out), es.n_dst, CH,
-                                                      heads, L, M, 0, 1.0, _stream()), "singa_rotate_back_scatter_fwd")
+        with _timed("rotate_back_scatter_fwd", es.E, es.n_dst):
+            _chk(_lib.lib().singa_rotate_back_scatter_fwd(seg, n, _p(alpha), _p(wr), _p(es.row_ptr), _p(out), es.n_dst,
+                                                          CH, heads, L, M, 0, 1.0, _stream()),
+                 "singa_rotate_back_scatter_fwd")
         ctx.save_for_backward(y0, y1, y2, alpha, wr)
         ctx.es, ctx.heads, ctx.L, ctx.M, ctx.CH = es, heads, L, M, CH
         return out
