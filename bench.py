@@ -187,8 +187,7 @@ def main():
         torch.cuda.synchronize()
         log(f"warmup step {i}: {time.perf_counter() - t_w:.3f} s")
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, MAX over ranks
-    ops.PROFILE.clear()
-    ops.PROFILE_ON = True
+    ops.profile_start()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -201,7 +200,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    ops.PROFILE_ON = False
+    recs = ops.profile_collect()
+    if os.environ.get("SINGA_CALIB") == "1" and rank == 0:
+        # known-byte launches for calibrating FETCH_SIZE / WRITE_SIZE under `rocprofv3 --pmc`
+        import ctypes
+        from singa_amd import _lib
+        n = 64 * 1024 * 1024
+        a = torch.randn(n, device=dev)
+        b = torch.empty_like(a)
+        for _ in range(3):
+            _lib.lib().singa_calib_copy(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n,
+                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -211,18 +221,17 @@ def main():
 
     # ---- roofline of the dominant launch of the scatter-TP kernel (k10 forward on the protein-protein edges)
     roof = None
-    recs = ops.PROFILE.get("rotate_back_scatter_fwd", [])
     if recs:
-        big = max(r[2] for r in recs)                     # launches with the most edges = PP passes
-        sel = [r for r in recs if r[2] == big]
-        ms = sum(a.elapsed_time(b) for a, b, _, _ in sel) / len(sel)
-        E, N = sel[0][2], sel[0][3]
+        big = max(r[1] for r in recs)                     # dispatches with the most edges = the protein-protein passes
+        sel = [r for r in recs if r[1] == big]
+        ms = sum(r[0] for r in sel) / len(sel)
+        E, N = sel[0][1], sel[0][2]
         by = k10_algorithmic_bytes(E, N, L)
         ach = by / (ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "rotate_back_scatter_kernel (k10 fwd, protein-protein edges)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": None, "bytes_per_launch": by, "avg_launch_us": round(ms * 1e3, 2), "launches": len(sel),
-                "edges": E, "dst_nodes": N}
+                "edges": E, "dst_nodes": N, "timing": "start/stop events attached to each dispatch, timed region"}
 
     if rank == 0:
         total_graphs = n_graphs * world * args.steps

@@ -102,6 +102,23 @@ int singa_segment_wsum_fwd(const float* w, const float* v, const int32_t* row_pt
 int singa_segment_wsum_bwd(const float* g_out, const float* w, const float* v, const int32_t* row_ptr, float* gw,
                            float* gv, int N, int H, int F, void* stream);
 
+/* k15b — CProMG MultiHeadAttention (CP:59-74) with weight_k_lin / weight_v_lin hoisted to node level by linearity, so
+ * no [E,H,D] tensor exists.  Edges sorted by row (centre node): row_ptr[N+1], col[E]; col_ptr/eperm = edges grouped by
+ * col (for the gradient of the gathered operand); row[E] = centre of each edge.  H = 4, D = 32, F = 64.
+ *   qk[e,h]    = scale * sum_d qp[row,h,d] wk[e,d] hk[col,h,d] + cterm[row,h]      (CP:61-65)
+ *   out[n,h,f] = sum_e alpha[e,h] wv[e,f] hv[col,h,f]                                (CP:70-74) */
+int singa_edge_logits_fwd(const float* qp, const float* wk, const float* hk, const float* cterm, const int32_t* row_ptr,
+                          const int32_t* col, float* qk, int N, int H, int D, float scale, void* stream);
+int singa_edge_logits_bwd(const float* g, const float* qp, const float* wk, const float* hk, const int32_t* row_ptr,
+                          const int32_t* col, const int32_t* col_ptr, const int32_t* eperm, const int32_t* row,
+                          float* g_qp, float* g_wk, float* g_hk, float* g_cterm, int N, int H, int D, float scale,
+                          void* stream);
+int singa_gather_wsum_fwd(const float* alpha, const float* wv, const float* hv, const int32_t* row_ptr, const int32_t* col,
+                          float* out, int N, int H, int F, void* stream);
+int singa_gather_wsum_bwd(const float* g, const float* alpha, const float* wv, const float* hv, const int32_t* row_ptr,
+                          const int32_t* col, const int32_t* col_ptr, const int32_t* eperm, const int32_t* row,
+                          float* g_alpha, float* g_wv, float* g_hv, int N, int H, int F, void* stream);
+
 /* k8 — SeparableS2Activation (EF:1736-1773): rows -> S2 grid (to_grid[G,KIN]) -> SiLU -> rows (from_grid[G,KIN]);
  * row 0 of the output is SiLU(gate).  x: KIN rows of C channels in `nseg` segments; gate[E, ldg]; out[E,KIN,C].
  * Grid matrices are given in the row order of x (the host permutes them for m-primary inputs). */
@@ -120,6 +137,14 @@ int singa_so3_rmsnorm_fwd(const float* x, const float* weight, const float* bias
 int singa_so3_rmsnorm_nparts(int N);
 int singa_so3_rmsnorm_bwd(const float* x, const float* weight, const float* gy, float* gx, float* gw_part,
                           float* gb_part, int N, int C, int lmax, float eps, void* stream);
+
+/* Measurement helpers (bench.py): exact per-dispatch timing of the scatter-TP forward kernel with start/stop events
+ * attached to the dispatch (hipExtLaunchKernelGGL) on the caller's stream, and a copy kernel with the segment kernels'
+ * access shape for calibrating the PMC byte counters. */
+int singa_prof_enable(int on);
+int singa_prof_hint_edges(int E);
+int singa_prof_collect(float* ms, int* edges, int* nodes, int cap); /* after synchronising; returns #records */
+int singa_calib_copy(const float* src, float* dst, long long n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,14 @@ _SIGS = {
     "singa_so3_rmsnorm_nparts": ([I32], I32),
     "singa_so3_rmsnorm_fwd": ([P, P, P, P, I32, I32, I32, F32, P], I32),
     "singa_so3_rmsnorm_bwd": ([P, P, P, P, P, P, I32, I32, I32, F32, P], I32),
+    "singa_edge_logits_fwd": ([P] * 7 + [I32, I32, I32, F32, P], I32),
+    "singa_edge_logits_bwd": ([P] * 13 + [I32, I32, I32, F32, P], I32),
+    "singa_gather_wsum_fwd": ([P] * 6 + [I32, I32, I32, P], I32),
+    "singa_gather_wsum_bwd": ([P] * 12 + [I32, I32, I32, P], I32),
+    "singa_prof_enable": ([I32], I32),
+    "singa_prof_hint_edges": ([I32], I32),
+    "singa_prof_collect": ([P, P, P, I32], I32),
+    "singa_calib_copy": ([P, P, C.c_longlong, P], I32),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -11,6 +11,7 @@
 //  * Loops over (l, m, j) are fully unrolled against the constexpr tables of so3_index.h; accumulators live in
 //    statically indexed VGPRs.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <math.h>
 #include <stdint.h>
@@ -38,6 +39,19 @@ int check_launch(const char* what) {
     return SINGA_OK;
 }
 
+// Optional per-dispatch timing of the scatter-TP forward kernel: when enabled, its launches go through
+// hipExtLaunchKernelGGL with a start and a stop event attached to the dispatch itself (the timestamps rocprofv3 reads),
+// on the caller's stream.  singa_prof_collect() reads them back after the caller has synchronised.
+struct ProfRec {
+    hipEvent_t a, b;
+    int E, N;
+};
+constexpr int PROF_CAP = 8192;
+ProfRec g_prof[PROF_CAP];
+int g_prof_n = 0;
+bool g_prof_on = false;
+int g_prof_edges_hint = 0;  // E of the next profiled launch (the kernel itself only needs row_ptr)
+
 constexpr int MAX_J = 2300;  // sum_{l<=11} (2l+1)^2
 __device__ float g_J[MAX_J];
 int g_lmax_init = -1;
@@ -64,6 +78,28 @@ __device__ __forceinline__ float silu_grad(float u) {
     float s = 1.0f / (1.0f + __expf(-u));
     return s * (1.0f + u * (1.0f - s));
 }
+
+// Per-edge Wigner rows are the same for every lane of a wavefront.  Fetching them with scalar loads serialises on the
+// ~100-SGPR budget (the compiler issues them piecemeal, one s_waitcnt round trip per piece: measured 40 us block
+// lifetimes).  Instead each wave reads the record ONCE with ordinary coalesced vector loads (lane i holds W[i], W[i+64],
+// ...) - these overlap with the message loads - and every use broadcasts one element to an SGPR with v_readlane.
+#ifndef SINGA_LANE_BCAST  // tests/emul overrides this with a plain memory read (sequential threads have no lanes)
+#define SINGA_LANE_BCAST(reg, lane, ptr, idx) \
+    __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (reg)), (lane)))
+#endif
+
+template <int WSZ>
+struct WRows {
+    static constexpr int NW = (WSZ + 63) / 64;
+    float v[NW];
+    const float* p;
+    __device__ __forceinline__ void load(const float* W, int lane) {
+        p = W;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) v[k] = (lane + 64 * k < WSZ) ? W[lane + 64 * k] : 0.f;
+    }
+};
+#define W_AT(w, idx) SINGA_LANE_BCAST((w).v[(idx) / 64], (idx) % 64, (w).p, (idx))
 
 // ------------------------------------------------------------------------------------------------ k2: Wigner rows
 // One thread per (edge, reduced row).  D_l = Za J Zb J Zc with Z(t) = diag cos(f t) + antidiag sin(f t),
@@ -138,13 +174,15 @@ __global__ void __launch_bounds__(64) gather_rotate_kernel(const float* __restri
                                      const float* __restrict__ g_out, float* __restrict__ out, int E) {
     using I = SO3Idx<L, M>;
     const int lane = threadIdx.x;
-    if (lane >= 2 * C) return;
+    const bool act = lane < 2 * C;       // lanes >= 2C shadow lanes 0..2C-1 (same loads, no stores): every lane of the
+    const int ln = lane & (2 * C - 1);   // wave must stay live for the Wigner-record fetch and its lane broadcasts
     for (int e = blockIdx.x; e < E; e += gridDim.x) {
-        const float* W = wr + (long long)e * I::WSZ;
-        const int node = lane < C ? src[e] : dst[e];
-        const float* xin = (lane < C ? x_src : x_dst) + (long long)node * I::K * C + (lane & (C - 1));
-        const long long eo = (long long)e * I::KR * 2 * C + lane;
-        const long long ro = (long long)e * I::RAD_ROWS * 2 * C + lane;
+        WRows<I::WSZ> W;
+        W.load(wr + (long long)e * I::WSZ, lane);
+        const int node = ln < C ? src[e] : dst[e];
+        const float* xin = (ln < C ? x_src : x_dst) + (long long)node * I::K * C + (ln & (C - 1));
+        const long long eo = (long long)e * I::KR * 2 * C + ln;
+        const long long ro = (long long)e * I::RAD_ROWS * 2 * C + ln;
         float gr[I::RAD_ROWS];
         if (MODE == 1) {
 #pragma unroll
@@ -160,16 +198,16 @@ __global__ void __launch_bounds__(64) gather_rotate_kernel(const float* __restri
                 const int m = mi - I::mm(l);
                 float acc = 0.f;
 #pragma unroll
-                for (int j = 0; j < 2 * l + 1; ++j) acc = fmaf(W[I::w_off(l) + mi * (2 * l + 1) + j], xv[j], acc);
+                for (int j = 0; j < 2 * l + 1; ++j) acc = fmaf(W_AT(W, I::w_off(l) + mi * (2 * l + 1) + j), xv[j], acc);
                 if (MODE == 0) {
                     float rv = rad ? rad[ro + I::rad_row(l, m) * 2 * C] : 1.f;
-                    out[eo + I::mpos(l, m) * 2 * C] = acc * rv;
+                    if (act) out[eo + I::mpos(l, m) * 2 * C] = acc * rv;
                 } else {
                     gr[I::rad_row(l, m)] = fmaf(g_out[eo + I::mpos(l, m) * 2 * C], acc, gr[I::rad_row(l, m)]);
                 }
             }
         }
-        if (MODE == 1) {
+        if (MODE == 1 && act) {
 #pragma unroll
             for (int i = 0; i < I::RAD_ROWS; ++i) out[ro + i * 2 * C] = gr[i];
         }
@@ -185,8 +223,8 @@ __global__ void __launch_bounds__(64) gather_rotate_bwd_node_kernel(const float*
                                               const int* __restrict__ eperm, float* __restrict__ gx, int N) {
     using I = SO3Idx<L, M>;
     const int lane = threadIdx.x;
-    if (lane >= C) return;
-    const int co = SIDE == 0 ? C + lane : lane;  // dst half of the 2C channels is [C, 2C)
+    const bool act = lane < C;
+    const int co = SIDE == 0 ? C + (lane & (C - 1)) : (lane & (C - 1));  // dst half of the 2C channels is [C, 2C)
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
         float acc[I::K];
 #pragma unroll
@@ -194,7 +232,8 @@ __global__ void __launch_bounds__(64) gather_rotate_bwd_node_kernel(const float*
         const int beg = ptr[n], end = ptr[n + 1];
         for (int i = beg; i < end; ++i) {
             const int e = SIDE == 0 ? i : eperm[i];
-            const float* W = wr + (long long)e * I::WSZ;
+            WRows<I::WSZ> W;
+            W.load(wr + (long long)e * I::WSZ, lane);
             const long long eo = (long long)e * I::KR * 2 * C + co;
             const long long ro = (long long)e * I::RAD_ROWS * 2 * C + co;
 #pragma unroll
@@ -206,13 +245,15 @@ __global__ void __launch_bounds__(64) gather_rotate_bwd_node_kernel(const float*
                     if (rad) g *= rad[ro + I::rad_row(l, m) * 2 * C];
 #pragma unroll
                     for (int j = 0; j < 2 * l + 1; ++j)
-                        acc[l * l + j] = fmaf(W[I::w_off(l) + mi * (2 * l + 1) + j], g, acc[l * l + j]);
+                        acc[l * l + j] = fmaf(W_AT(W, I::w_off(l) + mi * (2 * l + 1) + j), g, acc[l * l + j]);
                 }
             }
         }
-        float* o = gx + (long long)n * I::K * C + lane;
+        if (act) {
+            float* o = gx + (long long)n * I::K * C + lane;
 #pragma unroll
-        for (int k = 0; k < I::K; ++k) o[k * C] = acc[k];
+            for (int k = 0; k < I::K; ++k) o[k * C] = acc[k];
+        }
     }
 }
 
@@ -226,14 +267,18 @@ __host__ __device__ constexpr float rescale_of(int l, int M) {
 }
 
 // One workgroup per destination node; thread = channel (blockDim = 64 or 128 >= CH).  Walks the node's edge
-// segment; per edge: m[r] = alpha * msg[e, r, c]; acc[l^2+j] += W_e[r][j] * m[r].  M0: only the m = 0 rows exist.
-template <int L, int M, bool M0>
+// segment U edges at a time: all U*rows message loads of a chunk are issued before the first FMA (memory-level
+// parallelism; the segment walk is otherwise a chain of dependent HBM round trips), then per edge
+// m[r] = alpha * msg[e, r, c]; acc[l^2+j] += W_e[r][j] * m[r].  M0: only the m = 0 rows exist.
+template <int L, int M, bool M0, int U>
 __global__ void rotate_back_scatter_kernel(Segs msg, const float* __restrict__ alpha, const float* __restrict__ wr,
                                            const int* __restrict__ row_ptr, float* __restrict__ out, int N, int CH,
                                            int vh, float out_scale) {
     using I = SO3Idx<L, M>;
-    const int c = threadIdx.x;
-    if (c >= CH) return;
+    constexpr int NR = M0 ? L + 1 : I::KR;
+    const int act = threadIdx.x < CH;
+    const int c = act ? threadIdx.x : CH - 1;   // surplus lanes shadow the last channel (they only fetch Wigner rows)
+    const int lane = threadIdx.x & 63;
     const int heads = CH / vh;
     const int r0 = msg.rows[0], r01 = msg.rows[0] + msg.rows[1];
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
@@ -241,32 +286,57 @@ __global__ void rotate_back_scatter_kernel(Segs msg, const float* __restrict__ a
 #pragma unroll
         for (int k = 0; k < I::K; ++k) acc[k] = 0.f;
         const int beg = row_ptr[n], end = row_ptr[n + 1];
-        for (int e = beg; e < end; ++e) {
-            const float* W = wr + (long long)e * I::WSZ;
-            const float a = alpha ? alpha[(long long)e * heads + c / vh] : 1.f;
-            const float* b0 = msg.p[0] + (long long)e * msg.ld[0] + c;
-            const float* b1 = M0 ? b0 : msg.p[1] + (long long)e * msg.ld[1] + c - (long long)r0 * CH;
-            const float* b2 = M0 ? b0 : msg.p[2] + (long long)e * msg.ld[2] + c - (long long)r01 * CH;
+        for (int e0 = beg; e0 < end; e0 += U) {
+            float v[U][NR];
+            WRows<I::WSZ> W[U];
 #pragma unroll
-            for (int l = 0; l <= L; ++l) {
+            for (int u = 0; u < U; ++u) {
+                const bool ok = e0 + u < end;
+                const int e = ok ? e0 + u : end - 1;  // wave-uniform; out-of-range slots re-read the last edge, weight 0
+                W[u].load(wr + (long long)e * I::WSZ, lane);
+                const float a = ok ? (alpha ? alpha[(long long)e * heads + c / vh] : 1.f) : 0.f;
+                const float* b0 = msg.p[0] + (long long)e * msg.ld[0] + c;
+                const float* b1 = M0 ? b0 : msg.p[1] + (long long)e * msg.ld[1] + c - (long long)r0 * CH;
+                const float* b2 = M0 ? b0 : msg.p[2] + (long long)e * msg.ld[2] + c - (long long)r01 * CH;
+                int ri = 0;
 #pragma unroll
-                for (int mi = 0; mi < I::nr(l); ++mi) {
-                    const int m = mi - I::mm(l);
-                    if (M0 && m != 0) continue;
-                    const int q = I::mpos(l, m);
-                    const float* bp = q < r0 ? b0 : (q < r01 ? b1 : b2);
-                    const float v = bp[(long long)q * CH] * a;
+                for (int l = 0; l <= L; ++l) {
 #pragma unroll
-                    for (int j = 0; j < 2 * l + 1; ++j)
-                        acc[l * l + j] = fmaf(W[I::w_off(l) + mi * (2 * l + 1) + j], v, acc[l * l + j]);
+                    for (int mi = 0; mi < I::nr(l); ++mi) {
+                        const int m = mi - I::mm(l);
+                        if (M0 && m != 0) continue;
+                        const int q = I::mpos(l, m);
+                        const float* bp = q < r0 ? b0 : (q < r01 ? b1 : b2);
+                        v[u][M0 ? l : I::kr_off(l) + mi] = bp[(long long)q * CH] * a;
+                        ++ri;
+                    }
+                }
+                (void)ri;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int l = 0; l <= L; ++l) {
+#pragma unroll
+                    for (int mi = 0; mi < I::nr(l); ++mi) {
+                        const int m = mi - I::mm(l);
+                        if (M0 && m != 0) continue;
+                        const float x = v[u][M0 ? l : I::kr_off(l) + mi];
+#pragma unroll
+                        for (int j = 0; j < 2 * l + 1; ++j)
+                            acc[l * l + j] = fmaf(W_AT(W[u], I::w_off(l) + mi * (2 * l + 1) + j), x, acc[l * l + j]);
+                    }
                 }
             }
         }
-        float* o = out + (long long)n * I::K * CH + c;
+        if (act) {
+            float* o = out + (long long)n * I::K * CH + c;
 #pragma unroll
-        for (int l = 0; l <= L; ++l) {
+            for (int l = 0; l <= L; ++l) {
 #pragma unroll
-            for (int j = 0; j < 2 * l + 1; ++j) o[(long long)(l * l + j) * CH] = acc[l * l + j] * (rescale_of(l, M) * out_scale);
+                for (int j = 0; j < 2 * l + 1; ++j)
+                    o[(long long)(l * l + j) * CH] = acc[l * l + j] * (rescale_of(l, M) * out_scale);
+            }
         }
     }
 }
@@ -279,8 +349,9 @@ __global__ void rotate_back_scatter_bwd_kernel(const float* __restrict__ g_out, 
                                                const int* __restrict__ row_ptr, float* __restrict__ g_alpha_part, int N,
                                                int CH, int vh, float out_scale) {
     using I = SO3Idx<L, M>;
-    const int c = threadIdx.x;
-    if (c >= CH) return;
+    const bool act = threadIdx.x < CH;
+    const int c = act ? threadIdx.x : CH - 1;   // surplus lanes shadow the last channel and never store
+    const int lane = threadIdx.x & 63;
     const int heads = CH / vh;
     const int r0 = gmsg.rows[0], r01 = gmsg.rows[0] + gmsg.rows[1];
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
@@ -293,7 +364,8 @@ __global__ void rotate_back_scatter_bwd_kernel(const float* __restrict__ g_out, 
         }
         const int beg = row_ptr[n], end = row_ptr[n + 1];
         for (int e = beg; e < end; ++e) {
-            const float* W = wr + (long long)e * I::WSZ;
+            WRows<I::WSZ> W;
+            W.load(wr + (long long)e * I::WSZ, lane);
             const float a = alpha ? alpha[(long long)e * heads + c / vh] : 1.f;
             const float* b0 = alpha ? msg.p[0] + (long long)e * msg.ld[0] + c : nullptr;
             const float* b1 = (M0 || !alpha) ? b0 : msg.p[1] + (long long)e * msg.ld[1] + c - (long long)r0 * CH;
@@ -311,16 +383,16 @@ __global__ void rotate_back_scatter_bwd_kernel(const float* __restrict__ g_out, 
                     const int q = I::mpos(l, m);
                     float t = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 2 * l + 1; ++j) t = fmaf(W[I::w_off(l) + mi * (2 * l + 1) + j], g[l * l + j], t);
+                    for (int j = 0; j < 2 * l + 1; ++j) t = fmaf(W_AT(W, I::w_off(l) + mi * (2 * l + 1) + j), g[l * l + j], t);
                     float* op = q < r0 ? o0 : (q < r01 ? o1 : o2);
-                    op[(long long)q * CH] = a * t;
+                    if (act) op[(long long)q * CH] = a * t;
                     if (alpha) {
                         const float* bp = q < r0 ? b0 : (q < r01 ? b1 : b2);
                         part = fmaf(bp[(long long)q * CH], t, part);
                     }
                 }
             }
-            if (alpha) g_alpha_part[(long long)e * CH + c] = part;
+            if (alpha && act) g_alpha_part[(long long)e * CH + c] = part;
         }
     }
 }
@@ -395,6 +467,208 @@ __global__ void segment_wsum_bwd_kernel(const float* __restrict__ g_out, const f
             for (int o = F >> 1; o > 0; o >>= 1) p += __shfl_xor(p, o, 64);
             if (act && (t % F) == 0) gw[(long long)e * H + h] = p;
         }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ k15b: fused graph attention
+// CProMG MultiHeadAttention (CP:59-74) with weight_k_lin / weight_v_lin hoisted to node level by linearity:
+//   qk[e,h]   = scale * sum_d qp[row,h,d] * wk[e,d] * hk[col,h,d] + cterm[row,h]
+//   out[n,h,f] = sum_e alpha[e,h] * wv[e,f] * hv[col_e,h,f]
+// so that no [E,H,D] / [E,H,F] tensor is ever materialised.  Edges are sorted by row (the centre node).
+__device__ __forceinline__ float group_sum(float v, int width) {  // butterfly over `width` consecutive lanes
+    for (int o = width >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One wavefront per centre node; lane = (slot, d) with D lanes per slot and 64/D edge slots; loop over heads.
+template <int D, int H>
+__global__ void __launch_bounds__(64) edge_logits_fwd_kernel(const float* __restrict__ qp, const float* __restrict__ wk,
+                                                             const float* __restrict__ hk, const float* __restrict__ cterm,
+                                                             const int* __restrict__ row_ptr, const int* __restrict__ col,
+                                                             float* __restrict__ qk, int N, float scale) {
+    constexpr int SL = 64 / D;
+    const int lane = threadIdx.x, d = lane % D, slot = lane / D;
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        float q[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) q[h] = qp[((long long)n * H + h) * D + d] * scale;
+        const int beg = row_ptr[n], end = row_ptr[n + 1];
+        for (int e0 = beg; e0 < end; e0 += SL) {
+            const int e = e0 + slot;
+            const bool ok = e < end;
+            const int j = ok ? col[e] : 0;
+            const float w = ok ? wk[(long long)e * D + d] : 0.f;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                float p = ok ? q[h] * w * hk[((long long)j * H + h) * D + d] : 0.f;
+                p = group_sum(p, D);
+                if (ok && d == 0) qk[(long long)e * H + h] = p + cterm[(long long)n * H + h];
+            }
+        }
+    }
+}
+
+// grads w.r.t. qp (and cterm) and wk: same walk.  g_qp[n,h,d] = scale * sum_e g[e,h] wk[e,d] hk[col,h,d];
+// g_wk[e,d] = scale * sum_h g[e,h] qp[n,h,d] hk[col,h,d];  g_cterm[n,h] = sum_e g[e,h].
+template <int D, int H>
+__global__ void __launch_bounds__(64) edge_logits_bwd_row_kernel(const float* __restrict__ g, const float* __restrict__ qp,
+                                                                 const float* __restrict__ wk, const float* __restrict__ hk,
+                                                                 const int* __restrict__ row_ptr, const int* __restrict__ col,
+                                                                 float* __restrict__ g_qp, float* __restrict__ g_wk,
+                                                                 float* __restrict__ g_cterm, int N, float scale) {
+    constexpr int SL = 64 / D;
+    const int lane = threadIdx.x, d = lane % D, slot = lane / D;
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        float q[H], aq[H], ac[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            q[h] = qp[((long long)n * H + h) * D + d] * scale;
+            aq[h] = 0.f;
+            ac[h] = 0.f;
+        }
+        const int beg = row_ptr[n], end = row_ptr[n + 1];
+        for (int e0 = beg; e0 < end; e0 += SL) {
+            const int e = e0 + slot;
+            if (e < end) {
+                const int j = col[e];
+                const float w = wk[(long long)e * D + d];
+                float gw = 0.f;
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const float ge = g[(long long)e * H + h];
+                    const float k = hk[((long long)j * H + h) * D + d];
+                    aq[h] = fmaf(ge * w, k, aq[h]);
+                    gw = fmaf(ge * q[h], k, gw);
+                    ac[h] += ge;
+                }
+                g_wk[(long long)e * D + d] = gw;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float a = aq[h], c = ac[h];
+            for (int o = D; o < 64; o <<= 1) {  // combine the edge slots
+                a += __shfl_xor(a, o, 64);
+                c += __shfl_xor(c, o, 64);
+            }
+            if (slot == 0) g_qp[((long long)n * H + h) * D + d] = a * scale;
+            if (lane == 0) g_cterm[(long long)n * H + h] = c;
+        }
+    }
+}
+
+// grad w.r.t. hk, by neighbour node j over the edges that have col == j (eperm = edge ids sorted by col):
+// g_hk[j,h,d] = scale * sum_e g[e,h] qp[row_e,h,d] wk[e,d].
+template <int D, int H>
+__global__ void __launch_bounds__(64) edge_logits_bwd_col_kernel(const float* __restrict__ g, const float* __restrict__ qp,
+                                                                 const float* __restrict__ wk, const int* __restrict__ col_ptr,
+                                                                 const int* __restrict__ eperm, const int* __restrict__ row,
+                                                                 float* __restrict__ g_hk, int N, float scale) {
+    constexpr int SL = 64 / D;
+    const int lane = threadIdx.x, d = lane % D, slot = lane / D;
+    for (int j = blockIdx.x; j < N; j += gridDim.x) {
+        float acc[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) acc[h] = 0.f;
+        const int beg = col_ptr[j], end = col_ptr[j + 1];
+        for (int i0 = beg; i0 < end; i0 += SL) {
+            const int i = i0 + slot;
+            if (i < end) {
+                const int e = eperm[i];
+                const int n = row[e];
+                const float w = wk[(long long)e * D + d];
+#pragma unroll
+                for (int h = 0; h < H; ++h)
+                    acc[h] = fmaf(g[(long long)e * H + h] * w, qp[((long long)n * H + h) * D + d], acc[h]);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            float a = acc[h];
+            for (int o = D; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+            if (slot == 0) g_hk[((long long)j * H + h) * D + d] = a * scale;
+        }
+    }
+}
+
+// out[n,h,f] = sum_e alpha[e,h] * wv[e,f] * hv[col_e,h,f]; one wavefront per centre node, lane = f (F = 64).
+template <int H>
+__global__ void __launch_bounds__(64) gather_wsum_fwd_kernel(const float* __restrict__ alpha, const float* __restrict__ wv,
+                                                             const float* __restrict__ hv, const int* __restrict__ row_ptr,
+                                                             const int* __restrict__ col, float* __restrict__ out, int N) {
+    constexpr int F = 64;
+    const int f = threadIdx.x;
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        float acc[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) acc[h] = 0.f;
+        const int beg = row_ptr[n], end = row_ptr[n + 1];
+        for (int e = beg; e < end; ++e) {
+            const int j = col[e];
+            const float w = wv[(long long)e * F + f];
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+                acc[h] = fmaf(alpha[(long long)e * H + h] * w, hv[((long long)j * H + h) * F + f], acc[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) out[((long long)n * H + h) * F + f] = acc[h];
+    }
+}
+
+// g_alpha[e,h] = sum_f g[n,h,f] wv[e,f] hv[col,h,f];  g_wv[e,f] = sum_h g[n,h,f] alpha[e,h] hv[col,h,f].
+template <int H>
+__global__ void __launch_bounds__(64) gather_wsum_bwd_row_kernel(const float* __restrict__ g, const float* __restrict__ alpha,
+                                                                 const float* __restrict__ wv, const float* __restrict__ hv,
+                                                                 const int* __restrict__ row_ptr, const int* __restrict__ col,
+                                                                 float* __restrict__ g_alpha, float* __restrict__ g_wv, int N) {
+    constexpr int F = 64;
+    const int f = threadIdx.x;
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+        float gn[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) gn[h] = g[((long long)n * H + h) * F + f];
+        const int beg = row_ptr[n], end = row_ptr[n + 1];
+        for (int e = beg; e < end; ++e) {
+            const int j = col[e];
+            const float w = wv[(long long)e * F + f];
+            float gw = 0.f;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const float v = hv[((long long)j * H + h) * F + f];
+                const float t = gn[h] * v;
+                gw = fmaf(t, alpha[(long long)e * H + h], gw);
+                const float pa = group_sum(t * w, 64);
+                if (f == 0) g_alpha[(long long)e * H + h] = pa;
+            }
+            g_wv[(long long)e * F + f] = gw;
+        }
+    }
+}
+
+// g_hv[j,h,f] = sum_{e: col_e = j} alpha[e,h] wv[e,f] g[row_e,h,f].
+template <int H>
+__global__ void __launch_bounds__(64) gather_wsum_bwd_col_kernel(const float* __restrict__ g, const float* __restrict__ alpha,
+                                                                 const float* __restrict__ wv, const int* __restrict__ col_ptr,
+                                                                 const int* __restrict__ eperm, const int* __restrict__ row,
+                                                                 float* __restrict__ g_hv, int N) {
+    constexpr int F = 64;
+    const int f = threadIdx.x;
+    for (int j = blockIdx.x; j < N; j += gridDim.x) {
+        float acc[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) acc[h] = 0.f;
+        const int beg = col_ptr[j], end = col_ptr[j + 1];
+        for (int i = beg; i < end; ++i) {
+            const int e = eperm[i];
+            const int n = row[e];
+            const float w = wv[(long long)e * F + f];
+#pragma unroll
+            for (int h = 0; h < H; ++h)
+                acc[h] = fmaf(alpha[(long long)e * H + h] * w, g[((long long)n * H + h) * F + f], acc[h]);
+        }
+#pragma unroll
+        for (int h = 0; h < H; ++h) g_hv[((long long)j * H + h) * F + f] = acc[h];
     }
 }
 
@@ -648,10 +922,53 @@ bool pack_mut(const singa_seg_mut_t* s, int nseg, SegsMut* out) {
         }                                                                               \
     } while (0)
 
+// Calibration kernel for the PMC byte counters (MI355X_MICROARCH.md §HBM: FETCH_SIZE is only calibrated for 16-B
+// lanes): copies n floats with the access shape of the segment kernels (one dword per lane, 256 B per wave-instruction)
+// so that a known byte count can be compared with FETCH_SIZE / WRITE_SIZE.
+__global__ void calib_copy_kernel(const float* __restrict__ src, float* __restrict__ dst, long long n) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
 }  // namespace
 
 // ================================================================================================= C ABI
 extern "C" {
+
+int singa_prof_enable(int on) {
+    g_prof_on = on != 0;
+    return SINGA_OK;
+}
+
+int singa_prof_hint_edges(int E) {
+    g_prof_edges_hint = E;
+    return SINGA_OK;
+}
+
+int singa_prof_collect(float* ms, int* edges, int* nodes, int cap) {
+    int n = 0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        float t = 0.f;
+        hipError_t e = hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b);
+        if (e == hipSuccess && n < cap) {
+            ms[n] = t;
+            edges[n] = g_prof[i].E;
+            nodes[n] = g_prof[i].N;
+            ++n;
+        }
+        (void)hipEventDestroy(g_prof[i].a);
+        (void)hipEventDestroy(g_prof[i].b);
+    }
+    g_prof_n = 0;
+    return n;
+}
+
+int singa_calib_copy(const float* src, float* dst, long long n, void* stream) {
+    if (!src || !dst) return fail(SINGA_E_NULL, "calib_copy: null pointer");
+    hipLaunchKernelGGL(calib_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, src, dst, n);
+    return check_launch("calib_copy");
+}
 
 int singa_version(void) { return 100; }
 
@@ -740,14 +1057,24 @@ int singa_rotate_back_scatter_fwd(const singa_seg_t* msg, int nseg, const float*
     if (!m0_only && nseg != 3) return fail(SINGA_E_SHAPE, "rotate_back_scatter: full mode takes the 3 per-m segments");
     if (Nd <= 0) return SINGA_OK;
     int bs = CH <= 64 ? 64 : 128;
+    const int n_edges_hint = g_prof_edges_hint;
     SINGA_DISPATCH_L(lmax, mmax, {
         if (!m0_only && (s.rows[0] != L_ + 1 || s.rows[1] != 2 * L_ || s.rows[2] != 2 * (L_ - 1)))
             return fail(SINGA_E_SHAPE, "rotate_back_scatter: segment row counts must be L+1, 2L, 2(L-1)");
         if (m0_only)
-            hipLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, true>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
+            hipLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, true, 4>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
                                (hipStream_t)stream, s, alpha, wr, row_ptr, out, Nd, CH, CH / heads, out_scale);
-        else
-            hipLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, false>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
+        else if (g_prof_on && g_prof_n < PROF_CAP) {
+            ProfRec& r = g_prof[g_prof_n++];
+            (void)hipEventCreate(&r.a);
+            (void)hipEventCreate(&r.b);
+            r.E = n_edges_hint;
+            r.N = Nd;
+            hipExtLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, false, (L_ == 2 ? 4 : (L_ == 4 ? 2 : 1))>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
+                                  (hipStream_t)stream, r.a, r.b, 0, s, alpha, wr, row_ptr, out, Nd, CH, CH / heads,
+                                  out_scale);
+        } else
+            hipLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, false, (L_ == 2 ? 4 : (L_ == 4 ? 2 : 1))>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
                                (hipStream_t)stream, s, alpha, wr, row_ptr, out, Nd, CH, CH / heads, out_scale);
     });
     return check_launch("rotate_back_scatter_fwd");
@@ -859,6 +1186,55 @@ int singa_s2act_bwd(const singa_seg_t* x, int nseg, const float* gate, int64_t l
     SINGA_DISPATCH_KIN(KIN, hipLaunchKernelGGL((s2act_bwd_kernel<KIN_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                                                s, gate, (long long)ldg, to_grid, from_grid, g_out, gx, g_gate, EC, C, G));
     return check_launch("s2act_bwd");
+}
+
+int singa_edge_logits_fwd(const float* qp, const float* wk, const float* hk, const float* cterm, const int32_t* row_ptr,
+                          const int32_t* col, float* qk, int N, int H, int D, float scale, void* stream) {
+    if (!qp || !wk || !hk || !cterm || !row_ptr || !col || !qk) return fail(SINGA_E_NULL, "edge_logits_fwd: null pointer");
+    if (H != 4 || D != 32) return fail(SINGA_E_SHAPE, "edge_logits: built for H = 4 heads, D = 32 key channels per head");
+    if (N <= 0) return SINGA_OK;
+    hipLaunchKernelGGL((edge_logits_fwd_kernel<32, 4>), dim3(grid_for(N, 1 << 20)), dim3(64), 0, (hipStream_t)stream, qp, wk,
+                       hk, cterm, row_ptr, col, qk, N, scale);
+    return check_launch("edge_logits_fwd");
+}
+
+int singa_edge_logits_bwd(const float* g, const float* qp, const float* wk, const float* hk, const int32_t* row_ptr,
+                          const int32_t* col, const int32_t* col_ptr, const int32_t* eperm, const int32_t* row,
+                          float* g_qp, float* g_wk, float* g_hk, float* g_cterm, int N, int H, int D, float scale,
+                          void* stream) {
+    if (!g || !qp || !wk || !hk || !row_ptr || !col || !col_ptr || !eperm || !row || !g_qp || !g_wk || !g_hk || !g_cterm)
+        return fail(SINGA_E_NULL, "edge_logits_bwd: null pointer");
+    if (H != 4 || D != 32) return fail(SINGA_E_SHAPE, "edge_logits: built for H = 4 heads, D = 32 key channels per head");
+    if (N <= 0) return SINGA_OK;
+    hipLaunchKernelGGL((edge_logits_bwd_row_kernel<32, 4>), dim3(grid_for(N, 1 << 20)), dim3(64), 0, (hipStream_t)stream, g,
+                       qp, wk, hk, row_ptr, col, g_qp, g_wk, g_cterm, N, scale);
+    hipLaunchKernelGGL((edge_logits_bwd_col_kernel<32, 4>), dim3(grid_for(N, 1 << 20)), dim3(64), 0, (hipStream_t)stream, g,
+                       qp, wk, col_ptr, eperm, row, g_hk, N, scale);
+    return check_launch("edge_logits_bwd");
+}
+
+int singa_gather_wsum_fwd(const float* alpha, const float* wv, const float* hv, const int32_t* row_ptr, const int32_t* col,
+                          float* out, int N, int H, int F, void* stream) {
+    if (!alpha || !wv || !hv || !row_ptr || !col || !out) return fail(SINGA_E_NULL, "gather_wsum_fwd: null pointer");
+    if (H != 4 || F != 64) return fail(SINGA_E_SHAPE, "gather_wsum: built for H = 4 heads, F = 64 value channels per head");
+    if (N <= 0) return SINGA_OK;
+    hipLaunchKernelGGL((gather_wsum_fwd_kernel<4>), dim3(grid_for(N, 1 << 20)), dim3(64), 0, (hipStream_t)stream, alpha, wv,
+                       hv, row_ptr, col, out, N);
+    return check_launch("gather_wsum_fwd");
+}
+
+int singa_gather_wsum_bwd(const float* g, const float* alpha, const float* wv, const float* hv, const int32_t* row_ptr,
+                          const int32_t* col, const int32_t* col_ptr, const int32_t* eperm, const int32_t* row,
+                          float* g_alpha, float* g_wv, float* g_hv, int N, int H, int F, void* stream) {
+    if (!g || !alpha || !wv || !hv || !row_ptr || !col || !col_ptr || !eperm || !row || !g_alpha || !g_wv || !g_hv)
+        return fail(SINGA_E_NULL, "gather_wsum_bwd: null pointer");
+    if (H != 4 || F != 64) return fail(SINGA_E_SHAPE, "gather_wsum: built for H = 4 heads, F = 64 value channels per head");
+    if (N <= 0) return SINGA_OK;
+    hipLaunchKernelGGL((gather_wsum_bwd_row_kernel<4>), dim3(grid_for(N, 1 << 20)), dim3(64), 0, (hipStream_t)stream, g,
+                       alpha, wv, hv, row_ptr, col, g_alpha, g_wv, N);
+    hipLaunchKernelGGL((gather_wsum_bwd_col_kernel<4>), dim3(grid_for(N, 1 << 20)), dim3(64), 0, (hipStream_t)stream, g,
+                       alpha, wv, col_ptr, eperm, row, g_hv, N);
+    return check_launch("gather_wsum_bwd");
 }
 
 int singa_so3_rmsnorm_nparts(int N) { return grid_for(N, 2048); }

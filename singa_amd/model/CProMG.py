@@ -91,10 +91,16 @@ class KnnEdges:
         row, col = torch.cat([row, loop]), torch.cat([col, loop])
         attr = torch.cat([-ea, deg], 0)
         order = torch.argsort(row, stable=True)
-        self.row, self.col, self.attr = row[order], col[order], attr[order]
+        self.row, self.col, self.attr = row[order], col[order], attr[order].contiguous()
         rp = torch.zeros(N + 1, dtype=torch.int64, device=pos.device)
         rp[1:] = torch.bincount(self.row, minlength=N).cumsum(0)
         self.row_ptr = rp.to(torch.int32)
+        self.row32, self.col32 = self.row.to(torch.int32), self.col.to(torch.int32)
+        # edges grouped by neighbour (col): needed by the gradients of the gathered key / value rows
+        self.eperm = torch.argsort(self.col, stable=True).to(torch.int32)
+        cp = torch.zeros(N + 1, dtype=torch.int64, device=pos.device)
+        cp[1:] = torch.bincount(self.col, minlength=N).cumsum(0)
+        self.col_ptr = cp.to(torch.int32)
         self.N = N
 
 
@@ -125,16 +131,26 @@ class MultiHeadAttention(nn.Module):
         og, ig = w.shape[0] // heads, w.shape[1]
         return torch.bmm(h.view(N, heads, ig).transpose(0, 1), w.view(heads, og, ig).transpose(1, 2)).transpose(0, 1)
 
+    def _edge_mlp(self, net, x):
+        h = self.act(ops.skinny_linear(x, net[0].weight, net[0].bias))
+        return ops.skinny_linear(h, net[2].weight, net[2].bias)
+
     def forward(self, node_attr, edges: KnnEdges):
+        """CP:50-78.  weight_k_lin and weight_v_lin act on the last axis only, so they commute with the per-edge
+        scaling and with the alpha-weighted sum: q.(W(w*k)+b) = (qW).(w*k) + q.b and sum_e a_e (W(w_e*v)+b) =
+        W sum_e a_e (w_e*v) + b (sum_e a_e = 1).  They are therefore applied to NODE tensors, and the two per-edge
+        contractions run as fused gather kernels without any [E,heads,channels] intermediate."""
         N = node_attr.size(0)
         h_keys, h_queries, h_values = (self._grouped(c, node_attr) for c in (self.k_lin, self.q_lin, self.v_lin))
-        W_k = self.weight_k_net(edges.attr)
-        keys_j = self.weight_k_lin(W_k.unsqueeze(1) * h_keys[edges.col])
-        qk_ij = (h_queries[edges.row] * keys_j).sum(-1) / np.sqrt(keys_j.size(-1))
+        scale = 1.0 / math.sqrt(h_keys.size(-1))
+        W_k = self._edge_mlp(self.weight_k_net, edges.attr)                      # [E, 32]
+        W_v = self._edge_mlp(self.weight_v_net, edges.attr)                      # [E, 64]
+        qp = torch.matmul(h_queries, self.weight_k_lin.weight)                   # (q W)[n,h,:]
+        cterm = (h_queries * self.weight_k_lin.bias).sum(-1) * scale
+        qk_ij = ops.edge_logits(qp, W_k, h_keys, cterm, edges, scale)
         alpha = ops.segment_softmax(qk_ij, edges.row_ptr, 0.0)
-        W_v = self.weight_v_net(edges.attr)
-        msg_j = self.weight_v_lin(W_v.unsqueeze(1) * h_values[edges.col])
-        aggr_msg = ops.segment_wsum(alpha, msg_j, edges.row_ptr).view(N, -1)
+        S = ops.gather_wsum(alpha, W_v, h_values, edges)                         # [N, heads, 64]
+        aggr_msg = F.linear(S, self.weight_v_lin.weight, self.weight_v_lin.bias).view(N, -1)
         out = self.centroid_lin(node_attr) + aggr_msg
         return self.layer_norm(self.out_transform(self.act(out)))
 

@@ -12,33 +12,31 @@ import torch
 from . import _capi, _lib, so3
 
 
-# Optional per-launch timing (bench.py): when PROFILE_ON, selected launches are bracketed by HIP events recorded on
-# the stream the kernel is enqueued on (torch's current stream) and appended to PROFILE[name] as
-# (start_event, end_event, n_edges, n_dst_nodes).
-PROFILE = {}
+# Optional exact timing of the scatter-TP forward dispatches (bench.py): while PROFILE_ON, the library attaches a
+# start and a stop event to each such dispatch on the stream it is launched on (singa_prof_enable / _collect).
 PROFILE_ON = False
+
+
+def profile_start():
+    global PROFILE_ON
+    PROFILE_ON = True
+    _chk(_lib.lib().singa_prof_enable(1), "singa_prof_enable")
+
+
+def profile_collect():
+    """Call after torch.cuda.synchronize().  Returns [(ms, n_edges, n_dst_nodes)] for every profiled dispatch."""
+    global PROFILE_ON
+    PROFILE_ON = False
+    lib = _lib.lib()
+    _chk(lib.singa_prof_enable(0), "singa_prof_enable")
+    cap = 8192
+    ms, ne, nn = (ctypes.c_float * cap)(), (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
+    n = lib.singa_prof_collect(ms, ne, nn, cap)
+    return [(ms[i], ne[i], nn[i]) for i in range(n)]
 
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
-class _timed:
-    def __init__(self, name, E, N):
-        self.name, self.E, self.N = name, E, N
-
-    def __enter__(self):
-        if PROFILE_ON:
-            self.a = torch.cuda.Event(enable_timing=True)
-            self.b = torch.cuda.Event(enable_timing=True)
-            self.a.record()
-        return self
-
-    def __exit__(self, *exc):
-        if PROFILE_ON:
-            self.b.record()
-            PROFILE.setdefault(self.name, []).append((self.a, self.b, self.E, self.N))
-        return False
 
 
 def _p(t):
@@ -103,9 +101,8 @@ class _GatherRotate(torch.autograd.Function):
         assert x_src.shape[1] == lay.K and x_dst.shape[1] == lay.K and wr.shape == (es.E, lay.WSZ)
         assert x_src.shape[0] == es.n_src and x_dst.shape[0] == es.n_dst and rad.shape == (es.E, lay.rad_rows * 2 * C)
         out = torch.empty(es.E, lay.KR * 2 * C, device=x_src.device, dtype=torch.float32)
-        with _timed("gather_rotate_fwd", es.E, es.n_dst):
-            _chk(_lib.lib().singa_gather_rotate_fwd(_p(x_src), _p(x_dst), _p(es.src), _p(es.dst), _p(wr), _p(rad),
-                                                    _p(out), es.E, C, L, M, _stream()), "singa_gather_rotate_fwd")
+        _chk(_lib.lib().singa_gather_rotate_fwd(_p(x_src), _p(x_dst), _p(es.src), _p(es.dst), _p(wr), _p(rad), _p(out),
+                                                es.E, C, L, M, _stream()), "singa_gather_rotate_fwd")
         ctx.save_for_backward(x_src, x_dst, rad, wr)
         ctx.es, ctx.L, ctx.M = es, L, M
         return out
@@ -145,10 +142,10 @@ class _RotateBackScatter(torch.autograd.Function):
         assert alpha.shape == (es.E, heads) and wr.shape == (es.E, lay.WSZ)
         out = torch.empty(es.n_dst, lay.K, CH, device=y0.device, dtype=torch.float32)
         seg, n = _segs3((y0, y1, y2), lay.seg_rows, CH)
-        with _timed("rotate_back_scatter_fwd", es.E, es.n_dst):
-            _chk(_lib.lib().singa_rotate_back_scatter_fwd(seg, n, _p(alpha), _p(wr), _p(es.row_ptr), _p(out), es.n_dst,
-                                                          CH, heads, L, M, 0, 1.0, _stream()),
-                 "singa_rotate_back_scatter_fwd")
+        if PROFILE_ON:
+            _lib.lib().singa_prof_hint_edges(es.E)
+        _chk(_lib.lib().singa_rotate_back_scatter_fwd(seg, n, _p(alpha), _p(wr), _p(es.row_ptr), _p(out), es.n_dst, CH,
+                                                      heads, L, M, 0, 1.0, _stream()), "singa_rotate_back_scatter_fwd")
         ctx.save_for_backward(y0, y1, y2, alpha, wr)
         ctx.es, ctx.heads, ctx.L, ctx.M, ctx.CH = es, heads, L, M, CH
         return out
@@ -398,3 +395,100 @@ class _SO3RMSNorm(torch.autograd.Function):
 def so3_rmsnorm(x, weight, bias, L, eps=1e-5):
     """k12: centred, degree-balanced RMS norm with per-degree affine weight and l=0 bias (EF:2155-2192, Q3)."""
     return _SO3RMSNorm.apply(x, weight, bias, L, eps)
+
+
+# ----------------------------------------------------------------------------------------------- fused graph attention
+class _EdgeLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qp, wk, hk, cterm, edges, scale):
+        qp, wk, hk, cterm = qp.contiguous(), wk.contiguous(), hk.contiguous(), cterm.contiguous()
+        _dev(qp, wk, hk, cterm)
+        N, H, D = qp.shape
+        qk = torch.empty(wk.shape[0], H, device=qp.device, dtype=torch.float32)
+        _chk(_lib.lib().singa_edge_logits_fwd(_p(qp), _p(wk), _p(hk), _p(cterm), _p(edges.row_ptr), _p(edges.col32),
+                                              _p(qk), N, H, D, scale, _stream()), "singa_edge_logits_fwd")
+        ctx.save_for_backward(qp, wk, hk)
+        ctx.edges, ctx.scale = edges, scale
+        return qk
+
+    @staticmethod
+    def backward(ctx, g):
+        qp, wk, hk = ctx.saved_tensors
+        e, N, H, D = ctx.edges, qp.shape[0], qp.shape[1], qp.shape[2]
+        g = g.contiguous()
+        g_qp, g_wk, g_hk = torch.empty_like(qp), torch.empty_like(wk), torch.empty_like(hk)
+        g_c = torch.empty(N, H, device=g.device, dtype=torch.float32)
+        _chk(_lib.lib().singa_edge_logits_bwd(_p(g), _p(qp), _p(wk), _p(hk), _p(e.row_ptr), _p(e.col32), _p(e.col_ptr),
+                                              _p(e.eperm), _p(e.row32), _p(g_qp), _p(g_wk), _p(g_hk), _p(g_c), N, H, D,
+                                              ctx.scale, _stream()), "singa_edge_logits_bwd")
+        return g_qp, g_wk, g_hk, g_c, None, None
+
+
+def edge_logits(qp, wk, hk, cterm, edges, scale):
+    """qk[e,h] = scale * sum_d qp[row,h,d] wk[e,d] hk[col,h,d] + cterm[row,h]  (CP:61-65 with weight_k_lin hoisted)."""
+    return _EdgeLogits.apply(qp, wk, hk, cterm, edges, scale)
+
+
+class _GatherWSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, alpha, wv, hv, edges):
+        alpha, wv, hv = alpha.contiguous(), wv.contiguous(), hv.contiguous()
+        _dev(alpha, wv, hv)
+        N, H, F = hv.shape
+        out = torch.empty(N, H, F, device=hv.device, dtype=torch.float32)
+        _chk(_lib.lib().singa_gather_wsum_fwd(_p(alpha), _p(wv), _p(hv), _p(edges.row_ptr), _p(edges.col32), _p(out), N,
+                                              H, F, _stream()), "singa_gather_wsum_fwd")
+        ctx.save_for_backward(alpha, wv, hv)
+        ctx.edges = edges
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        alpha, wv, hv = ctx.saved_tensors
+        e = ctx.edges
+        N, H, F = hv.shape
+        g = g.contiguous()
+        g_a, g_wv, g_hv = torch.empty_like(alpha), torch.empty_like(wv), torch.empty_like(hv)
+        _chk(_lib.lib().singa_gather_wsum_bwd(_p(g), _p(alpha), _p(wv), _p(hv), _p(e.row_ptr), _p(e.col32), _p(e.col_ptr),
+                                              _p(e.eperm), _p(e.row32), _p(g_a), _p(g_wv), _p(g_hv), N, H, F, _stream()),
+             "singa_gather_wsum_bwd")
+        return g_a, g_wv, g_hv, None
+
+
+def gather_wsum(alpha, wv, hv, edges):
+    """out[n,h,f] = sum_e alpha[e,h] wv[e,f] hv[col_e,h,f]  (CP:70-74 with weight_v_lin hoisted)."""
+    return _GatherWSum.apply(alpha, wv, hv, edges)
+
+
+def _splitk_tn(a, b, chunk=8192):
+    """a^T @ b for tall-skinny a [M,p], b [M,q] (M >> p,q): batched split-K so that the library GEMM has enough
+    workgroups (a single [p,M]x[M,q] GEMM launches p*q/tile workgroups only)."""
+    M, p = a.shape
+    q = b.shape[1]
+    S = M // chunk
+    if S < 2:
+        return a.t() @ b
+    Mc = S * chunk
+    out = torch.bmm(a[:Mc].view(S, chunk, p).transpose(1, 2), b[:Mc].view(S, chunk, q)).sum(0)
+    if Mc < M:
+        out = out + a[Mc:].t() @ b[Mc:]
+    return out
+
+
+class _SkinnyLinear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        return g @ w, _splitk_tn(g, x), g.sum(0)
+
+
+def skinny_linear(x, w, b):
+    """F.linear for [M,K] inputs with M in the 10^5..10^6 range and K, N <= 64 (per-edge MLPs): same forward,
+    weight gradient by batched split-K."""
+    return _SkinnyLinear.apply(x, w, b)

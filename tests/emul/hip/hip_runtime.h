@@ -9,6 +9,9 @@
 #include <cstdlib>
 #include <cstring>
 
+// sequential threads have no lanes: a lane broadcast of the Wigner record becomes a plain memory read
+#define SINGA_LANE_BCAST(reg, lane, ptr, idx) ((ptr)[(idx)])
+
 #define __global__
 #define __device__
 #define __host__
@@ -38,6 +41,12 @@ static inline float __shfl_xor(float, int, int) {
     fprintf(stderr, "emul: cross-lane kernel cannot be emulated sequentially\n");
     abort();
 }
+
+typedef void* hipEvent_t;
+static inline hipError_t hipEventCreate(hipEvent_t*) { return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float* t, hipEvent_t, hipEvent_t) { *t = 0.f; return hipSuccess; }
+#define hipExtLaunchKernelGGL(kern, g, b, shmem, stream, ea, eb, fl, ...) hipLaunchKernelGGL(kern, g, b, shmem, stream, __VA_ARGS__)
 
 #define hipLaunchKernelGGL(kern, g, b, shmem, stream, ...)                  \
     do {                                                                    \

@@ -253,3 +253,68 @@ def test_so3_rmsnorm(L):
     lk = torch.as_tensor(so3.layout(L, L).degree)
     bal = (1.0 / ((2 * lk + 1).float() * (L + 1))).view(1, -1, 1)
     assert float((((y1 ** 2) * bal).sum(1).mean(1) - 1).abs().max()) < 1e-3
+
+
+def test_fused_graph_attention_ops():
+    """edge_logits / gather_wsum (fwd + bwd) against the un-fused reference formulation of CP:59-74."""
+    ops = _ops()
+    rs = np.random.RandomState(9)
+    N, E, H, D, F_ = 150, 4000, 4, 32, 64
+    row = torch.tensor(np.sort(rs.randint(0, N, E)), dtype=torch.int64)
+    col = torch.tensor(rs.randint(0, N, E), dtype=torch.int64)
+
+    class Edges:
+        pass
+    e = Edges()
+    rp = torch.zeros(N + 1, dtype=torch.int64)
+    rp[1:] = torch.bincount(row, minlength=N).cumsum(0)
+    cp = torch.zeros(N + 1, dtype=torch.int64)
+    cp[1:] = torch.bincount(col, minlength=N).cumsum(0)
+    e.row_ptr, e.col_ptr = rp.to(torch.int32).to(DEV), cp.to(torch.int32).to(DEV)
+    e.row32, e.col32 = row.to(torch.int32).to(DEV), col.to(torch.int32).to(DEV)
+    e.eperm = torch.argsort(col, stable=True).to(torch.int32).to(DEV)
+    t = lambda *s: torch.tensor(rs.randn(*s), dtype=torch.float32, requires_grad=True)
+    q, hk, wk, wkl, bkl = t(N, H, D), t(N, H, D), t(E, D), t(D, D), t(D)
+    keys = F_lin(wk.unsqueeze(1) * hk[col], wkl, bkl)
+    ref = (q[row] * keys).sum(-1) / np.sqrt(D)
+    g = torch.tensor(rs.randn(E, H), dtype=torch.float32)
+    ref.backward(g)
+    qg, hkg, wkg, wklg, bklg = (x.detach().to(DEV).requires_grad_(True) for x in (q, hk, wk, wkl, bkl))
+    scale = 1.0 / np.sqrt(D)
+    out = ops.edge_logits(torch.matmul(qg, wklg), wkg, hkg, (qg * bklg).sum(-1) * scale, e, scale)
+    assert rel(out, ref) < 1e-5
+    out.backward(g.to(DEV))
+    for a, b in ((qg, q), (hkg, hk), (wkg, wk), (wklg, wkl), (bklg, bkl)):
+        assert rel(a.grad, b.grad) < 2e-5
+    # value path
+    alpha, hv, wv, wvl, bvl = torch.tensor(rs.rand(E, H), dtype=torch.float32, requires_grad=True), t(N, H, F_), t(E, F_), t(F_, F_), t(F_)
+    msg = alpha.unsqueeze(-1) * F_lin(wv.unsqueeze(1) * hv[col], wvl, torch.zeros(F_))
+    ref = torch.zeros(N, H, F_).index_add_(0, row, msg)
+    g = torch.tensor(rs.randn(N, H, F_), dtype=torch.float32)
+    ref.backward(g)
+    ag, hvg, wvg, wvlg = (x.detach().to(DEV).requires_grad_(True) for x in (alpha, hv, wv, wvl))
+    out = F_lin(ops.gather_wsum(ag, wvg, hvg, e), wvlg, None)
+    assert rel(out, ref) < 1e-5
+    out.backward(g.to(DEV))
+    for a, b in ((ag, alpha), (hvg, hv), (wvg, wv), (wvlg, wvl)):
+        assert rel(a.grad, b.grad) < 2e-5
+
+
+def F_lin(x, w, b):
+    return torch.nn.functional.linear(x, w, b)
+
+
+def test_skinny_linear_split_k():
+    ops = _ops()
+    rs = np.random.RandomState(10)
+    x = torch.tensor(rs.randn(40000, 64), dtype=torch.float32, device=DEV, requires_grad=True)
+    w = torch.tensor(rs.randn(32, 64), dtype=torch.float32, device=DEV, requires_grad=True)
+    b = torch.tensor(rs.randn(32), dtype=torch.float32, device=DEV, requires_grad=True)
+    g = torch.tensor(rs.randn(40000, 32), dtype=torch.float32, device=DEV)
+    ref = F_lin(x, w, b)
+    ref.backward(g)
+    gx, gw, gb = x.grad.clone(), w.grad.clone(), b.grad.clone()
+    x.grad = w.grad = b.grad = None
+    out = ops.skinny_linear(x, w, b)
+    out.backward(g)
+    assert rel(out, ref) < 1e-6 and rel(x.grad, gx) < 1e-6 and rel(w.grad, gw) < 1e-5 and rel(b.grad, gb) < 1e-5

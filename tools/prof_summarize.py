@@ -1,0 +1,65 @@
+"""Condense rocprofv3 output (kernel_stats / kernel_trace / counter_collection CSVs) into small per-kernel summaries."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+raw, out = sys.argv[1], sys.argv[2]
+
+
+def short(name):
+    """'void (anonymous namespace)::kern<2, 2, false, 4>((anonymous namespace)::Segs, ...' -> 'kern<2, 2, false, 4>'"""
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    depth, out_ = 0, []
+    for ch in n:
+        if ch == "<":
+            depth += 1
+        if ch == "(" and depth == 0:
+            break
+        if ch == ">":
+            depth -= 1
+        out_.append(ch)
+    return "".join(out_)[:90]
+
+
+def first(pat):
+    g = glob.glob(os.path.join(raw, pat), recursive=True)
+    return g[0] if g else None
+
+
+f = first("trace/**/*kernel_stats.csv")
+if f:
+    rows = list(csv.DictReader(open(f)))
+    with open(os.path.join(out, "kernel_stats.csv"), "w", newline="") as o:
+        w = csv.DictWriter(o, fieldnames=rows[0].keys())
+        w.writeheader()
+        w.writerows(rows[:80])
+f = first("trace/**/*kernel_trace.csv")
+if f:  # per (kernel, grid) durations: the stats file mixes launches of different sizes under one name
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "anonymous namespace" in r["Kernel_Name"] and "at::" not in r["Kernel_Name"]:
+            agg[(short(r["Kernel_Name"]), r["Grid_Size_X"], r["Workgroup_Size_X"], r["VGPR_Count"], r["SGPR_Count"])].append(
+                int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(os.path.join(out, "singa_kernels_by_grid.csv"), "w", newline="") as o:
+        w = csv.writer(o)
+        w.writerow(["kernel", "grid_x", "wg_x", "vgpr", "sgpr", "calls", "avg_us", "min_us", "max_us", "total_ms"])
+        for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+            w.writerow(list(k) + [len(v), round(sum(v) / len(v) / 1e3, 2), round(min(v) / 1e3, 2), round(max(v) / 1e3, 2),
+                                  round(sum(v) / 1e6, 3)])
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = first(f"pmc_{c}/**/*counter_collection.csv")
+    if not f:
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        name = r.get("Kernel_Name", "")
+        if ("anonymous namespace" in name and "at::" not in name) or "calib_copy" in name:
+            agg[(short(name), r.get("Grid_Size", r.get("Grid_Size_X", "")), r.get("Counter_Name", c))].append(
+                float(r["Counter_Value"]))
+    with open(os.path.join(out, f"pmc_{c}.csv"), "w", newline="") as o:
+        w = csv.writer(o)
+        w.writerow(["kernel", "grid", "counter", "dispatches", "avg_value", "min", "max"])
+        for k, v in sorted(agg.items()):
+            w.writerow(list(k) + [len(v), sum(v) / len(v), min(v), max(v)])
