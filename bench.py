@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2_b32_l2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
+    ap.add_argument("--roofline-steps", type=int, default=3, help="instrumented eager steps after the timed region")
     ap.add_argument("--cpu-graphs", type=int, default=12, help="graphs in the bounded CPU-oracle sample")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
@@ -158,48 +160,53 @@ def main():
     model.train()
     reducer = dp.GradAllReducer(model)
     reducer.check_same_init()
+    use_graph = not args.eager
     opt = torch.optim.Adam(model.parameters(), lr=cfg.train.optimizer.lr,
-                           betas=(cfg.train.optimizer.beta1, cfg.train.optimizer.beta2), weight_decay=0)
+                           betas=(cfg.train.optimizer.beta1, cfg.train.optimizer.beta2), weight_decay=0,
+                           capturable=use_graph)
     batch = G.synthetic_batch(n_graphs, first_id=rank * n_graphs, **kw).to(dev)   # this rank's shard, resident in HBM
-    target = batch["ligand_data"]["smiIndices_tgt"].reshape(-1)
-    crit = torch.nn.CrossEntropyLoss()
-    params = [p for p in model.parameters()]
-
-    def step():
-        EF_layers._edge_cache.clear()                     # a fresh batch arrives every step: re-sort its edges
-        opt.zero_grad(set_to_none=True)
-        logits = model(batch)
-        loss = crit(logits, target)
-        loss.backward()
-        reducer.reduce()
-        torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], float("inf"))
-        opt.step()
-        return loss
+    from singa_amd.engine import TrainStep
+    engine = TrainStep(model, opt, reducer if world > 1 else None, use_graph=use_graph,
+                       max_grad_norm=float(cfg.train.max_grad_norm))
 
     def log(msg):
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    log(f"workload {args.workload}: {n_graphs} graphs/GPU, L={L}; model + batch ready")
+    log(f"workload {args.workload}: {n_graphs} graphs/GPU, L={L}; model + batch ready; "
+        f"{'HIP-graph replay' if use_graph else 'eager'} step")
     for i in range(args.warmup):
         t_w = time.perf_counter()
-        loss = step()
+        loss = engine.step(batch)
         torch.cuda.synchronize()
         log(f"warmup step {i}: {time.perf_counter() - t_w:.3f} s")
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides, MAX over ranks
-    ops.profile_start()
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides, MAX over ranks.  Every step handles the
+    # batch as newly arrived: its graph structure (edge sorting, kNN graphs, dense maps) is rebuilt inside the step.
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = engine.step(batch)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    final_loss = float(loss.detach())
+    log(f"timed {args.steps} steps in {elapsed:.3f} s ({engine.captures} graph capture(s) so far)")
+
+    # ---- instrumented pass for the roofline: the same step run eagerly with start/stop events attached to every
+    # scatter-TP forward dispatch (graph replays cannot carry per-dispatch events); not part of `value`.
+    ops.profile_start()
+    for _ in range(args.roofline_steps):
+        engine.eager_step(batch)
+    torch.cuda.synchronize()
     recs = ops.profile_collect()
     if os.environ.get("SINGA_CALIB") == "1" and rank == 0:
         # known-byte launches for calibrating FETCH_SIZE / WRITE_SIZE under `rocprofv3 --pmc`
@@ -212,14 +219,7 @@ def main():
             _lib.lib().singa_calib_copy(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n,
                                         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         torch.cuda.synchronize()
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
-    final_loss = float(loss.detach())
-    log(f"timed {args.steps} steps in {elapsed:.3f} s")
 
-    # ---- roofline of the dominant launch of the scatter-TP kernel (k10 forward on the protein-protein edges)
     roof = None
     if recs:
         big = max(r[1] for r in recs)                     # dispatches with the most edges = the protein-protein passes
@@ -231,7 +231,8 @@ def main():
         roof = {"bound": "hbm", "kernel": "rotate_back_scatter_kernel (k10 fwd, protein-protein edges)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": None, "bytes_per_launch": by, "avg_launch_us": round(ms * 1e3, 2), "launches": len(sel),
-                "edges": E, "dst_nodes": N, "timing": "start/stop events attached to each dispatch, timed region"}
+                "edges": E, "dst_nodes": N, "timing": f"start/stop events attached to each dispatch, {args.roofline_steps} instrumented eager steps "
+                          "right after the timed region (same process, same batch)"}
 
     if rank == 0:
         total_graphs = n_graphs * world * args.steps
@@ -242,7 +243,8 @@ def main():
                "config": {"workload": args.workload, "graphs_per_gpu": n_graphs, "lmax": L, "mmax": 2,
                           "nodes_per_graph": kw["n_protein"] + kw["n_ligand"],
                           "edges_per_graph": kw["e_pp"] + kw["e_ll"] + 2 * kw["e_x"],
-                          "parallelism": f"dp{world}", "step": "zero_grad+fwd+CE+bwd+allreduce+clip+Adam",
+                          "parallelism": f"dp{world}", "step": "prepare+zero_grad+fwd+CE+bwd+allreduce+clip+Adam",
+                          "launch": "hipGraph replay" if use_graph else "eager",
                           "grad_allreduce_bytes": reducer.payload_bytes},
                "final_loss": round(final_loss, 5), "roofline": roof}
         if not args.no_cpu_baseline and world == 1:

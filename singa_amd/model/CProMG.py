@@ -42,22 +42,43 @@ class GaussianSmearing(nn.Module):
 
 
 # ----------------------------------------------------------------------------------------------- graph helpers (GPU)
+class DenseMap:
+    """to_dense_batch bookkeeping for one node type of one batch: flat positions of the nodes inside the
+    padded [B, max_nodes] layout and the validity mask.  Built once per batch (one host sync for max_nodes) and reused
+    by every layer, so the forward itself stays free of host synchronisation."""
+
+    def __init__(self, batch, batch_size, mx=None):
+        num = torch.zeros(batch_size, dtype=torch.int64, device=batch.device).index_add_(0, batch, torch.ones_like(batch))
+        self.B = batch_size
+        self.mx = int(num.max()) if mx is None else int(mx)
+        start = num.cumsum(0) - num
+        self.idx = torch.arange(batch.numel(), device=batch.device) - start[batch] + batch * self.mx
+        self.mask = torch.zeros(batch_size * self.mx, dtype=torch.bool, device=batch.device)
+        self.mask[self.idx] = True
+        self.mask = self.mask.view(batch_size, self.mx)
+        self.pad_mask = ~self.mask.unsqueeze(1)
+
+    def tensors(self):
+        return [self.idx, self.mask, self.pad_mask]
+
+    def dense(self, x):
+        out = x.new_zeros((self.B * self.mx,) + tuple(x.shape[1:]))
+        out = out.index_copy(0, self.idx, x)
+        return out.view(self.B, self.mx, *x.shape[1:])
+
+
 def to_dense_batch(x, batch, batch_size):
-    num = torch.bincount(batch, minlength=batch_size)
-    mx = int(num.max())
-    start = num.cumsum(0) - num
-    idx = torch.arange(batch.numel(), device=x.device) - start[batch] + batch * mx
-    out = x.new_zeros((batch_size * mx,) + tuple(x.shape[1:]))
-    out[idx] = x
-    mask = torch.zeros(batch_size * mx, dtype=torch.bool, device=x.device)
-    mask[idx] = True
-    return out.view(batch_size, mx, *x.shape[1:]), mask.view(batch_size, mx), idx
+    dm = DenseMap(batch, batch_size)
+    return dm.dense(x), dm.mask, dm.idx
 
 
-def knn_graph(pos, k, batch, batch_size):
+def knn_graph(pos, k, batch, batch_size, dm=None):
     """For every node its k nearest other nodes of the same graph, row = centre (torch_cluster.knn_graph with
-    flow='target_to_source', CP:293,330).  Dense per-graph distance matrices on the GPU."""
-    dense, mask, idx = to_dense_batch(pos, batch, batch_size)
+    flow='target_to_source', CP:293,330).  Dense per-graph distance matrices on the GPU.  Returns a fixed-size
+    [2, B*max_nodes*k] list in which slots that do not exist (padding rows, graphs with fewer than k+1 nodes) hold -1:
+    no data-dependent compaction (and no host synchronisation) happens here."""
+    dm = dm or DenseMap(batch, batch_size)
+    dense, mask, idx = dm.dense(pos), dm.mask, dm.idx
     mx = dense.shape[1]
     d = torch.cdist(dense, dense)
     d = d.masked_fill(~mask.unsqueeze(1), float("inf"))
@@ -70,38 +91,56 @@ def knn_graph(pos, k, batch, batch_size):
     centre = node_of.unsqueeze(2).expand(-1, -1, kk)
     neigh = torch.gather(node_of.unsqueeze(1).expand(-1, mx, -1), 2, nb)
     ok = torch.isfinite(dist) & (centre >= 0)
-    return torch.stack([centre[ok], neigh[ok]], 0)
+    minus = torch.full_like(neigh, -1)
+    return torch.stack([torch.where(ok, centre, minus).reshape(-1), torch.where(ok, neigh, minus).reshape(-1)], 0)
 
 
 class KnnEdges:
-    """CP:295-298 on a raw kNN edge list: edge lengths, to_undirected(reduce='mean'), Gaussian smearing and
-    get_laplacian (self-loops appended; 2-D weights, Q12), then sorted by centre node -> CSR row_ptr."""
+    """CP:295-298 on a raw kNN edge list (entries < 0 = absent): edge lengths, to_undirected(reduce='mean'), Gaussian
+    smearing and get_laplacian (self-loops appended; 2-D weights, Q12), then sorted by centre node -> CSR row_ptr.
+    Coalescing is a radix sort + adjacent-difference + prefix sum (two scalar read-backs for the counts)."""
 
     def __init__(self, pos, knn_ei, smear):
         N = pos.shape[0]
-        ln = (pos[knn_ei[0]] - pos[knn_ei[1]]).norm(dim=1)
-        r = torch.cat([knn_ei[0], knn_ei[1]])
-        c = torch.cat([knn_ei[1], knn_ei[0]])
-        key, inv, cnt = torch.unique(r * N + c, sorted=True, return_inverse=True, return_counts=True)
-        ln = torch.zeros(key.numel(), device=pos.device).index_add_(0, inv, torch.cat([ln, ln])) / cnt
-        row, col = key // N, key % N
+        dev = pos.device
+        valid = (knn_ei[0] >= 0) & (knn_ei[1] >= 0)
+        a, b = knn_ei[0].clamp(min=0), knn_ei[1].clamp(min=0)
+        ln = (pos[a] - pos[b]).norm(dim=1)
+        sentinel = N * N
+        fwd = torch.where(valid, a * N + b, torch.full_like(a, sentinel))
+        bwd = torch.where(valid, b * N + a, torch.full_like(a, sentinel))
+        skey, perm = torch.sort(torch.cat([fwd, bwd]))
+        new = torch.ones_like(skey, dtype=torch.bool)
+        new[1:] = skey[1:] != skey[:-1]
+        gid = torch.cumsum(new, 0) - 1
+        n_groups = int(gid[-1]) + 1
+        n_edges = n_groups - (1 if int(skey[-1]) == sentinel else 0)
+        ukey = torch.zeros(n_groups, dtype=torch.int64, device=dev).scatter_(0, gid, skey)[:n_edges]
+        ln2 = torch.cat([ln, ln])[perm]
+        cnt = torch.zeros(n_groups, device=dev).index_add_(0, gid, torch.ones_like(ln2))[:n_edges]
+        ln = torch.zeros(n_groups, device=dev).index_add_(0, gid, ln2)[:n_edges] / cnt
+        row, col = ukey // N, ukey % N
         ea = smear(ln)
-        deg = torch.zeros(N, ea.shape[1], device=pos.device).index_add_(0, row, ea)
-        loop = torch.arange(N, device=pos.device)
+        deg = torch.zeros(N, ea.shape[1], device=dev).index_add_(0, row, ea)
+        loop = torch.arange(N, device=dev)
         row, col = torch.cat([row, loop]), torch.cat([col, loop])
         attr = torch.cat([-ea, deg], 0)
         order = torch.argsort(row, stable=True)
         self.row, self.col, self.attr = row[order], col[order], attr[order].contiguous()
-        rp = torch.zeros(N + 1, dtype=torch.int64, device=pos.device)
-        rp[1:] = torch.bincount(self.row, minlength=N).cumsum(0)
+        ones = torch.ones_like(self.row)
+        rp = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+        rp[1:] = torch.zeros(N, dtype=torch.int64, device=dev).index_add_(0, self.row, ones).cumsum(0)
         self.row_ptr = rp.to(torch.int32)
         self.row32, self.col32 = self.row.to(torch.int32), self.col.to(torch.int32)
         # edges grouped by neighbour (col): needed by the gradients of the gathered key / value rows
         self.eperm = torch.argsort(self.col, stable=True).to(torch.int32)
-        cp = torch.zeros(N + 1, dtype=torch.int64, device=pos.device)
-        cp[1:] = torch.bincount(self.col, minlength=N).cumsum(0)
+        cp = torch.zeros(N + 1, dtype=torch.int64, device=dev)
+        cp[1:] = torch.zeros(N, dtype=torch.int64, device=dev).index_add_(0, self.col, ones).cumsum(0)
         self.col_ptr = cp.to(torch.int32)
         self.N = N
+
+    def tensors(self):
+        return [self.row, self.col, self.attr, self.row_ptr, self.row32, self.col32, self.eperm, self.col_ptr]
 
 
 # ----------------------------------------------------------------------------------------------- attention modules
@@ -265,13 +304,12 @@ class EncoderLayer2(nn.Module):
         self.layer_norm = LayerNorm(config.hidden_channels, device=device)
         self.pos_ffn = PoswiseFeedForwardNet(config.hidden_channels, device=device)
 
-    def forward(self, node_attr, edges, idx, atom_msa_outputs, atom_mask, batch, batch_size):
+    def forward(self, node_attr, edges, idx, atom_msa_outputs, atom_mask, dm):
         msa_outputs = self.enc_self_attn(node_attr, edges)
         if idx == 2 or idx == 5:                                                   # CP:262
             kv = self.proj(atom_msa_outputs[idx])
-            dense, _, flat_idx = to_dense_batch(msa_outputs, batch, batch_size)
-            cross = self.cross_attn(dense, kv, kv, atom_mask)
-            msa_outputs = self.layer_norm(msa_outputs + cross.reshape(-1, cross.size(-1))[flat_idx])
+            cross = self.cross_attn(dm.dense(msa_outputs), kv, kv, atom_mask)
+            msa_outputs = self.layer_norm(msa_outputs + cross.reshape(-1, cross.size(-1)).index_select(0, dm.idx))
         return self.pos_ffn(msa_outputs)
 
 
@@ -286,18 +324,23 @@ class Encoder(nn.Module):
         self.out = Linear(config.hidden_channels, config.hidden_channels, device=device)       # unused (Q10)
         self.layer_norm = LayerNorm(config.hidden_channels, device=device)                      # unused (Q10)
 
-    def forward(self, protein_atom_feature, pos, batch, atom_laplacian, batch_size=None, knn=None):
-        B = int(batch.max()) + 1 if batch_size is None else batch_size
-        node_attr = self.protein_atom_emb(protein_atom_feature) + self.laplacian_emb(atom_laplacian)
+    def prepare(self, pos, batch, batch_size, knn=None):
+        """Per-batch graph structure (no parameters involved): dense-batch map, kNN edges (CP:293-298)."""
+        dm = DenseMap(batch, batch_size)
         if knn is None:
-            knn = knn_graph(pos, self.config.knn, batch, B)
-        edges = KnnEdges(pos, knn, self.distance_expansion)
+            knn = knn_graph(pos, self.config.knn, batch, batch_size, dm)
+        return {"dense": dm, "edges": KnnEdges(pos, knn, self.distance_expansion)}
+
+    def forward(self, protein_atom_feature, pos, batch, atom_laplacian, batch_size=None, knn=None, prep=None):
+        if prep is None:
+            prep = self.prepare(pos, batch, int(batch.max()) + 1 if batch_size is None else batch_size, knn)
+        dm, edges = prep["dense"], prep["edges"]
+        node_attr = self.protein_atom_emb(protein_atom_feature) + self.laplacian_emb(atom_laplacian)
         msa_outputs1 = []
         for layer in self.layers:
             msa_outputs, node_attr = layer(node_attr, edges)
-            msa_outputs1.append(to_dense_batch(msa_outputs, batch, B)[0])
-        enc_outputs1, mask, _ = to_dense_batch(node_attr, batch, B)
-        return enc_outputs1, ~mask.unsqueeze(1), msa_outputs1
+            msa_outputs1.append(dm.dense(msa_outputs))
+        return dm.dense(node_attr), dm.pad_mask, msa_outputs1
 
 
 class Encoder2(nn.Module):
@@ -311,16 +354,21 @@ class Encoder2(nn.Module):
         self.out = Linear(config.hidden_channels, config.hidden_channels, device=device)       # unused (Q10)
         self.layer_norm = LayerNorm(config.hidden_channels, device=device)                      # unused (Q10)
 
-    def forward(self, aa_feature, aa_pos, aa_batch, aa_laplacian, atom_mask, atom_msa_outputs, batch_size=None, knn=None):
-        B = int(aa_batch.max()) + 1 if batch_size is None else batch_size
-        node_attr = self.aa_emb(aa_feature) + self.laplacian_emb(aa_laplacian)
+    def prepare(self, aa_pos, aa_batch, batch_size, knn=None):
+        dm = DenseMap(aa_batch, batch_size)
         if knn is None:
-            knn = knn_graph(aa_pos, 30, aa_batch, B)                               # CP:330
-        edges = KnnEdges(aa_pos, knn, self.distance_expansion)
+            knn = knn_graph(aa_pos, 30, aa_batch, batch_size, dm)                  # CP:330
+        return {"dense": dm, "edges": KnnEdges(aa_pos, knn, self.distance_expansion)}
+
+    def forward(self, aa_feature, aa_pos, aa_batch, aa_laplacian, atom_mask, atom_msa_outputs, batch_size=None, knn=None,
+                prep=None):
+        if prep is None:
+            prep = self.prepare(aa_pos, aa_batch, int(aa_batch.max()) + 1 if batch_size is None else batch_size, knn)
+        dm, edges = prep["dense"], prep["edges"]
+        node_attr = self.aa_emb(aa_feature) + self.laplacian_emb(aa_laplacian)
         for idx, layer in enumerate(self.layers):
-            node_attr = layer(node_attr, edges, idx, atom_msa_outputs, atom_mask, aa_batch, B)
-        enc_outputs1, mask, _ = to_dense_batch(node_attr, aa_batch, B)
-        return enc_outputs1, ~mask.unsqueeze(1)
+            node_attr = layer(node_attr, edges, idx, atom_msa_outputs, atom_mask, dm)
+        return dm.dense(node_attr), dm.pad_mask
 
 
 class DecoderLayer(nn.Module):
@@ -351,7 +399,8 @@ class Decoder(nn.Module):
     def forward(self, smiles_index, enc_outputs, enc_pad_mask, tgt_len, prop=None):
         b, t = smiles_index.size()
         dev = smiles_index.device
-        dec_inputs = self.mol_emb(smiles_index)
+        # nn.Embedding(.., padding_idx=0) of the reference (CP:377, Q9): plain lookup, row 0 gets no gradient
+        dec_inputs = ops.embedding(self.mol_emb.weight, smiles_index, self.mol_emb.padding_idx)
         dec_inputs = self.pos_emb(dec_inputs.transpose(0, 1)).transpose(0, 1)
         ids = smiles_index
         num = 0
@@ -382,11 +431,13 @@ class Transformer(nn.Module):
         self.projection = nn.Linear(config.hidden_channels, len(config.decoder.smiVoc), bias=False, device=device)
 
     def forward(self, node_attr, pos, batch, atom_laplacian, smiles_index, tgt_len, aa_node_attr, aa_pos, aa_batch,
-                aa_laplacian, prop=None, knn=None, aa_knn=None):
+                aa_laplacian, prop=None, knn=None, aa_knn=None, prep=None):
         B = smiles_index.shape[0]
-        enc_outputs1, enc_pad_mask1, msa_outputs = self.encoder(node_attr, pos, batch, atom_laplacian, B, knn)
+        prep = prep or {}
+        enc_outputs1, enc_pad_mask1, msa_outputs = self.encoder(node_attr, pos, batch, atom_laplacian, B, knn,
+                                                                prep.get("p"))
         enc_outputs2, enc_pad_mask2 = self.encoder2(aa_node_attr, aa_pos, aa_batch, aa_laplacian, enc_pad_mask1,
-                                                    msa_outputs, B, aa_knn)
+                                                    msa_outputs, B, aa_knn, prep.get("l"))
         enc_outputs = torch.cat([enc_outputs1, enc_outputs2], dim=1)
         enc_pad_mask = torch.cat([enc_pad_mask1, enc_pad_mask2], dim=2)
         dec_outputs = self.decoder(smiles_index, enc_outputs, enc_pad_mask, tgt_len, prop)

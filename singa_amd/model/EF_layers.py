@@ -56,11 +56,15 @@ class SO3_Embedding:
 
 
 _edge_cache: Dict[tuple, ops.EdgeSet] = {}
+_edge_pinned: Dict[int, ops.EdgeSet] = {}     # static batches (HIP-graph replay): edge_index storage -> its EdgeSet
 
 
 def edge_set(edge_index: Tensor, n_src: int, n_dst: int) -> ops.EdgeSet:
     """Destination-sorted view of an edge list, cached per (storage, shape, sizes): the four edge types of a batch are
     sorted once and reused by all layers, by backward, and by the edge-degree embedding."""
+    pinned = _edge_pinned.get(edge_index.data_ptr())
+    if pinned is not None:
+        return pinned
     key = (edge_index.data_ptr(), tuple(edge_index.shape), int(n_src), int(n_dst), edge_index._version)
     es = _edge_cache.get(key)
     if es is None:

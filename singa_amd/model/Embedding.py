@@ -11,6 +11,7 @@ from typing import Dict, Optional
 import torch
 import torch.nn as nn
 
+from .. import ops
 from ..graph import E_LL, E_LP, E_PL, E_PP, LA, PA
 from .EF_layers import (CoefficientMappingModule, EdgeDegreeEmbedding, GaussianSmearing, ModuleListInfo, SO3_Embedding,
                         SO3_Grid, SO3_Rotation, TransBlockV2, get_normalization_layer, init_edge_rot_mat)
@@ -95,8 +96,8 @@ class EquivariantEmbedding(nn.Module):
         return init_edge_rot_mat(vec, rand=rand)
 
     def _edge_scalars(self, dist, z_src, z_dst, ei):
-        return torch.cat((self.distance_expansion(dist), self.source_embedding(z_src[ei[0]]),
-                          self.target_embedding(z_dst[ei[1]])), dim=1)
+        return torch.cat((self.distance_expansion(dist), ops.embedding(self.source_embedding.weight, z_src[ei[0]]),
+                          ops.embedding(self.target_embedding.weight, z_dst[ei[1]])), dim=1)
 
     def _homo_pass(self, g, node_type, edge_type, key):
         z = g["atomicnum"][node_type]
@@ -106,7 +107,9 @@ class EquivariantEmbedding(nn.Module):
         self.SO3_rotation[0].set_wigner(self._frames(g, key, ev))
         K = (self.lmax_list[0] + 1) ** 2
         # Q1: the reference stores the l=0 initialisation in a LONG tensor: truncation toward zero, no gradient
-        init = (self.sphere_embedding(z) + self.sphere_embedding_2(barcode(x_feat))).detach().to(torch.long)
+        with torch.no_grad():
+            init = (self.sphere_embedding.weight.index_select(0, z)
+                    + self.sphere_embedding_2.weight.index_select(0, barcode(x_feat))).to(torch.long)
         emb = torch.zeros(z.shape[0], K, self.sphere_channels, device=pos.device, dtype=torch.float32)
         emb[:, self.offset_res, :] = init.to(torch.float32)
         edge_distance = self._edge_scalars(ev.norm(dim=-1), z, z, ei)

@@ -40,9 +40,34 @@ class SINGA(nn.Module):
         embed = self.embedding(g)
         feat = self.config.model.featurizer_feat_dim
         knn = getattr(g, "extras", {}).get("knn", {})
+        prep = getattr(g, "extras", {}).get("prepared")
         return self.model(
             node_attr=embed[PA].embedding.reshape(-1, feat), pos=g[PA]["pos"], batch=batch,
             atom_laplacian=lap_pe(g, PA), smiles_index=ld["smiIndices_input"],
             tgt_len=self.config.model.decoder.tgt_len, aa_node_attr=embed[LA].embedding.reshape(-1, feat),
             aa_pos=g[LA]["pos"], aa_batch=batch_aa, aa_laplacian=lap_pe(g, LA), prop=prop,
-            knn=knn.get(PA), aa_knn=knn.get(LA))
+            knn=knn.get(PA), aa_knn=knn.get(LA), prep=prep)
+
+    def prepare(self, g):
+        """Per-batch graph structure that does not depend on parameters: destination-sorted edge sets of the four edge
+        types, kNN graphs of both encoders, dense-batch maps.  Everything with a host synchronisation lives here, so that
+        forward/backward on a prepared batch only enqueue work (and can be captured in a HIP graph)."""
+        from .EF_layers import edge_set
+        from ..graph import E_LL, E_LP, E_PL, E_PP
+        n_p, n_l = g[PA]["x"].shape[0], g[LA]["x"].shape[0]
+        B = g.num_graphs
+        knn = getattr(g, "extras", {}).get("knn", {})
+        import os
+        dbg = os.environ.get("SINGA_DEBUG_SYNC") == "1"
+        prep = {}
+        prep["p"] = self.model.encoder.prepare(g[PA]["pos"], g[PA]["batch"], B, knn.get(PA))
+        if dbg:
+            torch.cuda.synchronize(); print("[prepare] p done", flush=True)
+        prep["l"] = self.model.encoder2.prepare(g[LA]["pos"], g[LA]["batch"], B, knn.get(LA))
+        if dbg:
+            torch.cuda.synchronize(); print("[prepare] l done", flush=True)
+        prep.update({
+                "es": {"pp": edge_set(g[E_PP]["edge_index"], n_p, n_p), "ll": edge_set(g[E_LL]["edge_index"], n_l, n_l),
+                       "lp": edge_set(g[E_LP]["edge_index"], n_l, n_p), "pl": edge_set(g[E_PL]["edge_index"], n_p, n_l)}})
+        g.extras["prepared"] = prep
+        return prep

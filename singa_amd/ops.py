@@ -71,13 +71,17 @@ class EdgeSet:
         self.order = order
         self.src64, self.dst64 = ei[0][order].contiguous(), ei[1][order].contiguous()
         self.src, self.dst = self.src64.to(torch.int32), self.dst64.to(torch.int32)
+        ones = torch.ones_like(self.dst64)
         self.row_ptr = torch.zeros(self.n_dst + 1, dtype=torch.int64, device=dev)
-        self.row_ptr[1:] = torch.bincount(self.dst64, minlength=self.n_dst).cumsum(0)
+        self.row_ptr[1:] = torch.zeros(self.n_dst, dtype=torch.int64, device=dev).index_add_(0, self.dst64, ones).cumsum(0)
         self.row_ptr = self.row_ptr.to(torch.int32)
         self.eperm = torch.argsort(self.src64, stable=True).to(torch.int32)
         self.col_ptr = torch.zeros(self.n_src + 1, dtype=torch.int64, device=dev)
-        self.col_ptr[1:] = torch.bincount(self.src64, minlength=self.n_src).cumsum(0)
+        self.col_ptr[1:] = torch.zeros(self.n_src, dtype=torch.int64, device=dev).index_add_(0, self.src64, ones).cumsum(0)
         self.col_ptr = self.col_ptr.to(torch.int32)
+
+    def tensors(self):
+        return [self.order, self.src64, self.dst64, self.src, self.dst, self.row_ptr, self.eperm, self.col_ptr]
 
 
 def wigner_rows(rot, L, M=2):
@@ -362,6 +366,17 @@ def s2act_node(x, gate, L):
     return _S2ActNode.apply(x, gate, L)
 
 
+_deg_cache = {}
+
+
+def _degree_index(L, device):
+    """degree l of every coefficient row, as a device tensor (cached: no host->device copy inside a graph capture)."""
+    key = (L, str(device))
+    if key not in _deg_cache:
+        _deg_cache[key] = torch.as_tensor(so3.layout(L, L).degree, device=device, dtype=torch.int64)
+    return _deg_cache[key]
+
+
 class _SO3RMSNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, L, eps):
@@ -387,7 +402,7 @@ class _SO3RMSNorm(torch.autograd.Function):
         gbp = torch.empty(nparts, C, device=x.device, dtype=torch.float32)
         _chk(_lib.lib().singa_so3_rmsnorm_bwd(_p(x), _p(weight), _p(gy), _p(gx), _p(gwp), _p(gbp), N, C, L, eps,
                                               _stream()), "singa_so3_rmsnorm_bwd")
-        deg = torch.as_tensor(so3.layout(L, L).degree, device=x.device, dtype=torch.int64)
+        deg = _degree_index(L, x.device)
         gw = torch.zeros(L + 1, C, device=x.device, dtype=torch.float32).index_add_(0, deg, gwp.sum(0))
         return gx, gw, gbp.sum(0), None, None
 
@@ -492,3 +507,29 @@ def skinny_linear(x, w, b):
     """F.linear for [M,K] inputs with M in the 10^5..10^6 range and K, N <= 64 (per-edge MLPs): same forward,
     weight gradient by batched split-K."""
     return _SkinnyLinear.apply(x, w, b)
+
+
+class _SmallVocabEmbedding(torch.autograd.Function):
+    """weight[idx] for small tables (atomic numbers, SMILES tokens).  The backward of nn.Embedding on this ROCm build goes
+    through thrust::unique_by_key with its own hipMalloc'ed scratch and a host read-back of the segment count - neither
+    survives HIP-graph replay (dangling scratch pointers -> memory-aperture faults).  Here the weight gradient is a
+    one-hot GEMM: deterministic, allocation-free apart from PyTorch's own pool, capturable."""
+
+    @staticmethod
+    def forward(ctx, weight, idx, padding_idx):
+        ctx.save_for_backward(idx)
+        ctx.V, ctx.padding_idx = weight.shape[0], padding_idx
+        return weight.index_select(0, idx.reshape(-1)).view(*idx.shape, weight.shape[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        onehot = torch.nn.functional.one_hot(idx.reshape(-1), ctx.V).to(g.dtype)
+        gw = onehot.t() @ g.reshape(-1, g.shape[-1])
+        if ctx.padding_idx is not None:                     # nn.Embedding(padding_idx=i): row i receives no gradient
+            gw[ctx.padding_idx] = 0
+        return gw, None, None
+
+
+def embedding(weight, idx, padding_idx=None):
+    return _SmallVocabEmbedding.apply(weight, idx, padding_idx)

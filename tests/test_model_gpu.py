@@ -118,10 +118,15 @@ def test_own_knn_graph_matches_oracle_edges():
     knn = CP.knn_graph(pos, 48, batch, 3)
     smear = CP.GaussianSmearing(stop=15, num_gaussians=64, device=DEV)
     e = CP.KnnEdges(pos, knn, smear)
-    row, col, ea = O.knn_edges(pos.cpu(), knn.cpu(), 15.0, 64)
+    knn = knn.cpu()
+    knn = knn[:, knn[0] >= 0]                      # absent slots (padding rows) are marked -1
+    row, col, ea = O.knn_edges(pos.cpu(), knn, 15.0, 64)
     N = pos.shape[0]
     a = torch.sort(e.row.cpu() * N + e.col.cpu()).values
     b = torch.sort(row * N + col).values
     assert torch.equal(a, b)
     # every node has exactly 48 out-neighbours before symmetrisation
-    assert int(torch.bincount(knn[0].cpu(), minlength=N).min()) == 48
+    assert int(torch.bincount(knn[0], minlength=N).min()) == 48
+    # and the attributes agree edge by edge
+    ia, ib = torch.sort(e.row.cpu() * N + e.col.cpu()).indices, torch.sort(row * N + col).indices
+    assert float((e.attr.cpu()[ia] - ea[ib]).abs().max()) < 1e-5
