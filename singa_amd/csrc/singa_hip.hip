@@ -672,6 +672,36 @@ __global__ void __launch_bounds__(64) gather_wsum_bwd_col_kernel(const float* __
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ column sums
+// out[j] = sum_i x[i*ld + j]: bias / broadcast gradients.  Two deterministic passes (row slabs -> partials -> total);
+// no atomics and no global semaphores, so the result is the same under eager launch and HIP-graph replay.
+__global__ void colsum_partial_kernel(const float* __restrict__ x, long long ld, long long M, int n, int rows_per_block,
+                                      float* __restrict__ part) {
+    const long long r0 = (long long)blockIdx.y * rows_per_block;
+    const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        long long i = r0;
+        for (; i + 3 < r1; i += 4) {
+            a0 += x[i * ld + j];
+            a1 += x[(i + 1) * ld + j];
+            a2 += x[(i + 2) * ld + j];
+            a3 += x[(i + 3) * ld + j];
+        }
+        for (; i < r1; ++i) a0 += x[i * ld + j];
+        part[(long long)blockIdx.y * n + j] = (a0 + a1) + (a2 + a3);
+    }
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    float a = 0.f;
+    for (int p = 0; p < nparts; ++p) a += part[(long long)p * n + j];
+    out[j] = a;
+}
+
 // ------------------------------------------------------------------------------------------------ k8: S2 activation
 // thread = (edge-or-node e, channel c).  x rows in registers; loop over the G grid points with the two grid-matrix
 // rows as wave-uniform scalars: u = to[g,:].x, s = SiLU(u), y += from[g,:] * s.  Row 0 of the result is SiLU(gate).
@@ -1235,6 +1265,22 @@ int singa_gather_wsum_bwd(const float* g, const float* alpha, const float* wv, c
     hipLaunchKernelGGL((gather_wsum_bwd_col_kernel<4>), dim3(grid_for(N, 1 << 20)), dim3(64), 0, (hipStream_t)stream, g,
                        alpha, wv, col_ptr, eperm, row, g_hv, N);
     return check_launch("gather_wsum_bwd");
+}
+
+int singa_colsum_nparts(long long M) {
+    long long p = (M + 255) / 256;
+    return (int)(p > 1024 ? 1024 : (p < 1 ? 1 : p));
+}
+
+int singa_colsum(const float* x, long long ld, long long M, int n, float* part, float* out, void* stream) {
+    if (!x || !part || !out) return fail(SINGA_E_NULL, "colsum: null pointer");
+    if (n <= 0) return SINGA_OK;
+    int nparts = singa_colsum_nparts(M);
+    int rows = (int)((M + nparts - 1) / nparts);
+    int bx = (n + 255) / 256;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(bx, nparts), dim3(256), 0, (hipStream_t)stream, x, ld, M, n, rows, part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(bx), dim3(256), 0, (hipStream_t)stream, part, nparts, n, out);
+    return check_launch("colsum");
 }
 
 int singa_so3_rmsnorm_nparts(int N) { return grid_for(N, 2048); }

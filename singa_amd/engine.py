@@ -66,8 +66,15 @@ class TrainStep:
         return loss
 
     def _update(self):
-        params = [p for p in self.model.parameters() if p.grad is not None]
-        torch.nn.utils.clip_grad_norm_(params, self.max_grad_norm)
+        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+        # clip_grad_norm_(parameters, max_norm) of train.py:126.  The reference passes max_norm = inf, i.e. it only
+        # wants the total norm for logging; torch's implementation still multiplies every gradient by
+        # clamp(inf / (norm + 1e-6), max=1), which turned into NaN under HIP-graph replay on this build, so the
+        # (mathematically void) scaling is skipped when max_norm is infinite and done with a finite coefficient otherwise.
+        self.grad_norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
+        if self.max_grad_norm != float("inf"):
+            coef = (self.max_grad_norm / (self.grad_norm + 1e-6)).clamp(max=1.0)
+            torch._foreach_mul_(grads, coef)
         self.opt.step()
 
     def eager_step(self, batch):

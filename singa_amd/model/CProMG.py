@@ -15,9 +15,10 @@ import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
-from torch.nn import BatchNorm1d, Conv1d, Dropout, Embedding, LayerNorm, Linear, Sequential
+from torch.nn import BatchNorm1d, Conv1d, Dropout, Embedding, LayerNorm, Sequential
 
 from .. import ops
+from ..nn import Linear
 
 
 class ShiftedSoftplus(nn.Module):
@@ -171,8 +172,7 @@ class MultiHeadAttention(nn.Module):
         return torch.bmm(h.view(N, heads, ig).transpose(0, 1), w.view(heads, og, ig).transpose(1, 2)).transpose(0, 1)
 
     def _edge_mlp(self, net, x):
-        h = self.act(ops.skinny_linear(x, net[0].weight, net[0].bias))
-        return ops.skinny_linear(h, net[2].weight, net[2].bias)
+        return net[2](self.act(net[0](x)))
 
     def forward(self, node_attr, edges: KnnEdges):
         """CP:50-78.  weight_k_lin and weight_v_lin act on the last axis only, so they commute with the per-edge
@@ -185,11 +185,11 @@ class MultiHeadAttention(nn.Module):
         W_k = self._edge_mlp(self.weight_k_net, edges.attr)                      # [E, 32]
         W_v = self._edge_mlp(self.weight_v_net, edges.attr)                      # [E, 64]
         qp = torch.matmul(h_queries, self.weight_k_lin.weight)                   # (q W)[n,h,:]
-        cterm = (h_queries * self.weight_k_lin.bias).sum(-1) * scale
+        cterm = torch.matmul(h_queries, self.weight_k_lin.bias) * scale
         qk_ij = ops.edge_logits(qp, W_k, h_keys, cterm, edges, scale)
         alpha = ops.segment_softmax(qk_ij, edges.row_ptr, 0.0)
         S = ops.gather_wsum(alpha, W_v, h_values, edges)                         # [N, heads, 64]
-        aggr_msg = F.linear(S, self.weight_v_lin.weight, self.weight_v_lin.bias).view(N, -1)
+        aggr_msg = ops.linear(S, self.weight_v_lin.weight, self.weight_v_lin.bias).view(N, -1)
         out = self.centroid_lin(node_attr) + aggr_msg
         return self.layer_norm(self.out_transform(self.act(out)))
 
@@ -249,8 +249,8 @@ class PoswiseFeedForwardNet(nn.Module):
         self.batch_norm = BatchNorm1d(hidden_channels, device=device)
 
     def forward(self, inputs):
-        h = F.relu(F.linear(inputs, self.conv1.weight[:, :, 0], self.conv1.bias))
-        return self.layer_norm(F.linear(h, self.conv2.weight[:, :, 0], self.conv2.bias) + inputs)
+        h = F.relu(ops.linear(inputs, self.conv1.weight[:, :, 0], self.conv1.bias))
+        return self.layer_norm(ops.linear(h, self.conv2.weight[:, :, 0], self.conv2.bias) + inputs)
 
 
 class PoswiseFeedForwardDeNet(nn.Module):
@@ -261,8 +261,8 @@ class PoswiseFeedForwardDeNet(nn.Module):
         self.layer_norm = LayerNorm(hidden_channels, device=device)
 
     def forward(self, inputs):
-        h = F.relu(F.linear(inputs, self.conv1.weight[:, :, 0], self.conv1.bias))
-        return self.layer_norm(F.linear(h, self.conv2.weight[:, :, 0], self.conv2.bias) + inputs)
+        h = F.relu(ops.linear(inputs, self.conv1.weight[:, :, 0], self.conv1.bias))
+        return self.layer_norm(ops.linear(h, self.conv2.weight[:, :, 0], self.conv2.bias) + inputs)
 
 
 class PositionalEncoding(nn.Module):
@@ -406,8 +406,8 @@ class Decoder(nn.Module):
         num = 0
         if self.num_props:
             assert prop.shape[-1] == self.num_props
-            dec_inputs = dec_inputs + self.type_emb.weight[1]
-            p = self.prop_nn(prop.unsqueeze(1)) + self.type_emb.weight[0]
+            dec_inputs = ops.bias_add(dec_inputs, self.type_emb.weight[1])
+            p = ops.bias_add(self.prop_nn(prop.unsqueeze(1)), self.type_emb.weight[0])
             dec_inputs = torch.cat([p, dec_inputs], 1)
             ids = torch.cat([torch.ones(b, 1, dtype=ids.dtype, device=dev), ids], 1)    # property token: id 1, never pad (Q9)
             num = 1
@@ -428,7 +428,7 @@ class Transformer(nn.Module):
         self.encoder = Encoder(config.encoder, protein_atom_feature_dim, device=device)
         self.encoder2 = Encoder2(config.encoder, protein_atom_feature_dim, device=device)
         self.decoder = Decoder(config.decoder, self.num_props, device=device)
-        self.projection = nn.Linear(config.hidden_channels, len(config.decoder.smiVoc), bias=False, device=device)
+        self.projection = Linear(config.hidden_channels, len(config.decoder.smiVoc), bias=False, device=device)
 
     def forward(self, node_attr, pos, batch, atom_laplacian, smiles_index, tgt_len, aa_node_attr, aa_pos, aa_batch,
                 aa_laplacian, prop=None, knn=None, aa_knn=None, prep=None):

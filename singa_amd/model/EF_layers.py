@@ -22,9 +22,9 @@ from typing import Dict, Optional, Tuple, Union
 import torch
 import torch.nn as nn
 from torch import Tensor
-from torch.nn import Linear
 
 from .. import ops, so3
+from ..nn import Linear
 
 
 # ----------------------------------------------------------------------------------------------- containers / helpers
@@ -190,10 +190,9 @@ class SO3_LinearV2(nn.Module):
         if self._deg is None or self._deg.device != x.device:
             self._deg = torch.as_tensor(so3.layout(self.lmax, self.lmax).degree, device=x.device, dtype=torch.int64)
         w = self.weight.index_select(0, self._deg)                               # [K, out, in]
-        out = torch.bmm(x.transpose(0, 1), w.transpose(1, 2)).transpose(0, 1)    # [N, K, out]
-        bias_rows = torch.zeros(out.shape[1], 1, device=x.device, dtype=x.dtype)
-        bias_rows[0] = 1.0
-        return out + bias_rows * self.bias.view(1, 1, -1)
+        out = torch.bmm(x.transpose(0, 1), w.transpose(1, 2)).transpose(0, 1).contiguous()    # [N, K, out]
+        out[:, 0, :] = ops.bias_add(out[:, 0, :], self.bias)                     # bias on l = 0 only (EF:658-659)
+        return out
 
     def forward(self, input_embedding: SO3_Embedding) -> SO3_Embedding:
         out = self.apply_tensor(input_embedding.embedding)
@@ -272,9 +271,9 @@ class SO2_Convolution(nn.Module):
         (y0 [E, extra + (L+1)*Cout], y1 [E, 2*L*Cout], y2 [E, 2*(L-1)*Cout]), each m-primary and contiguous."""
         c = self.sphere_channels
         st = self.layout.seg_start
-        outs = [torch.addmm(self.fc_m0.bias, X[:, : st[1] * c], self.fc_m0.weight.t())]
+        outs = [ops.linear(X[:, : st[1] * c], self.fc_m0.weight, self.fc_m0.bias)]
         for i, conv in enumerate(self.so2_m_conv):
-            outs.append(X[:, st[i + 1] * c: st[i + 2] * c] @ conv.block_weight().t())
+            outs.append(ops.linear(X[:, st[i + 1] * c: st[i + 2] * c], conv.block_weight()))
         return outs
 
 
@@ -364,7 +363,7 @@ class SO2EquivariantGraphAttention(nn.Module):
         y0, y1, y2 = self.so2_conv_2(act)
         # attention weights: LayerNorm -> smooth leaky ReLU -> dot -> softmax over each destination's edges
         a = self.alpha_act(self.alpha_norm(h0[:, : heads * A].reshape(-1, heads, A)))
-        logits = (a * self.alpha_dot.unsqueeze(0)).sum(-1)
+        logits = torch.bmm(a.transpose(0, 1), self.alpha_dot.unsqueeze(-1)).squeeze(-1).t()   # [E, heads]
         alpha = ops.segment_softmax(logits, es.row_ptr, 1e-16)
         # k10: alpha * value, rotate back, sum over incoming edges
         agg = ops.rotate_back_scatter(y0, y1, y2, alpha, wr, es, heads, L, M)

@@ -403,8 +403,8 @@ class _SO3RMSNorm(torch.autograd.Function):
         _chk(_lib.lib().singa_so3_rmsnorm_bwd(_p(x), _p(weight), _p(gy), _p(gx), _p(gwp), _p(gbp), N, C, L, eps,
                                               _stream()), "singa_so3_rmsnorm_bwd")
         deg = _degree_index(L, x.device)
-        gw = torch.zeros(L + 1, C, device=x.device, dtype=torch.float32).index_add_(0, deg, gwp.sum(0))
-        return gx, gw, gbp.sum(0), None, None
+        gw = torch.zeros(L + 1, C, device=x.device, dtype=torch.float32).index_add_(0, deg, colsum(gwp))
+        return gx, gw, colsum(gbp), None, None
 
 
 def so3_rmsnorm(x, weight, bias, L, eps=1e-5):
@@ -475,38 +475,86 @@ def gather_wsum(alpha, wv, hv, edges):
     return _GatherWSum.apply(alpha, wv, hv, edges)
 
 
+def colsum(t):
+    """Column sums of a [M, ...] tensor over dim 0 with the library's two-pass kernel.  torch's own long-column
+    reductions (bias gradients of Linear layers, broadcast gradients, `t.sum(0)`) go through a multi-block kernel with
+    global semaphores that returned garbage (1e12..1e36) for a few outputs per step under HIP-graph replay on this ROCm
+    build; this kernel has no cross-launch state and a fixed summation order."""
+    t2 = t.reshape(t.shape[0], -1)
+    if not t2.is_cuda:                       # host-side unit tests of the autograd wrappers only
+        return t2.sum(0).view(t.shape[1:])
+    if t2.stride(1) != 1:
+        t2 = t2.contiguous()
+    M, n = t2.shape
+    lib = _lib.lib()
+    part = torch.empty(lib.singa_colsum_nparts(M), n, device=t.device, dtype=torch.float32)
+    out = torch.empty(n, device=t.device, dtype=torch.float32)
+    _chk(lib.singa_colsum(_p(t2), t2.stride(0), M, n, _p(part), _p(out), _stream()), "singa_colsum")
+    return out.view(t.shape[1:])
+
+
+class _BiasAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, b):
+        return x + b
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, colsum(g.reshape(-1, g.shape[-1]))
+
+
+def bias_add(x, b):
+    """x[..., n] + b[n] whose bias gradient is a replay-safe column sum."""
+    return _BiasAdd.apply(x, b)
+
+
+import os as _os
+
+_SPLITK_MIN_ROWS = int(_os.environ.get("SINGA_SPLITK_MIN", "131072"))
+
+
 def _splitk_tn(a, b, chunk=8192):
     """a^T @ b for tall-skinny a [M,p], b [M,q] (M >> p,q): batched split-K so that the library GEMM has enough
     workgroups (a single [p,M]x[M,q] GEMM launches p*q/tile workgroups only)."""
     M, p = a.shape
     q = b.shape[1]
     S = M // chunk
-    if S < 2:
+    if M < _SPLITK_MIN_ROWS or S < 2:
         return a.t() @ b
     Mc = S * chunk
-    out = torch.bmm(a[:Mc].view(S, chunk, p).transpose(1, 2), b[:Mc].view(S, chunk, q)).sum(0)
+    out = colsum(torch.bmm(a[:Mc].view(S, chunk, p).transpose(1, 2), b[:Mc].view(S, chunk, q)))
     if Mc < M:
         out = out + a[Mc:].t() @ b[Mc:]
     return out
 
 
-class _SkinnyLinear(torch.autograd.Function):
+class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
-        ctx.save_for_backward(x, w)
-        return torch.addmm(b, x, w.t())
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, w)
+        ctx.xshape, ctx.has_bias = x.shape, b is not None
+        y = torch.addmm(b, x2, w.t()) if b is not None else x2 @ w.t()
+        return y.view(*x.shape[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, g):
-        x, w = ctx.saved_tensors
-        g = g.contiguous()
-        return g @ w, _splitk_tn(g, x), g.sum(0)
+        x2, w = ctx.saved_tensors
+        g2 = g.reshape(-1, g.shape[-1])
+        gx = (g2 @ w).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        gw = _splitk_tn(g2, x2) if ctx.needs_input_grad[1] else None
+        gb = colsum(g2) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return gx, gw, gb
+
+
+def linear(x, w, b=None):
+    """y = x W^T + b with gradients that are all GEMMs: dW by batched split-K when the row count is large (per-edge
+    layers: 10^4..10^6 rows against <= 10^3 columns), db as a ones-row GEMM (see colsum)."""
+    return _Linear.apply(x, w, b)
 
 
 def skinny_linear(x, w, b):
-    """F.linear for [M,K] inputs with M in the 10^5..10^6 range and K, N <= 64 (per-edge MLPs): same forward,
-    weight gradient by batched split-K."""
-    return _SkinnyLinear.apply(x, w, b)
+    return _Linear.apply(x, w, b)
 
 
 class _SmallVocabEmbedding(torch.autograd.Function):

@@ -53,10 +53,12 @@ static inline hipError_t hipEventElapsedTime(float* t, hipEvent_t, hipEvent_t) {
         dim3 _g = (g), _b = (b);                                            \
         gridDim = _g;                                                       \
         blockDim = _b;                                                      \
-        for (unsigned _bx = 0; _bx < _g.x; ++_bx)                           \
-            for (unsigned _tx = 0; _tx < _b.x; ++_tx) {                     \
-                blockIdx.x = _bx;                                           \
-                threadIdx.x = _tx;                                          \
-                kern(__VA_ARGS__);                                          \
-            }                                                               \
+        for (unsigned _by = 0; _by < _g.y; ++_by)                           \
+            for (unsigned _bx = 0; _bx < _g.x; ++_bx)                       \
+                for (unsigned _tx = 0; _tx < _b.x; ++_tx) {                 \
+                    blockIdx.x = _bx;                                       \
+                    blockIdx.y = _by;                                       \
+                    threadIdx.x = _tx;                                      \
+                    kern(__VA_ARGS__);                                      \
+                }                                                           \
     } while (0)

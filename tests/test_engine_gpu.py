@@ -35,3 +35,32 @@ def test_graph_replay_matches_eager():
     for a, b in zip(graph[:3], eager[2:5]):
         assert abs(a - b) < 2e-4 * abs(b), (graph, eager)
     assert eager[4] < eager[0]                              # and the step does train
+
+
+def test_graph_replay_gradients_match_eager_per_parameter():
+    """After a few replayed steps, the gradients one more forward+backward replay leaves in .grad equal the eager
+    gradients at the same parameters - for every parameter (guards against stale / uninitialised buffers in replay)."""
+    from singa_amd.config import load_config
+    from singa_amd.engine import TrainStep
+    from singa_amd.model.GAN import SINGA
+    _, eng = _run(True, steps=2)
+    z = golden("singa_L2_B3.npz")
+    batch = product_batch(NAMES, z)
+    assert eng._load(batch)
+    eng.g_fb.replay()
+    torch.cuda.synchronize()
+    ref = SINGA(load_config(lmax=2), device="cuda")
+    ref.load_state_dict(eng.model.state_dict())
+    ref.eval()
+    ref.prepare(batch)
+    logits = ref(batch)
+    torch.nn.functional.cross_entropy(logits, batch["ligand_data"]["smiIndices_tgt"].reshape(-1)).backward()
+    bad = []
+    for (n, p), (_, q) in zip(eng.model.named_parameters(), ref.named_parameters()):
+        if q.grad is None:
+            assert p.grad is None, n
+            continue
+        err = float((p.grad - q.grad).norm() / (q.grad.norm() + 1e-12))
+        if not (err < 2e-3) and float((p.grad - q.grad).abs().max()) > 1e-9:
+            bad.append((n, err, float(p.grad.abs().max()), float(q.grad.abs().max())))
+    assert not bad, bad[:8]

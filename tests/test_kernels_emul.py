@@ -242,3 +242,13 @@ def test_argument_errors(emul):
         assert emul.singa_dims(L, 2, ctypes.byref(kr), ctypes.byref(wsz), ctypes.byref(rr)) == 0
         lay = so3.layout(L, 2)
         assert (kr.value, wsz.value, rr.value) == (lay.KR, lay.WSZ, lay.rad_rows)
+
+
+def test_colsum(emul):
+    rs = np.random.RandomState(1)
+    for M, n, ld in ((1, 5, 5), (700, 33, 40), (5000, 300, 300)):
+        x = rs.randn(M, ld).astype(np.float32)
+        part = np.zeros((emul.singa_colsum_nparts(M), n), np.float32)
+        out = np.zeros(n, np.float32)
+        assert emul.singa_colsum(ptr(x), ld, M, n, ptr(part), ptr(out), None) == 0
+        assert np.abs(out - x[:, :n].astype(np.float64).sum(0)).max() < 1e-3
