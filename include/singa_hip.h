@@ -139,9 +139,9 @@ int singa_so3_rmsnorm_bwd(const float* x, const float* weight, const float* gy, 
                           float* gb_part, int N, int C, int lmax, float eps, void* stream);
 
 /* Column sums out[n] = sum_i x[i*ld + j] (bias and broadcast gradients; replaces torch's multi-block `sum(0)`, which
- * is not replay-safe on this ROCm build).  part: workspace of singa_colsum_nparts(M) * n floats. */
-int singa_colsum_nparts(long long M);
-int singa_colsum(const float* x, long long ld, long long M, int n, float* part, float* out, void* stream);
+ * is not replay-safe on this ROCm build).  work: singa_colsum_work(M, n) floats. */
+long long singa_colsum_work(long long M, int n);
+int singa_colsum(const float* x, long long ld, long long M, int n, float* work, float* out, void* stream);
 
 /* Measurement helpers (bench.py): exact per-dispatch timing of the scatter-TP forward kernel with start/stop events
  * attached to the dispatch (hipExtLaunchKernelGGL) on the caller's stream, and a copy kernel with the segment kernels'

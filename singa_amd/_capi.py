@@ -38,7 +38,7 @@ _SIGS = {
     "singa_edge_logits_bwd": ([P] * 13 + [I32, I32, I32, F32, P], I32),
     "singa_gather_wsum_fwd": ([P] * 6 + [I32, I32, I32, P], I32),
     "singa_gather_wsum_bwd": ([P] * 12 + [I32, I32, I32, P], I32),
-    "singa_colsum_nparts": ([C.c_longlong], I32),
+    "singa_colsum_work": ([C.c_longlong, I32], C.c_longlong),
     "singa_colsum": ([P, C.c_longlong, C.c_longlong, I32, P, P, P], I32),
     "singa_prof_enable": ([I32], I32),
     "singa_prof_hint_edges": ([I32], I32),

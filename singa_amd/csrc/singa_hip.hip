@@ -674,32 +674,29 @@ __global__ void __launch_bounds__(64) gather_wsum_bwd_col_kernel(const float* __
 
 
 // ------------------------------------------------------------------------------------------------ column sums
-// out[j] = sum_i x[i*ld + j]: bias / broadcast gradients.  Two deterministic passes (row slabs -> partials -> total);
-// no atomics and no global semaphores, so the result is the same under eager launch and HIP-graph replay.
-__global__ void colsum_partial_kernel(const float* __restrict__ x, long long ld, long long M, int n, int rows_per_block,
-                                      float* __restrict__ part) {
-    const long long r0 = (long long)blockIdx.y * rows_per_block;
-    const long long r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
-    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        long long i = r0;
-        for (; i + 3 < r1; i += 4) {
-            a0 += x[i * ld + j];
-            a1 += x[(i + 1) * ld + j];
-            a2 += x[(i + 2) * ld + j];
-            a3 += x[(i + 3) * ld + j];
-        }
-        for (; i < r1; ++i) a0 += x[i * ld + j];
-        part[(long long)blockIdx.y * n + j] = (a0 + a1) + (a2 + a3);
-    }
-}
+// out[j] = sum_i x[i*ld + j]: bias / broadcast gradients.  A fixed-shape reduction tree: every pass lets one thread add up
+// to COLSUM_R rows of one column (consecutive threads = consecutive columns, so loads coalesce), passes repeat until one
+// row is left.  No atomics, no LDS, no global semaphores: identical results under eager launch and HIP-graph replay.
+constexpr int COLSUM_R = 128;
 
-__global__ void colsum_final_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
-    int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    float a = 0.f;
-    for (int p = 0; p < nparts; ++p) a += part[(long long)p * n + j];
-    out[j] = a;
+__global__ void colsum_pass_kernel(const float* __restrict__ x, long long ld, long long M, int n, float* __restrict__ out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long slabs = (M + COLSUM_R - 1) / COLSUM_R;
+    if (t >= slabs * n) return;
+    const long long slab = t / n;
+    const int j = (int)(t - slab * n);
+    const long long r0 = slab * COLSUM_R;
+    const long long r1 = r0 + COLSUM_R < M ? r0 + COLSUM_R : M;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long long i = r0;
+    for (; i + 3 < r1; i += 4) {
+        a0 += x[i * ld + j];
+        a1 += x[(i + 1) * ld + j];
+        a2 += x[(i + 2) * ld + j];
+        a3 += x[(i + 3) * ld + j];
+    }
+    for (; i < r1; ++i) a0 += x[i * ld + j];
+    out[slab * n + j] = (a0 + a1) + (a2 + a3);
 }
 
 // ------------------------------------------------------------------------------------------------ k8: S2 activation
@@ -1267,19 +1264,32 @@ int singa_gather_wsum_bwd(const float* g, const float* alpha, const float* wv, c
     return check_launch("gather_wsum_bwd");
 }
 
-int singa_colsum_nparts(long long M) {
-    long long p = (M + 255) / 256;
-    return (int)(p > 1024 ? 1024 : (p < 1 ? 1 : p));
+long long singa_colsum_work(long long M, int n) {
+    // floats of workspace: the first-level partials plus the second level (ping-pong)
+    long long s1 = (M + COLSUM_R - 1) / COLSUM_R, s2 = (s1 + COLSUM_R - 1) / COLSUM_R;
+    return (s1 + s2) * (long long)n + 2;
 }
 
-int singa_colsum(const float* x, long long ld, long long M, int n, float* part, float* out, void* stream) {
-    if (!x || !part || !out) return fail(SINGA_E_NULL, "colsum: null pointer");
-    if (n <= 0) return SINGA_OK;
-    int nparts = singa_colsum_nparts(M);
-    int rows = (int)((M + nparts - 1) / nparts);
-    int bx = (n + 255) / 256;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(bx, nparts), dim3(256), 0, (hipStream_t)stream, x, ld, M, n, rows, part);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(bx), dim3(256), 0, (hipStream_t)stream, part, nparts, n, out);
+int singa_colsum(const float* x, long long ld, long long M, int n, float* work, float* out, void* stream) {
+    if (!x || !work || !out) return fail(SINGA_E_NULL, "colsum: null pointer");
+    if (n <= 0 || M <= 0) return SINGA_OK;
+    const float* src = x;
+    long long rows = M, sld = ld;
+    long long s1 = (M + COLSUM_R - 1) / COLSUM_R;
+    float* bufs[2] = {work, work + s1 * n};
+    int which = 0;
+    while (true) {
+        long long slabs = (rows + COLSUM_R - 1) / COLSUM_R;
+        float* dst = slabs == 1 ? out : bufs[which];
+        long long threads = slabs * n;
+        hipLaunchKernelGGL(colsum_pass_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           src, sld, rows, n, dst);
+        if (slabs == 1) break;
+        src = dst;
+        sld = n;
+        rows = slabs;
+        which ^= 1;
+    }
     return check_launch("colsum");
 }
 

@@ -487,9 +487,9 @@ def colsum(t):
         t2 = t2.contiguous()
     M, n = t2.shape
     lib = _lib.lib()
-    part = torch.empty(lib.singa_colsum_nparts(M), n, device=t.device, dtype=torch.float32)
+    work = torch.empty(lib.singa_colsum_work(M, n), device=t.device, dtype=torch.float32)
     out = torch.empty(n, device=t.device, dtype=torch.float32)
-    _chk(lib.singa_colsum(_p(t2), t2.stride(0), M, n, _p(part), _p(out), _stream()), "singa_colsum")
+    _chk(lib.singa_colsum(_p(t2), t2.stride(0), M, n, _p(work), _p(out), _stream()), "singa_colsum")
     return out.view(t.shape[1:])
 
 
@@ -510,7 +510,7 @@ def bias_add(x, b):
 
 import os as _os
 
-_SPLITK_MIN_ROWS = int(_os.environ.get("SINGA_SPLITK_MIN", "131072"))
+_SPLITK_MIN_ROWS = int(_os.environ.get("SINGA_SPLITK_MIN", "16384"))
 
 
 def _splitk_tn(a, b, chunk=8192):

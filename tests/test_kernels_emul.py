@@ -246,9 +246,9 @@ def test_argument_errors(emul):
 
 def test_colsum(emul):
     rs = np.random.RandomState(1)
-    for M, n, ld in ((1, 5, 5), (700, 33, 40), (5000, 300, 300)):
+    for M, n, ld in ((1, 5, 5), (128, 3, 3), (700, 33, 40), (5000, 300, 300), (40000, 7, 9)):
         x = rs.randn(M, ld).astype(np.float32)
-        part = np.zeros((emul.singa_colsum_nparts(M), n), np.float32)
+        part = np.zeros(emul.singa_colsum_work(M, n), np.float32)
         out = np.zeros(n, np.float32)
         assert emul.singa_colsum(ptr(x), ld, M, n, ptr(part), ptr(out), None) == 0
         assert np.abs(out - x[:, :n].astype(np.float64).sum(0)).max() < 1e-3
