@@ -520,12 +520,39 @@ def _splitk_tn(a, b, chunk=8192):
     q = b.shape[1]
     S = M // chunk
     if M < _SPLITK_MIN_ROWS or S < 2:
-        return a.t() @ b
+        return _mm(a.t(), b)
     Mc = S * chunk
     out = colsum(torch.bmm(a[:Mc].view(S, chunk, p).transpose(1, 2), b[:Mc].view(S, chunk, q)))
     if Mc < M:
         out = out + a[Mc:].t() @ b[Mc:]
     return out
+
+
+class _blas:
+    """Per-call choice of the GEMM library (measured on MI355X, fp32, tools/lab/gemm_probe.py): hipBLASLt has a ~19 us
+    floor and picks single-workgroup tiles for some small shapes (256x960x256: 214 us vs 8 us in rocBLAS), rocBLAS
+    collapses on tall reductions (64x28800x64: 1.5 ms).  Small-K / moderate-M products go to rocBLAS, the rest to
+    hipBLASLt.  The switch is host-side state only; under HIP-graph replay the chosen kernels are baked in."""
+
+    def __init__(self, m, n, k):
+        self.use_rocblas = _ROCBLAS_SMALL and k <= 2048 and m <= 32768 and n <= 4096
+
+    def __enter__(self):
+        if self.use_rocblas:
+            torch.backends.cuda.preferred_blas_library("cublas")
+
+    def __exit__(self, *a):
+        if self.use_rocblas:
+            torch.backends.cuda.preferred_blas_library("cublaslt")
+        return False
+
+
+_ROCBLAS_SMALL = _os.environ.get("SINGA_ROCBLAS_SMALL", "1") == "1"
+
+
+def _mm(a, b):
+    with _blas(a.shape[0], b.shape[1], a.shape[1]):
+        return a @ b
 
 
 class _Linear(torch.autograd.Function):
@@ -534,14 +561,15 @@ class _Linear(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         ctx.save_for_backward(x2, w)
         ctx.xshape, ctx.has_bias = x.shape, b is not None
-        y = torch.addmm(b, x2, w.t()) if b is not None else x2 @ w.t()
+        with _blas(x2.shape[0], w.shape[0], x2.shape[1]):
+            y = torch.addmm(b, x2, w.t()) if b is not None else x2 @ w.t()
         return y.view(*x.shape[:-1], w.shape[0])
 
     @staticmethod
     def backward(ctx, g):
         x2, w = ctx.saved_tensors
         g2 = g.reshape(-1, g.shape[-1])
-        gx = (g2 @ w).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        gx = _mm(g2, w).view(ctx.xshape) if ctx.needs_input_grad[0] else None
         gw = _splitk_tn(g2, x2) if ctx.needs_input_grad[1] else None
         gb = colsum(g2) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb
@@ -581,3 +609,22 @@ class _SmallVocabEmbedding(torch.autograd.Function):
 
 def embedding(weight, idx, padding_idx=None):
     return _SmallVocabEmbedding.apply(weight, idx, padding_idx)
+
+
+class _RowDotBias(torch.autograd.Function):
+    """(x[..., d] * b[d]).sum(-1) with a replay-safe, GEMV-free bias gradient (rocBLAS gemv took 236 us here)."""
+
+    @staticmethod
+    def forward(ctx, x, b):
+        ctx.save_for_backward(x, b)
+        return (x * b).sum(-1)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, b = ctx.saved_tensors
+        ge = g.unsqueeze(-1)
+        return ge * b, colsum((ge * x).reshape(-1, x.shape[-1]))
+
+
+def rowdot_bias(x, b):
+    return _RowDotBias.apply(x, b)
