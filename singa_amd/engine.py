@@ -139,6 +139,7 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.opt.zero_grad(set_to_none=True)
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # warm-up ran on the side stream
         self.g_fb = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_fb):
             self.static_loss = self._fwd_bwd(st)

@@ -6,8 +6,11 @@ inputs exactly as in the reference (`.detach()` at EF:490-491, 2351); backward k
 rotated intermediates.
 """
 import ctypes
+import warnings
 
 import torch
+
+warnings.filterwarnings("ignore", message=".*preferred_blas_library is an experimental feature.*")
 
 from . import _capi, _lib, so3
 

@@ -1,0 +1,170 @@
+#!/usr/bin/env python
+"""Training entrypoint with the reference's shape (reference train.py:32-260): `--config --device --logdir`, YAML config,
+seeded model build, Adam(lr 1e-4, betas (0.99, 0.999)), CrossEntropy, clip_grad_norm_(max_grad_norm), plateau scheduler,
+validation every `val_freq` iterations with early stopping, checkpoints {'config','model','optimizer','scheduler',
+'iteration'}.  The step itself runs through singa_amd.engine.TrainStep (HIP kernels + HIP-graph replay).
+
+The CrossDocked dataset and the RDKit/ODDT featurisation of the reference are out of scope, so graphs
+come from `--data golden` (the three bundled example graphs, tests/golden/graph_*.npz) or `--data synthetic`
+(singa_amd.graph.synthetic_graph).  Under `torch.distributed.run` every rank trains on its own shard of each batch and
+gradients are averaged with RCCL (singa_amd.dp).
+
+    python train.py --config ./config/train.yml --device cuda --logdir ./logs --data synthetic --max-iters 20
+"""
+import argparse
+import logging
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class EarlyStopping:
+    """utils/Stopping.py:3-42 of the reference: stop after `patience` validations without a `delta` improvement."""
+
+    def __init__(self, mode="min", patience=20, delta=0.00005):
+        self.best, self.bad, self.patience, self.delta = None, 0, patience, delta
+
+    def step(self, value):
+        if self.best is None or value < self.best - self.delta:
+            self.best, self.bad = value, 0
+        else:
+            self.bad += 1
+        return self.bad >= self.patience
+
+
+def get_logger(name, log_dir):
+    logger = logging.getLogger(name)
+    logger.setLevel(logging.DEBUG)
+    fmt = logging.Formatter("[%(asctime)s::%(name)s::%(levelname)s] %(message)s")
+    for h in (logging.StreamHandler(), logging.FileHandler(os.path.join(log_dir, "log.txt"))):
+        h.setFormatter(fmt)
+        logger.addHandler(h)
+    return logger
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, default=os.path.join(ROOT, "config", "train.yml"))
+    ap.add_argument("--device", type=str, default="cuda")
+    ap.add_argument("--logdir", type=str, default="./logs")
+    ap.add_argument("--data", choices=["synthetic", "golden"], default="synthetic")
+    ap.add_argument("--lmax", type=int, default=None, help="override embedding.lmax_list (2, 4 or 6)")
+    ap.add_argument("--max-iters", type=int, default=None)
+    ap.add_argument("--batch-size", type=int, default=None, help="graphs per step over all ranks")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step into HIP graphs and replay it (needs same-shape batches, e.g. --data golden; "
+                         "a batch with different edge counts triggers a re-capture)")
+    ap.add_argument("--resume", type=str, default=None, help="checkpoint to load (model, optimizer, scheduler, iteration)")
+    args = ap.parse_args()
+    assert args.device.startswith("cuda"), "the hot path is the HIP path: there is no CPU fallback"
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    from singa_amd import dp, graph as G
+    from singa_amd.config import load_config
+    from singa_amd.engine import TrainStep
+    from singa_amd.model.GAN import SINGA
+
+    cfg = load_config(args.config, lmax=args.lmax)
+    torch.manual_seed(cfg.train.seed)
+    log_dir = os.path.join(args.logdir, time.strftime("train_%Y_%m_%d__%H_%M_%S"))
+    ckpt_dir = os.path.join(log_dir, "checkpoints")
+    if rank == 0:
+        os.makedirs(ckpt_dir, exist_ok=True)
+        logger = get_logger("training_log", log_dir)
+        logger.info(f"args {vars(args)}; world {world}")
+    log = (lambda m: logger.info(m)) if rank == 0 else (lambda m: None)
+
+    batch_size = args.batch_size or cfg.train.batch_size
+    lo, hi = dp.shard_range(batch_size, rank, world)
+
+    def make_batch(split, it):
+        """One batch of `batch_size` graphs; this rank materialises only its shard [lo, hi)."""
+        if args.data == "golden":
+            names = ["3wi2_4tpp", "4agq_5a7b", "5cp5_4nue"]
+            gs = [G.load_npz(os.path.join(ROOT, "tests", "golden", f"graph_{names[i % 3]}.npz")) for i in range(lo, hi)]
+        else:
+            base = {"train": 0, "val": 10_000_000, "test": 20_000_000}[split] + it * batch_size
+            gs = [G.synthetic_graph(base + i) for i in range(lo, hi)]
+        return G.collate(gs).to(dev)
+
+    model = SINGA(cfg, device=dev)
+    o = cfg.train.optimizer
+    opt = torch.optim.Adam(model.parameters(), lr=o.lr, betas=(o.beta1, o.beta2), weight_decay=o.weight_decay,
+                           capturable=args.graph)
+    s = cfg.train.scheduler
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=s.factor, patience=s.patience, min_lr=s.min_lr)
+    start_it = 1
+    if args.resume:
+        ck = torch.load(args.resume, map_location=dev)
+        model.load_state_dict(ck["model"], strict=False)        # reference checkpoints: derived buffers are recomputed
+        opt.load_state_dict(ck["optimizer"])
+        sched.load_state_dict(ck["scheduler"])
+        start_it = ck["iteration"] + 1
+    reducer = dp.GradAllReducer(model) if world > 1 else None
+    if reducer:
+        reducer.check_same_init()
+    engine = TrainStep(model, opt, reducer, use_graph=args.graph, max_grad_norm=float(cfg.train.max_grad_norm))
+    early = EarlyStopping(patience=20, delta=0.00005)
+
+    def evaluate(split, n_batches=2):
+        model.eval()
+        tot = 0.0
+        with torch.no_grad():
+            for b in range(n_batches):
+                batch = make_batch(split, b)
+                model.prepare(batch)
+                logits = model(batch)
+                loss = torch.nn.functional.cross_entropy(logits, batch["ligand_data"]["smiIndices_tgt"].reshape(-1))
+                t = loss.detach().clone()
+                if world > 1:
+                    dist.all_reduce(t)
+                    t /= world
+                tot += float(t)
+        return tot / n_batches
+
+    max_iters = args.max_iters or cfg.train.max_iters
+    log(f"model built: {sum(p.numel() for p in model.parameters())} parameters; training for {max_iters} iterations")
+    for it in range(start_it, max_iters + 1):
+        model.train()
+        t0 = time.perf_counter()
+        loss = engine.step(make_batch("train", it))
+        loss_v = float(loss.detach())
+        log(f"[Train] Iter {it} | Loss {loss_v:.6f} | Grad {float(engine.grad_norm):.4f} | "
+            f"LR {opt.param_groups[0]['lr']:.2e} | {time.perf_counter() - t0:.3f} s")
+        if it % cfg.train.val_freq == 0 or it == max_iters:
+            val = evaluate("val")
+            sched.step(val)
+            log(f"[Validate] Iter {it} | Loss {val:.6f}")
+            if rank == 0:
+                torch.save({"config": dict(cfg), "model": model.state_dict(), "optimizer": opt.state_dict(),
+                            "scheduler": sched.state_dict(), "iteration": it}, os.path.join(ckpt_dir, f"{it}.pt"))
+            if early.step(val):
+                log("Early stopping")
+                break
+    log(f"[Test] Loss {evaluate('test'):.6f}")
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
