@@ -270,63 +270,83 @@ __host__ __device__ constexpr float rescale_of(int l, int M) {
 // segment U edges at a time: all U*rows message loads of a chunk are issued before the first FMA (memory-level
 // parallelism; the segment walk is otherwise a chain of dependent HBM round trips), then per edge
 // m[r] = alpha * msg[e, r, c]; acc[l^2+j] += W_e[r][j] * m[r].  M0: only the m = 0 rows exist.
-template <int L, int M, bool M0, int U>
-__global__ void rotate_back_scatter_kernel(Segs msg, const float* __restrict__ alpha, const float* __restrict__ wr,
-                                           const int* __restrict__ row_ptr, float* __restrict__ out, int N, int CH,
-                                           int vh, float out_scale) {
+template <int L, int M, bool M0, int U, int CH, int VH>
+__global__ void __launch_bounds__(128) rotate_back_scatter_kernel(Segs msg, const float* __restrict__ alpha, const float* __restrict__ wr,
+                                           const int* __restrict__ row_ptr, float* __restrict__ out, int N,
+                                           float out_scale) {
     using I = SO3Idx<L, M>;
     constexpr int NR = M0 ? L + 1 : I::KR;
+    constexpr int heads = CH / VH;
+    constexpr int r0 = L + 1, r01 = L + 1 + 2 * L;   // rows of the m = 0 and m = +-1 segments (checked by the host)
     const int act = threadIdx.x < CH;
     const int c = act ? threadIdx.x : CH - 1;   // surplus lanes shadow the last channel (they only fetch Wigner rows)
     const int lane = threadIdx.x & 63;
-    const int heads = CH / vh;
-    const int r0 = msg.rows[0], r01 = msg.rows[0] + msg.rows[1];
+
+    // fetch one edge: Wigner record + its NR message rows (scaled by alpha; weight 0 for an out-of-range slot)
+    auto fetch = [&](int e, bool ok, WRows<I::WSZ>& W, float (&v)[NR]) {
+        W.load(wr + (long long)e * I::WSZ, lane);
+        const float a = ok ? (alpha ? alpha[(long long)e * heads + c / VH] : 1.f) : 0.f;
+        const float* b0 = msg.p[0] + (long long)e * msg.ld[0] + c;
+        const float* b1 = M0 ? b0 : msg.p[1] + (long long)e * msg.ld[1] + c;
+        const float* b2 = M0 ? b0 : msg.p[2] + (long long)e * msg.ld[2] + c;
+#pragma unroll
+        for (int l = 0; l <= L; ++l) {
+#pragma unroll
+            for (int mi = 0; mi < I::nr(l); ++mi) {
+                const int m = mi - I::mm(l);
+                if (M0 && m != 0) continue;
+                const int q = I::mpos(l, m);        // compile-time: segment and offset are immediates
+                const float x = q < r0 ? b0[q * CH] : (q < r01 ? b1[(q - r0) * CH] : b2[(q - r01) * CH]);
+                v[M0 ? l : I::kr_off(l) + mi] = x * a;
+            }
+        }
+    };
+    auto rotate_add = [&](const WRows<I::WSZ>& W, const float (&v)[NR], float (&acc)[I::K]) {
+#pragma unroll
+        for (int l = 0; l <= L; ++l) {
+#pragma unroll
+            for (int mi = 0; mi < I::nr(l); ++mi) {
+                const int m = mi - I::mm(l);
+                if (M0 && m != 0) continue;
+                const float x = v[M0 ? l : I::kr_off(l) + mi];
+#pragma unroll
+                for (int j = 0; j < 2 * l + 1; ++j)
+                    acc[l * l + j] = fmaf(W_AT(W, I::w_off(l) + mi * (2 * l + 1) + j), x, acc[l * l + j]);
+            }
+        }
+    };
+
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
         float acc[I::K];
 #pragma unroll
         for (int k = 0; k < I::K; ++k) acc[k] = 0.f;
         const int beg = row_ptr[n], end = row_ptr[n + 1];
-        for (int e0 = beg; e0 < end; e0 += U) {
-            float v[U][NR];
-            WRows<I::WSZ> W[U];
+        if (U > 0) {
+            // chunked walk: all loads of U edges are in flight before the first FMA
+            for (int e0 = beg; e0 < end; e0 += (U > 0 ? U : 1)) {
+                float v[U > 0 ? U : 1][NR];
+                WRows<I::WSZ> W[U > 0 ? U : 1];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const bool ok = e0 + u < end;
-                const int e = ok ? e0 + u : end - 1;  // wave-uniform; out-of-range slots re-read the last edge, weight 0
-                W[u].load(wr + (long long)e * I::WSZ, lane);
-                const float a = ok ? (alpha ? alpha[(long long)e * heads + c / vh] : 1.f) : 0.f;
-                const float* b0 = msg.p[0] + (long long)e * msg.ld[0] + c;
-                const float* b1 = M0 ? b0 : msg.p[1] + (long long)e * msg.ld[1] + c - (long long)r0 * CH;
-                const float* b2 = M0 ? b0 : msg.p[2] + (long long)e * msg.ld[2] + c - (long long)r01 * CH;
-                int ri = 0;
-#pragma unroll
-                for (int l = 0; l <= L; ++l) {
-#pragma unroll
-                    for (int mi = 0; mi < I::nr(l); ++mi) {
-                        const int m = mi - I::mm(l);
-                        if (M0 && m != 0) continue;
-                        const int q = I::mpos(l, m);
-                        const float* bp = q < r0 ? b0 : (q < r01 ? b1 : b2);
-                        v[u][M0 ? l : I::kr_off(l) + mi] = bp[(long long)q * CH] * a;
-                        ++ri;
-                    }
+                for (int u = 0; u < U; ++u) {
+                    const bool ok = e0 + u < end;
+                    fetch(ok ? e0 + u : end - 1, ok, W[u], v[u]);
                 }
-                (void)ri;
+#pragma unroll
+                for (int u = 0; u < U; ++u) rotate_add(W[u], v[u], acc);
             }
+        } else if (beg < end) {
+            // software pipeline (large L: the rotation of one edge is ~500 instructions): the next edge's loads are
+            // issued before the current edge is rotated, so HBM latency hides under the FMAs
+            float vc[NR], vn[NR];
+            WRows<I::WSZ> Wc, Wn;
+            fetch(beg, true, Wc, vc);
+            for (int e = beg; e < end; ++e) {
+                const bool more = e + 1 < end;
+                fetch(more ? e + 1 : e, more, Wn, vn);
+                rotate_add(Wc, vc, acc);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int l = 0; l <= L; ++l) {
-#pragma unroll
-                    for (int mi = 0; mi < I::nr(l); ++mi) {
-                        const int m = mi - I::mm(l);
-                        if (M0 && m != 0) continue;
-                        const float x = v[u][M0 ? l : I::kr_off(l) + mi];
-#pragma unroll
-                        for (int j = 0; j < 2 * l + 1; ++j)
-                            acc[l * l + j] = fmaf(W_AT(W[u], I::w_off(l) + mi * (2 * l + 1) + j), x, acc[l * l + j]);
-                    }
-                }
+                for (int i = 0; i < NR; ++i) vc[i] = vn[i];
+                Wc = Wn;
             }
         }
         if (act) {
@@ -343,17 +363,40 @@ __global__ void rotate_back_scatter_kernel(Segs msg, const float* __restrict__ a
 
 // Backward: g[k] = g_out[n,k,c] * rescale * out_scale once per node; per edge t[r] = sum_j W_e[r][j] g[l^2+j];
 // g_msg[e,r,c] = alpha * t[r]; g_alpha_part[e,c] = sum_r msg[e,r,c] * t[r].
-template <int L, int M, bool M0>
-__global__ void rotate_back_scatter_bwd_kernel(const float* __restrict__ g_out, Segs msg, SegsMut gmsg,
+template <int L, int M, bool M0, int CH, int VH>
+__global__ void __launch_bounds__(128) rotate_back_scatter_bwd_kernel(const float* __restrict__ g_out, Segs msg, SegsMut gmsg,
                                                const float* __restrict__ alpha, const float* __restrict__ wr,
                                                const int* __restrict__ row_ptr, float* __restrict__ g_alpha_part, int N,
-                                               int CH, int vh, float out_scale) {
+                                               float out_scale) {
     using I = SO3Idx<L, M>;
+    constexpr int NR = M0 ? L + 1 : I::KR;
+    constexpr int heads = CH / VH;
+    constexpr int r0 = L + 1, r01 = L + 1 + 2 * L;
     const bool act = threadIdx.x < CH;
     const int c = act ? threadIdx.x : CH - 1;   // surplus lanes shadow the last channel and never store
     const int lane = threadIdx.x & 63;
-    const int heads = CH / vh;
-    const int r0 = gmsg.rows[0], r01 = gmsg.rows[0] + gmsg.rows[1];
+
+    // per-edge inputs: Wigner record, alpha, and (for d/d alpha) the forward message rows
+    auto fetch = [&](int e, WRows<I::WSZ>& W, float& a, float (&mv)[NR]) {
+        W.load(wr + (long long)e * I::WSZ, lane);
+        a = alpha ? alpha[(long long)e * heads + c / VH] : 1.f;
+        if (alpha) {
+            const float* b0 = msg.p[0] + (long long)e * msg.ld[0] + c;
+            const float* b1 = M0 ? b0 : msg.p[1] + (long long)e * msg.ld[1] + c;
+            const float* b2 = M0 ? b0 : msg.p[2] + (long long)e * msg.ld[2] + c;
+#pragma unroll
+            for (int l = 0; l <= L; ++l) {
+#pragma unroll
+                for (int mi = 0; mi < I::nr(l); ++mi) {
+                    const int m = mi - I::mm(l);
+                    if (M0 && m != 0) continue;
+                    const int q = I::mpos(l, m);
+                    mv[M0 ? l : I::kr_off(l) + mi] = q < r0 ? b0[q * CH] : (q < r01 ? b1[(q - r0) * CH] : b2[(q - r01) * CH]);
+                }
+            }
+        }
+    };
+
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
         float g[I::K];
         const float* gi = g_out + (long long)n * I::K * CH + c;
@@ -363,16 +406,15 @@ __global__ void rotate_back_scatter_bwd_kernel(const float* __restrict__ g_out, 
             for (int j = 0; j < 2 * l + 1; ++j) g[l * l + j] = gi[(long long)(l * l + j) * CH] * (rescale_of(l, M) * out_scale);
         }
         const int beg = row_ptr[n], end = row_ptr[n + 1];
+        if (beg >= end) continue;
+        WRows<I::WSZ> Wc, Wn;
+        float ac, an, mc[NR], mn[NR];
+        fetch(beg, Wc, ac, mc);
         for (int e = beg; e < end; ++e) {
-            WRows<I::WSZ> W;
-            W.load(wr + (long long)e * I::WSZ, lane);
-            const float a = alpha ? alpha[(long long)e * heads + c / vh] : 1.f;
-            const float* b0 = alpha ? msg.p[0] + (long long)e * msg.ld[0] + c : nullptr;
-            const float* b1 = (M0 || !alpha) ? b0 : msg.p[1] + (long long)e * msg.ld[1] + c - (long long)r0 * CH;
-            const float* b2 = (M0 || !alpha) ? b0 : msg.p[2] + (long long)e * msg.ld[2] + c - (long long)r01 * CH;
+            fetch(e + 1 < end ? e + 1 : e, Wn, an, mn);      // next edge's loads fly while this edge is rotated
             float* o0 = gmsg.p[0] + (long long)e * gmsg.ld[0] + c;
-            float* o1 = M0 ? o0 : gmsg.p[1] + (long long)e * gmsg.ld[1] + c - (long long)r0 * CH;
-            float* o2 = M0 ? o0 : gmsg.p[2] + (long long)e * gmsg.ld[2] + c - (long long)r01 * CH;
+            float* o1 = M0 ? o0 : gmsg.p[1] + (long long)e * gmsg.ld[1] + c;
+            float* o2 = M0 ? o0 : gmsg.p[2] + (long long)e * gmsg.ld[2] + c;
             float part = 0.f;
 #pragma unroll
             for (int l = 0; l <= L; ++l) {
@@ -383,16 +425,20 @@ __global__ void rotate_back_scatter_bwd_kernel(const float* __restrict__ g_out, 
                     const int q = I::mpos(l, m);
                     float t = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 2 * l + 1; ++j) t = fmaf(W_AT(W, I::w_off(l) + mi * (2 * l + 1) + j), g[l * l + j], t);
-                    float* op = q < r0 ? o0 : (q < r01 ? o1 : o2);
-                    if (act) op[(long long)q * CH] = a * t;
-                    if (alpha) {
-                        const float* bp = q < r0 ? b0 : (q < r01 ? b1 : b2);
-                        part = fmaf(bp[(long long)q * CH], t, part);
+                    for (int j = 0; j < 2 * l + 1; ++j) t = fmaf(W_AT(Wc, I::w_off(l) + mi * (2 * l + 1) + j), g[l * l + j], t);
+                    if (act) {
+                        if (q < r0) o0[q * CH] = ac * t;
+                        else if (q < r01) o1[(q - r0) * CH] = ac * t;
+                        else o2[(q - r01) * CH] = ac * t;
                     }
+                    if (alpha) part = fmaf(mc[M0 ? l : I::kr_off(l) + mi], t, part);
                 }
             }
             if (alpha && act) g_alpha_part[(long long)e * CH + c] = part;
+            Wc = Wn;
+            ac = an;
+#pragma unroll
+            for (int i = 0; i < NR; ++i) mc[i] = mn[i];
         }
     }
 }
@@ -702,24 +748,26 @@ __global__ void colsum_pass_kernel(const float* __restrict__ x, long long ld, lo
 // ------------------------------------------------------------------------------------------------ k8: S2 activation
 // thread = (edge-or-node e, channel c).  x rows in registers; loop over the G grid points with the two grid-matrix
 // rows as wave-uniform scalars: u = to[g,:].x, s = SiLU(u), y += from[g,:] * s.  Row 0 of the result is SiLU(gate).
-template <int KIN>
+// KIN rows, C channels (compile time).  EDGE: the rows come in the three per-m segments of an SO(2) convolution
+// ((L+1) | 2L | 2(L-1) rows, KIN = 5L-1); otherwise one contiguous [KIN, C] record per row of the batch.
+template <int KIN, int C, bool EDGE>
 __global__ void __launch_bounds__(256) s2act_fwd_kernel(Segs x, const float* __restrict__ gate, long long ldg,
                                                         const float* __restrict__ to_grid,
                                                         const float* __restrict__ from_grid, float* __restrict__ out,
-                                                        long long EC, int C, int G) {
+                                                        long long EC, int G) {
     long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= EC) return;
     long long e = tid / C;
     int c = (int)(tid - e * C);
-    const int r0 = x.rows[0], r01 = x.rows[0] + x.rows[1];
+    constexpr int LL = (KIN + 1) / 5;
+    constexpr int r0 = EDGE ? LL + 1 : KIN, r01 = EDGE ? 3 * LL + 1 : KIN;
     const float* b0 = x.p[0] + e * x.ld[0] + c;
-    const float* b1 = x.p[1] ? x.p[1] + e * x.ld[1] + c - (long long)r0 * C : b0;
-    const float* b2 = x.p[2] ? x.p[2] + e * x.ld[2] + c - (long long)r01 * C : b0;
+    const float* b1 = EDGE ? x.p[1] + e * x.ld[1] + c : b0;
+    const float* b2 = EDGE ? x.p[2] + e * x.ld[2] + c : b0;
     float xv[KIN], yv[KIN];
 #pragma unroll
     for (int i = 0; i < KIN; ++i) {
-        const float* bp = i < r0 ? b0 : (i < r01 ? b1 : b2);
-        xv[i] = bp[(long long)i * C];
+        xv[i] = i < r0 ? b0[i * C] : (i < r01 ? b1[(i - r0) * C] : b2[(i - r01) * C]);
         yv[i] = 0.f;
     }
     for (int g = 0; g < G; ++g) {
@@ -740,27 +788,27 @@ __global__ void __launch_bounds__(256) s2act_fwd_kernel(Segs x, const float* __r
 
 // Backward (recompute u): v = sum_{i>=1} from[g,i] gy[i];  w = v * SiLU'(u);  gx[i] += to[g,i] * w;
 // g_gate = gy[0] * SiLU'(gate).
-template <int KIN>
+template <int KIN, int C, bool EDGE>
 __global__ void __launch_bounds__(256) s2act_bwd_kernel(Segs x, const float* __restrict__ gate, long long ldg,
                                                         const float* __restrict__ to_grid,
                                                         const float* __restrict__ from_grid,
                                                         const float* __restrict__ g_out, float* __restrict__ gx,
-                                                        float* __restrict__ g_gate, long long EC, int C, int G) {
+                                                        float* __restrict__ g_gate, long long EC, int G) {
     long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= EC) return;
     long long e = tid / C;
     int c = (int)(tid - e * C);
-    const int r0 = x.rows[0], r01 = x.rows[0] + x.rows[1];
+    constexpr int LL = (KIN + 1) / 5;
+    constexpr int r0 = EDGE ? LL + 1 : KIN, r01 = EDGE ? 3 * LL + 1 : KIN;
     const float* b0 = x.p[0] + e * x.ld[0] + c;
-    const float* b1 = x.p[1] ? x.p[1] + e * x.ld[1] + c - (long long)r0 * C : b0;
-    const float* b2 = x.p[2] ? x.p[2] + e * x.ld[2] + c - (long long)r01 * C : b0;
+    const float* b1 = EDGE ? x.p[1] + e * x.ld[1] + c : b0;
+    const float* b2 = EDGE ? x.p[2] + e * x.ld[2] + c : b0;
     const float* gi = g_out + e * KIN * C + c;
     float xv[KIN], gy[KIN], ga[KIN];
 #pragma unroll
     for (int i = 0; i < KIN; ++i) {
-        const float* bp = i < r0 ? b0 : (i < r01 ? b1 : b2);
-        xv[i] = bp[(long long)i * C];
-        gy[i] = gi[(long long)i * C];
+        xv[i] = i < r0 ? b0[i * C] : (i < r01 ? b1[(i - r0) * C] : b2[(i - r01) * C]);
+        gy[i] = gi[i * C];
         ga[i] = 0.f;
     }
     for (int g = 0; g < G; ++g) {
@@ -1082,6 +1130,8 @@ int singa_rotate_back_scatter_fwd(const singa_seg_t* msg, int nseg, const float*
     if (!pack(msg, nseg, &s) || !wr || !row_ptr || !out) return fail(SINGA_E_NULL, "rotate_back_scatter_fwd: null pointer");
     if (CH < 1 || CH > 128 || heads < 1 || CH % heads) return fail(SINGA_E_SHAPE, "rotate_back_scatter: CH must be <= 128 and divisible by heads");
     if (!m0_only && nseg != 3) return fail(SINGA_E_SHAPE, "rotate_back_scatter: full mode takes the 3 per-m segments");
+    if (m0_only ? (CH != 16 || heads != 1) : (CH != 112 || heads != 7))
+        return fail(SINGA_E_SHAPE, "rotate_back_scatter: built for 7 heads x 16 value channels (full) and 16 channels (m0_only)");
     if (Nd <= 0) return SINGA_OK;
     int bs = CH <= 64 ? 64 : 128;
     const int n_edges_hint = g_prof_edges_hint;
@@ -1089,20 +1139,21 @@ int singa_rotate_back_scatter_fwd(const singa_seg_t* msg, int nseg, const float*
         if (!m0_only && (s.rows[0] != L_ + 1 || s.rows[1] != 2 * L_ || s.rows[2] != 2 * (L_ - 1)))
             return fail(SINGA_E_SHAPE, "rotate_back_scatter: segment row counts must be L+1, 2L, 2(L-1)");
         if (m0_only)
-            hipLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, true, 4>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
-                               (hipStream_t)stream, s, alpha, wr, row_ptr, out, Nd, CH, CH / heads, out_scale);
+            hipLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, true, 4, 16, 16>), dim3(grid_for(Nd, 1 << 20)), dim3(bs),
+                               0, (hipStream_t)stream, s, alpha, wr, row_ptr, out, Nd, out_scale);
         else if (g_prof_on && g_prof_n < PROF_CAP) {
             ProfRec& r = g_prof[g_prof_n++];
             (void)hipEventCreate(&r.a);
             (void)hipEventCreate(&r.b);
             r.E = n_edges_hint;
             r.N = Nd;
-            hipExtLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, false, (L_ == 2 ? 4 : (L_ == 4 ? 2 : 1))>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
-                                  (hipStream_t)stream, r.a, r.b, 0, s, alpha, wr, row_ptr, out, Nd, CH, CH / heads,
-                                  out_scale);
+            hipExtLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, false, (L_ == 2 ? 4 : 0), 112, 16>),
+                                  dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0, (hipStream_t)stream, r.a, r.b, 0, s, alpha, wr,
+                                  row_ptr, out, Nd, out_scale);
         } else
-            hipLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, false, (L_ == 2 ? 4 : (L_ == 4 ? 2 : 1))>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
-                               (hipStream_t)stream, s, alpha, wr, row_ptr, out, Nd, CH, CH / heads, out_scale);
+            hipLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, false, (L_ == 2 ? 4 : 0), 112, 16>),
+                               dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0, (hipStream_t)stream, s, alpha, wr, row_ptr, out,
+                               Nd, out_scale);
     });
     return check_launch("rotate_back_scatter_fwd");
 }
@@ -1118,19 +1169,19 @@ int singa_rotate_back_scatter_bwd(const float* g_out, const singa_seg_t* msg, co
     if (alpha && (!pack(msg, nseg, &s) || !g_alpha_part)) return fail(SINGA_E_NULL, "rotate_back_scatter_bwd: alpha given without msg / g_alpha_part");
     if (CH < 1 || CH > 128 || heads < 1 || CH % heads) return fail(SINGA_E_SHAPE, "rotate_back_scatter: CH must be <= 128 and divisible by heads");
     if (!m0_only && nseg != 3) return fail(SINGA_E_SHAPE, "rotate_back_scatter: full mode takes the 3 per-m segments");
+    if (m0_only ? (CH != 16 || heads != 1) : (CH != 112 || heads != 7))
+        return fail(SINGA_E_SHAPE, "rotate_back_scatter: built for 7 heads x 16 value channels (full) and 16 channels (m0_only)");
     if (Nd <= 0) return SINGA_OK;
     int bs = CH <= 64 ? 64 : 128;
     SINGA_DISPATCH_L(lmax, mmax, {
         if (!m0_only && (gm.rows[0] != L_ + 1 || gm.rows[1] != 2 * L_ || gm.rows[2] != 2 * (L_ - 1)))
             return fail(SINGA_E_SHAPE, "rotate_back_scatter: segment row counts must be L+1, 2L, 2(L-1)");
         if (m0_only)
-            hipLaunchKernelGGL((rotate_back_scatter_bwd_kernel<L_, 2, true>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
-                               (hipStream_t)stream, g_out, s, gm, alpha, wr, row_ptr, g_alpha_part, Nd, CH, CH / heads,
-                               out_scale);
+            hipLaunchKernelGGL((rotate_back_scatter_bwd_kernel<L_, 2, true, 16, 16>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
+                               (hipStream_t)stream, g_out, s, gm, alpha, wr, row_ptr, g_alpha_part, Nd, out_scale);
         else
-            hipLaunchKernelGGL((rotate_back_scatter_bwd_kernel<L_, 2, false>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
-                               (hipStream_t)stream, g_out, s, gm, alpha, wr, row_ptr, g_alpha_part, Nd, CH, CH / heads,
-                               out_scale);
+            hipLaunchKernelGGL((rotate_back_scatter_bwd_kernel<L_, 2, false, 112, 16>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
+                               (hipStream_t)stream, g_out, s, gm, alpha, wr, row_ptr, g_alpha_part, Nd, out_scale);
     });
     return check_launch("rotate_back_scatter_bwd");
 }
@@ -1177,15 +1228,30 @@ int singa_segment_wsum_bwd(const float* g_out, const float* w, const float* v, c
     return check_launch("segment_wsum_bwd");
 }
 
-#define SINGA_DISPATCH_KIN(kin, ...)                                                        \
-    switch (kin) {                                                                            \
-        case 9: { constexpr int KIN_ = 9; __VA_ARGS__; } break;                                      \
-        case 19: { constexpr int KIN_ = 19; __VA_ARGS__; } break;                                    \
-        case 25: { constexpr int KIN_ = 25; __VA_ARGS__; } break;                                    \
-        case 29: { constexpr int KIN_ = 29; __VA_ARGS__; } break;                                    \
-        case 49: { constexpr int KIN_ = 49; __VA_ARGS__; } break;                                    \
-        default: return fail(SINGA_E_SHAPE, "s2act: KIN must be one of 9, 19, 25, 29, 49");   \
-    }
+// (KIN, C, edge?) combinations that are built: attention grids [L][2] on 128 hidden channels over the three per-m
+// segments (KIN = 9, 19, 29), FFN grids [L][L] on 512 hidden channels over one [KIN, C] record (KIN = 9, 25, 49).
+#define SINGA_DISPATCH_S2(kin, ch, nseg, ...)                                                            \
+    do {                                                                                                 \
+        if ((nseg) == 3 && (ch) == 128) {                                                                \
+            constexpr int C_ = 128; constexpr bool EDGE_ = true;                                         \
+            switch (kin) {                                                                               \
+                case 9: { constexpr int KIN_ = 9; __VA_ARGS__; } break;                                  \
+                case 19: { constexpr int KIN_ = 19; __VA_ARGS__; } break;                                \
+                case 29: { constexpr int KIN_ = 29; __VA_ARGS__; } break;                                \
+                default: return fail(SINGA_E_SHAPE, "s2act(edge): KIN must be 9, 19 or 29");             \
+            }                                                                                            \
+        } else if ((nseg) == 1 && (ch) == 512) {                                                         \
+            constexpr int C_ = 512; constexpr bool EDGE_ = false;                                        \
+            switch (kin) {                                                                               \
+                case 9: { constexpr int KIN_ = 9; __VA_ARGS__; } break;                                  \
+                case 25: { constexpr int KIN_ = 25; __VA_ARGS__; } break;                                \
+                case 49: { constexpr int KIN_ = 49; __VA_ARGS__; } break;                                \
+                default: return fail(SINGA_E_SHAPE, "s2act(node): KIN must be 9, 25 or 49");             \
+            }                                                                                            \
+        } else {                                                                                         \
+            return fail(SINGA_E_SHAPE, "s2act: built for (3 segments, C = 128) and (1 segment, C = 512)"); \
+        }                                                                                                \
+    } while (0)
 
 int singa_s2act_fwd(const singa_seg_t* x, int nseg, const float* gate, int64_t ldg, const float* to_grid,
                     const float* from_grid, float* out, int E, int C, int KIN, int G, void* stream) {
@@ -1195,8 +1261,11 @@ int singa_s2act_fwd(const singa_seg_t* x, int nseg, const float* gate, int64_t l
     if (E <= 0) return SINGA_OK;
     long long EC = (long long)E * C;
     int blocks = (int)((EC + 255) / 256);
-    SINGA_DISPATCH_KIN(KIN, hipLaunchKernelGGL((s2act_fwd_kernel<KIN_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                                               s, gate, (long long)ldg, to_grid, from_grid, out, EC, C, G));
+    if (nseg == 3 && (s.rows[0] != (KIN + 1) / 5 + 1 || s.rows[1] != 2 * ((KIN + 1) / 5)))
+        return fail(SINGA_E_SHAPE, "s2act(edge): segment rows must be L+1, 2L, 2(L-1)");
+    SINGA_DISPATCH_S2(KIN, C, nseg, hipLaunchKernelGGL((s2act_fwd_kernel<KIN_, C_, EDGE_>), dim3(blocks), dim3(256), 0,
+                                                       (hipStream_t)stream, s, gate, (long long)ldg, to_grid, from_grid,
+                                                       out, EC, G));
     return check_launch("s2act_fwd");
 }
 
@@ -1210,8 +1279,11 @@ int singa_s2act_bwd(const singa_seg_t* x, int nseg, const float* gate, int64_t l
     if (E <= 0) return SINGA_OK;
     long long EC = (long long)E * C;
     int blocks = (int)((EC + 255) / 256);
-    SINGA_DISPATCH_KIN(KIN, hipLaunchKernelGGL((s2act_bwd_kernel<KIN_>), dim3(blocks), dim3(256), 0, (hipStream_t)stream,
-                                               s, gate, (long long)ldg, to_grid, from_grid, g_out, gx, g_gate, EC, C, G));
+    if (nseg == 3 && (s.rows[0] != (KIN + 1) / 5 + 1 || s.rows[1] != 2 * ((KIN + 1) / 5)))
+        return fail(SINGA_E_SHAPE, "s2act(edge): segment rows must be L+1, 2L, 2(L-1)");
+    SINGA_DISPATCH_S2(KIN, C, nseg, hipLaunchKernelGGL((s2act_bwd_kernel<KIN_, C_, EDGE_>), dim3(blocks), dim3(256), 0,
+                                                       (hipStream_t)stream, s, gate, (long long)ldg, to_grid, from_grid,
+                                                       g_out, gx, g_gate, EC, G));
     return check_launch("s2act_bwd");
 }
 

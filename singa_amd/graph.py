@@ -202,6 +202,7 @@ WORKLOADS = {
     "cfg2_b32_l2": dict(n_graphs=32, lmax=2, n_protein=200, n_ligand=30, e_pp=1700, e_ll=64, e_x=118),
     "cfg3_b128_l4": dict(n_graphs=128, lmax=4, n_protein=350, n_ligand=30, e_pp=700, e_ll=66, e_x=80),
     "cfg5_l6": dict(n_graphs=64, lmax=6, n_protein=800, n_ligand=40, e_pp=7600, e_ll=88, e_x=156),
+    "cfg5_l6_b8": dict(n_graphs=8, lmax=6, n_protein=800, n_ligand=40, e_pp=7600, e_ll=88, e_x=156),
 }
 
 
