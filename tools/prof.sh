@@ -10,7 +10,7 @@ raw=/tmp/prof_raw_${tag}
 mkdir -p $out $raw
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/trace -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $out/trace.log 2>&1 || echo "trace run failed"
 for c in FETCH_SIZE WRITE_SIZE; do
-  SINGA_CALIB=1 timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $raw/pmc_$c -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $out/pmc_$c.log 2>&1 || echo "pmc $c run failed"
+  SINGA_CALIB=1 timeout -k 10 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $raw/pmc_$c -- python3 bench.py --eager --steps 2 --warmup 1 --roofline-steps 0 --no-cpu-baseline > $out/pmc_$c.log 2>&1 || echo "pmc $c run failed"
 done
 python3 tools/prof_summarize.py $raw $out
 ls -la $out
