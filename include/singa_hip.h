@@ -128,6 +128,15 @@ int singa_s2act_bwd(const singa_seg_t* x, int nseg, const float* gate, int64_t l
                     const float* from_grid, const float* g_out, float* gx, float* g_gate, int E, int C, int KIN,
                     int G, void* stream);
 
+/* k8, separable form (what the product calls): to_grid[(b,a),i] = P[b,i] * A[a,mc(i)], from_grid = Q[b,i] * A[a,mc(i)]
+ * (singa_amd.so3.s2_grid_factors): Legendre transform per beta ring, Fourier transform per ring - ~3x fewer FMAs.
+ * nseg = 3, C = 128: attention grid [lmax][2] on m-primary rows; nseg = 1, C = 512: FFN grid [lmax][lmax] on [K, C]. */
+int singa_s2act_sep_fwd(const singa_seg_t* x, int nseg, const float* gate, int64_t ldg, const float* P, const float* Q,
+                        const float* A, float* out, int E, int C, int lmax, void* stream);
+int singa_s2act_sep_bwd(const singa_seg_t* x, int nseg, const float* gate, int64_t ldg, const float* P, const float* Q,
+                        const float* A, const float* g_out, float* gx, float* g_gate, int E, int C, int lmax,
+                        void* stream);
+
 /* k12 — EquivariantRMSNormArraySphericalHarmonicsV2 as instantiated by get_normalization_layer (EF:2155-2192, 2273):
  * x[N,K,C] -> y[N,K,C]; weight[L+1,C], bias[C]. */
 int singa_so3_rmsnorm_fwd(const float* x, const float* weight, const float* bias, float* y, int N, int C, int lmax,

@@ -31,6 +31,8 @@ _SIGS = {
     "singa_segment_wsum_bwd": ([P, P, P, P, P, P, I32, I32, I32, P], I32),
     "singa_s2act_fwd": ([C.POINTER(Seg), I32, P, I64, P, P, P, I32, I32, I32, I32, P], I32),
     "singa_s2act_bwd": ([C.POINTER(Seg), I32, P, I64, P, P, P, P, P, I32, I32, I32, I32, P], I32),
+    "singa_s2act_sep_fwd": ([C.POINTER(Seg), I32, P, I64, P, P, P, P, I32, I32, I32, P], I32),
+    "singa_s2act_sep_bwd": ([C.POINTER(Seg), I32, P, I64, P, P, P, P, P, P, I32, I32, I32, P], I32),
     "singa_so3_rmsnorm_nparts": ([I32], I32),
     "singa_so3_rmsnorm_fwd": ([P, P, P, P, I32, I32, I32, F32, P], I32),
     "singa_so3_rmsnorm_bwd": ([P, P, P, P, P, P, I32, I32, I32, F32, P], I32),

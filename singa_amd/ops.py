@@ -274,15 +274,12 @@ def segment_wsum(w, v, row_ptr):
 _grid_cache = {}
 
 
-def _grids(L, M, m_primary, device):
+def _grid_factors(L, M, m_primary, device):
+    """Separable S2-grid tables (P [RB,KIN], Q [RB,KIN], A [RA,2M+1]) on `device`, cached (so3.s2_grid_factors)."""
     key = (L, M, m_primary, str(device))
     if key not in _grid_cache:
-        to, fr = so3.s2_grid(L, M)
-        if m_primary:
-            perm = so3.layout(L, M).to_m
-            to, fr = to[:, perm], fr[:, perm]
-        _grid_cache[key] = (torch.tensor(to, dtype=torch.float32, device=device).contiguous(),
-                            torch.tensor(fr, dtype=torch.float32, device=device).contiguous())
+        _grid_cache[key] = tuple(torch.tensor(t, dtype=torch.float32, device=device).contiguous()
+                                 for t in so3.s2_grid_factors(L, M, m_primary))
     return _grid_cache[key]
 
 
@@ -295,14 +292,14 @@ class _S2ActEdge(torch.autograd.Function):
         h0, h1, h2 = h0.contiguous(), h1.contiguous(), h2.contiguous()
         _dev(h0, h1, h2)
         lay = so3.layout(L, M)
-        to, fr = _grids(L, M, True, h0.device)
+        P, Q, A = _grid_factors(L, M, True, h0.device)
         E = h0.shape[0]
         out = torch.empty(E, lay.KR * C, device=h0.device, dtype=torch.float32)
         seg, n = _capi.segs([(h0.data_ptr() + 4 * x_off, h0.stride(0), lay.seg_rows[0]),
                              (h1.data_ptr(), h1.stride(0), lay.seg_rows[1]),
                              (h2.data_ptr(), h2.stride(0), lay.seg_rows[2])])
-        _chk(_lib.lib().singa_s2act_fwd(seg, n, ctypes.c_void_p(h0.data_ptr() + 4 * gate_off), h0.stride(0), _p(to),
-                                        _p(fr), _p(out), E, C, lay.KR, to.shape[0], _stream()), "singa_s2act_fwd")
+        _chk(_lib.lib().singa_s2act_sep_fwd(seg, n, ctypes.c_void_p(h0.data_ptr() + 4 * gate_off), h0.stride(0), _p(P),
+                                            _p(Q), _p(A), _p(out), E, C, L, _stream()), "singa_s2act_sep_fwd")
         ctx.save_for_backward(h0, h1, h2)
         ctx.cfg = (gate_off, x_off, C, L, M)
         return out
@@ -312,7 +309,7 @@ class _S2ActEdge(torch.autograd.Function):
         h0, h1, h2 = ctx.saved_tensors
         gate_off, x_off, C, L, M = ctx.cfg
         lay = so3.layout(L, M)
-        to, fr = _grids(L, M, True, h0.device)
+        P, Q, A = _grid_factors(L, M, True, h0.device)
         g = g.contiguous()
         E = h0.shape[0]
         gx = torch.empty(E, lay.KR * C, device=g.device, dtype=torch.float32)
@@ -320,9 +317,9 @@ class _S2ActEdge(torch.autograd.Function):
         seg, n = _capi.segs([(h0.data_ptr() + 4 * x_off, h0.stride(0), lay.seg_rows[0]),
                              (h1.data_ptr(), h1.stride(0), lay.seg_rows[1]),
                              (h2.data_ptr(), h2.stride(0), lay.seg_rows[2])])
-        _chk(_lib.lib().singa_s2act_bwd(seg, n, ctypes.c_void_p(h0.data_ptr() + 4 * gate_off), h0.stride(0), _p(to),
-                                        _p(fr), _p(g), _p(gx), _p(gg), E, C, lay.KR, to.shape[0], _stream()),
-             "singa_s2act_bwd")
+        _chk(_lib.lib().singa_s2act_sep_bwd(seg, n, ctypes.c_void_p(h0.data_ptr() + 4 * gate_off), h0.stride(0), _p(P),
+                                            _p(Q), _p(A), _p(g), _p(gx), _p(gg), E, C, L, _stream()),
+             "singa_s2act_sep_bwd")
         n0, n1 = lay.seg_rows[0] * C, lay.seg_rows[1] * C
         g0 = torch.zeros_like(h0)
         g0[:, gate_off:gate_off + C] = gg
@@ -341,12 +338,12 @@ class _S2ActNode(torch.autograd.Function):
     def forward(ctx, x, gate, L):
         x, gate = x.contiguous(), gate.contiguous()
         _dev(x, gate)
-        to, fr = _grids(L, L, False, x.device)
+        P, Q, A = _grid_factors(L, L, False, x.device)
         N, K, C = x.shape
         out = torch.empty_like(x)
         seg, n = _capi.segs([(x.data_ptr(), K * C, K)])
-        _chk(_lib.lib().singa_s2act_fwd(seg, n, _p(gate), gate.stride(0), _p(to), _p(fr), _p(out), N, C, K, to.shape[0],
-                                        _stream()), "singa_s2act_fwd(node)")
+        _chk(_lib.lib().singa_s2act_sep_fwd(seg, n, _p(gate), gate.stride(0), _p(P), _p(Q), _p(A), _p(out), N, C, L,
+                                            _stream()), "singa_s2act_sep_fwd(node)")
         ctx.save_for_backward(x, gate)
         ctx.L = L
         return out
@@ -355,13 +352,13 @@ class _S2ActNode(torch.autograd.Function):
     def backward(ctx, g):
         x, gate = ctx.saved_tensors
         L = ctx.L
-        to, fr = _grids(L, L, False, x.device)
+        P, Q, A = _grid_factors(L, L, False, x.device)
         g = g.contiguous()
         N, K, C = x.shape
         gx, gg = torch.empty_like(x), torch.empty_like(gate)
         seg, n = _capi.segs([(x.data_ptr(), K * C, K)])
-        _chk(_lib.lib().singa_s2act_bwd(seg, n, _p(gate), gate.stride(0), _p(to), _p(fr), _p(g), _p(gx), _p(gg), N, C, K,
-                                        to.shape[0], _stream()), "singa_s2act_bwd(node)")
+        _chk(_lib.lib().singa_s2act_sep_bwd(seg, n, _p(gate), gate.stride(0), _p(P), _p(Q), _p(A), _p(g), _p(gx), _p(gg),
+                                            N, C, L, _stream()), "singa_s2act_sep_bwd(node)")
         return gx, gg, None
 
 

@@ -252,3 +252,53 @@ def test_colsum(emul):
         out = np.zeros(n, np.float32)
         assert emul.singa_colsum(ptr(x), ld, M, n, ptr(part), ptr(out), None) == 0
         assert np.abs(out - x[:, :n].astype(np.float64).sum(0)).max() < 1e-3
+
+
+@pytest.mark.parametrize("L,edge", [(2, True), (4, True), (6, True), (2, False), (4, False), (6, False)])
+def test_s2act_separable(emul, L, edge):
+    """Separable (Legendre x Fourier) S2 activation == the dense-grid oracle, forward and backward."""
+    rs = np.random.RandomState(77 + L)
+    M = 2 if edge else L
+    C = 128 if edge else 512
+    E = 3
+    lay = so3.layout(L, M)
+    P, Q, A = (np.ascontiguousarray(t, np.float32) for t in so3.s2_grid_factors(L, M, edge))
+    KIN = P.shape[1]
+    if edge:
+        extra = 64
+        h0 = torch.tensor(rs.randn(E, extra + C + lay.seg_rows[0] * C), dtype=torch.float32, requires_grad=True)
+        h1 = torch.tensor(rs.randn(E, lay.seg_rows[1] * C), dtype=torch.float32, requires_grad=True)
+        h2 = torch.tensor(rs.randn(E, lay.seg_rows[2] * C), dtype=torch.float32, requires_grad=True)
+        xm = torch.cat([h0[:, extra + C:].view(E, -1, C), h1.view(E, -1, C), h2.view(E, -1, C)], 1)
+        to_l = torch.as_tensor(np.argsort(lay.to_m))
+        ref = O.sep_s2_act(h0[:, extra:extra + C], xm[:, to_l], L, M)[:, torch.as_tensor(lay.to_m)]
+        base = h0.detach().numpy()
+        items = [(iptr(base) + 4 * (extra + C), base.shape[1], lay.seg_rows[0]),
+                 (iptr(h1.detach().numpy()), h1.shape[1], lay.seg_rows[1]),
+                 (iptr(h2.detach().numpy()), h2.shape[1], lay.seg_rows[2])]
+        gate_ptr, ldg = iptr(base) + 4 * extra, base.shape[1]
+    else:
+        x = torch.tensor(rs.randn(E, KIN, C), dtype=torch.float32, requires_grad=True)
+        gt = torch.tensor(rs.randn(E, C), dtype=torch.float32, requires_grad=True)
+        ref = O.sep_s2_act(gt, x, L, M)
+        items = [(iptr(x.detach().numpy()), KIN * C, KIN)]
+        gate_ptr, ldg = iptr(gt.detach().numpy()), C
+    seg, n = _capi.segs(items)
+    out = np.full((E, KIN, C), np.nan, np.float32)
+    code = emul.singa_s2act_sep_fwd(seg, n, gate_ptr, ldg, ptr(P), ptr(Q), ptr(A), ptr(out), E, C, L, None)
+    assert code == 0, emul.singa_last_error_string()
+    assert np.abs(out - ref.detach().numpy()).max() < 3e-5 * max(1.0, float(ref.detach().abs().max()))
+    g = torch.tensor(rs.randn(E, KIN, C), dtype=torch.float32)
+    ref.backward(g)
+    gx = np.full((E, KIN, C), np.nan, np.float32)
+    gg = np.full((E, C), np.nan, np.float32)
+    code = emul.singa_s2act_sep_bwd(seg, n, gate_ptr, ldg, ptr(P), ptr(Q), ptr(A), ptr(g.numpy()), ptr(gx), ptr(gg), E, C,
+                                    L, None)
+    assert code == 0
+    if edge:
+        want = torch.cat([h0.grad[:, extra + C:].view(E, -1, C), h1.grad.view(E, -1, C), h2.grad.view(E, -1, C)], 1)
+        want_g = h0.grad[:, extra:extra + C]
+    else:
+        want, want_g = x.grad, gt.grad
+    assert np.abs(gx - want.numpy()).max() < 1e-4 * max(1.0, float(want.abs().max()))
+    assert np.abs(gg - want_g.numpy()).max() < 1e-5
