@@ -135,8 +135,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = torch.cuda.device_count()
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # RCCL ("nccl") is the product path.  SINGA_DIST_BACKEND=gloo exists only to rehearse the multi-rank control flow
+        # on a one-GPU box (several ranks sharing a device, which RCCL refuses).
+        backend = os.environ.get("SINGA_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            local = local % max(n_dev, 1)
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

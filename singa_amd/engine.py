@@ -141,10 +141,11 @@ class TrainStep:
         self.opt.zero_grad(set_to_none=True)
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # warm-up ran on the side stream
         self.g_fb = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fb):
+        # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
+        with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
             self.static_loss = self._fwd_bwd(st)
         self.g_opt = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_opt):
+        with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             self._update()
         self.captures += 1
 

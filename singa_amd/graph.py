@@ -208,3 +208,89 @@ WORKLOADS = {
 
 def synthetic_batch(n_graphs, first_id=0, **kw):
     return collate([synthetic_graph(first_id + i, **kw) for i in range(n_graphs)])
+
+
+# ----------------------------------------------------------------------------------------------- reference .pt graphs
+def load_reference_pt(path, with_lap=True):
+    """Read a pickled PyG `HeteroData` graph of the reference (example/*.pt, dataset/crossdocked_graph10_v3/*.pt) without
+    torch_geometric: stub classes with the pickled class paths receive the state dicts, and the
+    fields the hot path reads are copied into a HeteroGraph.  Older files keep the Vina score in `y[0]`
+    (reference utils/Featuriser.py:155 vs :164)."""
+    import sys
+    import types
+
+    created = []
+
+    def stub(mod, *names):
+        if mod not in sys.modules:
+            sys.modules[mod] = types.ModuleType(mod)
+            created.append(mod)
+        for n in names:
+            if not hasattr(sys.modules[mod], n):
+                setattr(sys.modules[mod], n, type(n, (), {}))
+
+    try:
+        import torch_geometric  # noqa: F401  (if the real package is present, use it)
+    except ImportError:
+        stub("torch_geometric")
+        stub("torch_geometric.data")
+        stub("torch_geometric.data.hetero_data", "HeteroData")
+        stub("torch_geometric.data.storage", "BaseStorage", "NodeStorage", "EdgeStorage")
+        stub("torch_geometric.data.graph_store", "EdgeAttr")
+        stub("torch_geometric.data.feature_store", "TensorAttr")
+    try:
+        obj = torch.load(path, map_location="cpu", weights_only=False)
+    finally:
+        for m in created:
+            sys.modules.pop(m, None)
+    st = obj.__dict__
+
+    def mapping(store):
+        return store.__dict__["_mapping"]
+    glob = mapping(st["_global_store"])
+    g = HeteroGraph()
+    for nt in (PA, LA):
+        m = mapping(st["_node_store_dict"][nt])
+        g.nodes[nt]["x"] = m["x"].float()
+        g.nodes[nt]["pos"] = m["pos"].float()
+        g.globals["atomicnum"][nt] = glob["atomicnum"][nt].long()
+    for et in (E_PP, E_LL, E_LP, E_PL):
+        g.edges[et]["edge_index"] = mapping(st["_edge_store_dict"][et])["edge_index"].long()
+    ld = glob["ligand_data"]
+    vina = float(ld["vina_score"]) if "vina_score" in ld else float(glob["y"][0])
+    g.globals["ligand_data"] = dict(vina_score=vina, qed=float(ld["qed"]), sas=float(ld["sas"]), logP=float(ld["logP"]),
+                                    weight=float(ld["weight"]), tpsa=float(ld["tpsa"]),
+                                    smiIndices_input=ld["smiIndices_input"].long().view(1, -1),
+                                    smiIndices_tgt=ld["smiIndices_tgt"].long().view(1, -1))
+    if with_lap:
+        g.nodes[PA]["lap_pe"] = laplacian_pe(g.edges[E_PP]["edge_index"].numpy(), g.nodes[PA]["x"].shape[0])
+        g.nodes[LA]["lap_pe"] = laplacian_pe(g.edges[E_LL]["edge_index"].numpy(), g.nodes[LA]["x"].shape[0])
+    return g
+
+
+def laplacian_pe_batched(edge_index, batch, num_graphs, k=8):
+    """laplacian_pe for every graph of a collated batch on the tensors' own device: dense per-graph
+    normalised Laplacians padded to the largest graph, one batched symmetric eigensolve, same sign convention.
+    Padding rows get unit diagonal above every real eigenvalue (<= 2), so they sort last."""
+    dev = edge_index.device
+    n = batch.numel()
+    num = torch.zeros(num_graphs, dtype=torch.long, device=dev).index_add_(0, batch, torch.ones_like(batch))
+    mx = int(num.max())
+    start = num.cumsum(0) - num
+    local = torch.arange(n, device=dev) - start[batch]
+    a = torch.zeros(num_graphs, mx, mx, dtype=torch.float64, device=dev)
+    gb = batch[edge_index[0]]
+    a[gb, local[edge_index[0]], local[edge_index[1]]] = 1.0
+    dinv = a.sum(1).clamp(min=1).pow(-0.5)
+    lap = torch.eye(mx, dtype=torch.float64, device=dev).unsqueeze(0) - dinv.unsqueeze(2) * a * dinv.unsqueeze(1)
+    lap = 0.5 * (lap + lap.transpose(1, 2))
+    pad = torch.arange(mx, device=dev).unsqueeze(0) >= num.unsqueeze(1)          # [B, mx]
+    lap = lap.masked_fill(pad.unsqueeze(1) | pad.unsqueeze(2), 0.0) + torch.diag_embed(pad.double() * 3.0)
+    _, v = torch.linalg.eigh(lap)
+    v = v[:, :, 1:k + 1]
+    if v.shape[2] < k:
+        v = torch.cat([v, v.new_zeros(num_graphs, mx, k - v.shape[2])], 2)
+    idx = v.abs().argmax(dim=1, keepdim=True)
+    sign = torch.where(torch.gather(v, 1, idx) < 0, -1.0, 1.0)
+    v = (v * sign)
+    return v[batch, local].to(torch.float32)
