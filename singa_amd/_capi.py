@@ -52,6 +52,7 @@ EXPORTS = tuple(_SIGS)
 
 
 def bind(path):
+    import torch  # noqa: F401  - the HIP runtime bundled with PyTorch must be the one this library resolves against
     lib = C.CDLL(path)
     for name, (args, res) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol

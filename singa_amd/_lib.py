@@ -4,6 +4,7 @@ import ctypes
 import os
 
 import numpy as np
+import torch  # noqa: F401  - loaded before libsinga_hip.so so that both use the HIP runtime PyTorch ships
 
 from . import _capi, so3
 

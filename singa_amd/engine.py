@@ -13,12 +13,6 @@ from .graph import E_LL, E_LP, E_PL, E_PP, LA, PA
 from .model import EF_layers
 
 
-import os as _os
-
-_DEBUG = _os.environ.get("SINGA_DEBUG_SYNC") == "1"
-_SYNC_BEFORE_PREPARE = _os.environ.get("SINGA_SYNC_BEFORE_PREPARE", "1") == "1"
-
-
 def _copy_tree(dst, src):
     """copy_ every tensor of a nested dict/list structure; returns False on a shape mismatch."""
     if torch.is_tensor(dst):
@@ -110,12 +104,7 @@ class TrainStep:
         st = self.static
         EF_layers._edge_cache.clear()
         batch.extras.pop("prepared", None)
-        if _DEBUG or _SYNC_BEFORE_PREPARE:
-            torch.cuda.synchronize()
         prep = self.model.prepare(batch)
-        if _DEBUG:
-            torch.cuda.synchronize()
-            print("[engine] load: prepared", flush=True)
         sig = (batch[PA]["x"].shape[0], batch[LA]["x"].shape[0], prep["p"]["dense"].mx, prep["l"]["dense"].mx)
         if sig != self._sig:
             return False
@@ -152,10 +141,7 @@ class TrainStep:
     def step(self, batch):
         if not self.use_graph:
             return self.eager_step(batch)
-        import os
-        if self.static is not None and os.environ.get("SINGA_NO_RELOAD") == "1":
-            pass                                            # debug knob: replay on the bound batch without re-preparing
-        elif self.static is None or not self._load(batch):
+        if self.static is None or not self._load(batch):
             self._capture(batch)
             self._load(batch)
         self.g_fb.replay()

@@ -57,15 +57,8 @@ class SINGA(nn.Module):
         n_p, n_l = g[PA]["x"].shape[0], g[LA]["x"].shape[0]
         B = g.num_graphs
         knn = getattr(g, "extras", {}).get("knn", {})
-        import os
-        dbg = os.environ.get("SINGA_DEBUG_SYNC") == "1"
-        prep = {}
-        prep["p"] = self.model.encoder.prepare(g[PA]["pos"], g[PA]["batch"], B, knn.get(PA))
-        if dbg:
-            torch.cuda.synchronize(); print("[prepare] p done", flush=True)
-        prep["l"] = self.model.encoder2.prepare(g[LA]["pos"], g[LA]["batch"], B, knn.get(LA))
-        if dbg:
-            torch.cuda.synchronize(); print("[prepare] l done", flush=True)
+        prep = {"p": self.model.encoder.prepare(g[PA]["pos"], g[PA]["batch"], B, knn.get(PA)),
+                "l": self.model.encoder2.prepare(g[LA]["pos"], g[LA]["batch"], B, knn.get(LA))}
         prep.update({
                 "es": {"pp": edge_set(g[E_PP]["edge_index"], n_p, n_p), "ll": edge_set(g[E_LL]["edge_index"], n_l, n_l),
                        "lp": edge_set(g[E_LP]["edge_index"], n_l, n_p), "pl": edge_set(g[E_PL]["edge_index"], n_p, n_l)}})
