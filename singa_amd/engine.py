@@ -38,9 +38,12 @@ def _clone_tree(x):
 
 
 def _prep_tensors(prep):
-    return {"p": prep["p"]["dense"].tensors() + prep["p"]["edges"].tensors(),
-            "l": prep["l"]["dense"].tensors() + prep["l"]["edges"].tensors(),
-            "es": {k: v.tensors() for k, v in prep["es"].items()}}
+    out = {"p": prep["p"]["dense"].tensors() + prep["p"]["edges"].tensors(),
+           "l": prep["l"]["dense"].tensors() + prep["l"]["edges"].tensors(),
+           "es": {k: v.tensors() for k, v in prep["es"].items()}}
+    if "homo" in prep:
+        out["homo"] = [prep["homo"]["ei"]] + prep["homo"]["es"].tensors()
+    return out
 
 
 class TrainStep:
@@ -95,6 +98,8 @@ class TrainStep:
         n_p, n_l = st[PA]["x"].shape[0], st[LA]["x"].shape[0]
         for key, et in (("pp", E_PP), ("ll", E_LL), ("lp", E_LP), ("pl", E_PL)):
             EF_layers._edge_pinned[st[et]["edge_index"].data_ptr()] = prep["es"][key]
+        if "homo" in prep:
+            EF_layers._edge_pinned[prep["homo"]["ei"].data_ptr()] = prep["homo"]["es"]
         self.static, self.static_prep = st, prep
         self._sig = (n_p, n_l, prep["p"]["dense"].mx, prep["l"]["dense"].mx)
 

@@ -55,6 +55,8 @@ class EquivariantEmbedding(nn.Module):
         self.block_use_atom_edge_embedding = False
         # when True, hetero layers whose outputs the reference discards only apply their norm_1 side effect (Q4)
         self.skip_dead_hetero_layers = True
+        # Parts 1 and 2 (protein-protein and ligand-ligand, same blocks, disjoint node sets) as ONE pass over their union
+        self.fuse_homo_passes = True
 
         self.SO3_rotation = nn.ModuleList([SO3_Rotation(self.lmax_list[0], device=device)])
         self.sphere_embedding = nn.Embedding(self.max_num_elements, self.sphere_channels_all, device=device)
@@ -138,14 +140,56 @@ class EquivariantEmbedding(nn.Module):
         x.embedding = self.norm(x.embedding)
         return x
 
+    def make_homo(self, g):
+        """Disjoint union of the two homogeneous graphs (protein-protein and ligand-ligand bonds): Parts 1 and 2 of the
+        reference (EMB:226-370) run the SAME blocks with hetero=False on two node sets that never interact, so they are
+        one pass over [protein atoms ; ligand atoms] with the ligand edges offset by the protein count.  Halves the
+        number of launches of the homogeneous passes and folds the tiny ligand pass (2 k edges) into GEMMs that are
+        already large.  Part of `prepare` (no parameters involved)."""
+        from .EF_layers import edge_set
+        n_p = g[PA]["x"].shape[0]
+        n_l = g[LA]["x"].shape[0]
+        ei = torch.cat([g[E_PP]["edge_index"], g[E_LL]["edge_index"] + n_p], dim=1).contiguous()
+        return {"ei": ei, "n_p": n_p, "n_l": n_l, "es": edge_set(ei, n_p + n_l, n_p + n_l)}
+
+    def _homo_union_pass(self, g, homo):
+        n_p = homo["n_p"]
+        ei = homo["ei"]
+        z = torch.cat([g["atomicnum"][PA], g["atomicnum"][LA]])
+        pos = torch.cat([g[PA]["pos"], g[LA]["pos"]])
+        code = torch.cat([barcode(g[PA]["x"]), barcode(g[LA]["x"])])
+        ev = pos[ei[0]] - pos[ei[1]]
+        e_pp = g[E_PP]["edge_index"].shape[1]
+        rot = torch.cat([self._frames(g, "pp", ev[:e_pp]), self._frames(g, "ll", ev[e_pp:])], 0)
+        self.SO3_rotation[0].set_wigner(rot)
+        K = (self.lmax_list[0] + 1) ** 2
+        with torch.no_grad():                                  # Q1: long-typed store truncates and cuts autograd
+            init = (self.sphere_embedding.weight.index_select(0, z)
+                    + self.sphere_embedding_2.weight.index_select(0, code)).to(torch.long)
+        emb = torch.zeros(z.shape[0], K, self.sphere_channels, device=pos.device, dtype=torch.float32)
+        emb[:, self.offset_res, :] = init.to(torch.float32)
+        edge_distance = self._edge_scalars(ev.norm(dim=-1), z, z, ei)
+        edge_degree = self.edge_degree_embedding(z, edge_distance, ei, hetero=False)
+        x = SO3_Embedding(0, self.lmax_list, self.sphere_channels, torch.float32, self.device, emb + edge_degree.embedding)
+        for i in range(self.num_layers):
+            x = self.blocks[i](x=x, atomic_numbers=z, edge_distance=edge_distance, edge_index=ei, batch=len(z), hetero=False)
+        out = self.norm(x.embedding)
+        mk = lambda t: SO3_Embedding(0, self.lmax_list, self.sphere_channels, torch.float32, self.device, t)
+        return mk(out[:n_p]), mk(out[n_p:])
+
     def forward(self, g, batch: Optional[int] = None, gen_mode: bool = False) -> Dict:
         x_dict = {}
         if getattr(g, "num_graphs", 1) > 1:
             batch = 64
-        x_dict[PA] = self._homo_pass(g, PA, E_PP, "pp")                         # Part 1, EMB:226-295
         if gen_mode:
+            x_dict[PA] = self._homo_pass(g, PA, E_PP, "pp")                     # Part 1 only, EMB:297-298
             return x_dict
-        x_dict[LA] = self._homo_pass(g, LA, E_LL, "ll")                         # Part 2, EMB:305-370
+        if self.fuse_homo_passes:
+            prep = getattr(g, "extras", {}).get("prepared") or {}
+            x_dict[PA], x_dict[LA] = self._homo_union_pass(g, prep.get("homo") or self.make_homo(g))
+        else:
+            x_dict[PA] = self._homo_pass(g, PA, E_PP, "pp")                     # Part 1, EMB:226-295
+            x_dict[LA] = self._homo_pass(g, LA, E_LL, "ll")                     # Part 2, EMB:305-370
         atomic_numbers = {PA: g["atomicnum"][PA], LA: g["atomicnum"][LA]}
         pos_p, pos_l = g[PA]["pos"], g[LA]["pos"]
         # Part 3: ligand -> protein (EMB:379-428)

@@ -62,5 +62,7 @@ class SINGA(nn.Module):
         prep.update({
                 "es": {"pp": edge_set(g[E_PP]["edge_index"], n_p, n_p), "ll": edge_set(g[E_LL]["edge_index"], n_l, n_l),
                        "lp": edge_set(g[E_LP]["edge_index"], n_l, n_p), "pl": edge_set(g[E_PL]["edge_index"], n_p, n_l)}})
+        if self.embedding.fuse_homo_passes:
+            prep["homo"] = self.embedding.make_homo(g)
         g.extras["prepared"] = prep
         return prep
