@@ -169,9 +169,9 @@ def main():
     reducer = dp.GradAllReducer(model)
     reducer.check_same_init()
     use_graph = not args.eager
-    opt = torch.optim.Adam(model.parameters(), lr=cfg.train.optimizer.lr,
-                           betas=(cfg.train.optimizer.beta1, cfg.train.optimizer.beta2), weight_decay=0,
-                           capturable=use_graph)
+    from singa_amd.optim import Adam
+    opt = Adam(model.parameters(), lr=cfg.train.optimizer.lr,
+               betas=(cfg.train.optimizer.beta1, cfg.train.optimizer.beta2))
     batch = G.synthetic_batch(n_graphs, first_id=rank * n_graphs, **kw).to(dev)   # this rank's shard, resident in HBM
     from singa_amd.engine import TrainStep
     engine = TrainStep(model, opt, reducer if world > 1 else None, use_graph=use_graph,

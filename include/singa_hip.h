@@ -152,6 +152,14 @@ int singa_so3_rmsnorm_bwd(const float* x, const float* weight, const float* gy, 
 long long singa_colsum_work(long long M, int n);
 int singa_colsum(const float* x, long long ld, long long M, int n, float* work, float* out, void* stream);
 
+/* Adam step of train.py:127 (torch.optim.Adam: lr, betas, eps; no weight decay) for ALL parameter tensors in one launch.
+ * p/g/m/v: DEVICE arrays of device pointers (one per tensor); sizes[t] = elements of tensor t; (chunk_tensor, chunk_off)
+ * [nchunks]: the flattened work list, `chunk` elements each; step (float, number of steps taken) and lr live in device
+ * memory so that the launch can be replayed from a HIP graph. */
+int singa_adam_step(float* const* p, const float* const* g, float* const* m, float* const* v, const long long* sizes,
+                    const int32_t* chunk_tensor, const long long* chunk_off, int nchunks, int chunk, float* step,
+                    const float* lr, float beta1, float beta2, float eps, void* stream);
+
 /* Measurement helpers (bench.py): exact per-dispatch timing of the scatter-TP forward kernel with start/stop events
  * attached to the dispatch (hipExtLaunchKernelGGL) on the caller's stream, and a copy kernel with the segment kernels'
  * access shape for calibrating the PMC byte counters. */

@@ -745,6 +745,42 @@ __global__ void colsum_pass_kernel(const float* __restrict__ x, long long ld, lo
     out[slab * n + j] = (a0 + a1) + (a2 + a3);
 }
 
+
+// ------------------------------------------------------------------------------------------------ fused Adam
+// One launch updates every parameter tensor (torch.optim.Adam semantics, no weight decay / amsgrad): block b handles
+// chunk b of the flattened (tensor, offset) table.  The step count and the learning rate live in device memory so the
+// launch can be replayed from a HIP graph; a second one-thread kernel advances the step.
+__global__ void __launch_bounds__(256) adam_kernel(float* const* __restrict__ p, const float* const* __restrict__ g,
+                                                   float* const* __restrict__ m, float* const* __restrict__ v,
+                                                   const long long* __restrict__ sizes, const int* __restrict__ chunk_tensor,
+                                                   const long long* __restrict__ chunk_off, int chunk,
+                                                   const float* __restrict__ step, const float* __restrict__ lr, float b1,
+                                                   float b2, float eps) {
+    const int t = chunk_tensor[blockIdx.x];
+    const long long off = chunk_off[blockIdx.x];
+    const long long n = sizes[t];
+    const float k = step[0] + 1.0f;
+    const float bc1 = 1.0f - powf(b1, k), bc2s = sqrtf(1.0f - powf(b2, k));
+    const float step_size = lr[0] / bc1;
+    float* pp = p[t];
+    const float* gg = g[t];
+    float* mm = m[t];
+    float* vv = v[t];
+    const long long end = off + chunk < n ? off + chunk : n;
+    for (long long i = off + threadIdx.x; i < end; i += blockDim.x) {
+        const float gi = gg[i];
+        const float mi = mm[i] + (gi - mm[i]) * (1.0f - b1);
+        const float vi = b2 * vv[i] + (1.0f - b2) * gi * gi;
+        mm[i] = mi;
+        vv[i] = vi;
+        pp[i] -= step_size * (mi / (sqrtf(vi) / bc2s + eps));
+    }
+}
+
+__global__ void adam_advance_kernel(float* step) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1.0f;
+}
+
 // ------------------------------------------------------------------------------------------------ k8: S2 activation
 // thread = (edge-or-node e, channel c).  x rows in registers; loop over the G grid points with the two grid-matrix
 // rows as wave-uniform scalars: u = to[g,:].x, s = SiLU(u), y += from[g,:] * s.  Row 0 of the result is SiLU(gate).
@@ -1520,6 +1556,18 @@ int singa_s2act_sep_bwd(const singa_seg_t* x, int nseg, const float* gate, int64
                                                         (hipStream_t)stream, s, gate, (long long)ldg, P, Q, A, g_out, gx,
                                                         g_gate, EC));
     return check_launch("s2act_sep_bwd");
+}
+
+int singa_adam_step(float* const* p, const float* const* g, float* const* m, float* const* v, const long long* sizes,
+                    const int32_t* chunk_tensor, const long long* chunk_off, int nchunks, int chunk, float* step,
+                    const float* lr, float beta1, float beta2, float eps, void* stream) {
+    if (!p || !g || !m || !v || !sizes || !chunk_tensor || !chunk_off || !step || !lr)
+        return fail(SINGA_E_NULL, "adam_step: null pointer");
+    if (nchunks <= 0) return SINGA_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, sizes, chunk_tensor,
+                       chunk_off, chunk, step, lr, beta1, beta2, eps);
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step);
+    return check_launch("adam_step");
 }
 
 long long singa_colsum_work(long long M, int n) {

@@ -72,6 +72,8 @@ class TrainStep:
         if self.max_grad_norm != float("inf"):
             coef = (self.max_grad_norm / (self.grad_norm + 1e-6)).clamp(max=1.0)
             torch._foreach_mul_(grads, coef)
+        if hasattr(self.opt, "sync_hyper") and not torch.cuda.is_current_stream_capturing():
+            self.opt.sync_hyper()
         self.opt.step()
 
     def eager_step(self, batch):
@@ -138,6 +140,9 @@ class TrainStep:
         # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
         with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
             self.static_loss = self._fwd_bwd(st)
+        if hasattr(self.opt, "_grad_table"):
+            self.opt._grad_table()        # the .grad tensors now live in the graph pool: publish their addresses (a
+                                          # host->device copy, so it has to happen outside the capture)
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             self._update()
@@ -152,5 +157,7 @@ class TrainStep:
         self.g_fb.replay()
         if self.reducer is not None:
             self.reducer.reduce()
+        if hasattr(self.opt, "sync_hyper"):
+            self.opt.sync_hyper()                            # scheduler-updated learning rate -> device scalar
         self.g_opt.replay()
         return self.static_loss

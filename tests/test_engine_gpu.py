@@ -9,7 +9,7 @@ from tests.helpers import NAMES, golden, product_batch, state_from_spec
 pytestmark = pytest.mark.gpu
 
 
-def _run(use_graph, steps=3):
+def _run(use_graph, steps=3, torch_adam=False):
     from singa_amd.config import load_config
     from singa_amd.engine import TrainStep
     from singa_amd.model.GAN import SINGA
@@ -17,7 +17,9 @@ def _run(use_graph, steps=3):
     model = SINGA(load_config(lmax=L), device="cuda")
     model.load_state_dict(state_from_spec(f"singa_L{L}"), strict=False)
     model.eval()                                            # dropout off so that both runs see the same numbers
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.99, 0.999), capturable=use_graph)
+    from singa_amd.optim import Adam
+    opt = (torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.99, 0.999)) if torch_adam
+           else Adam(model.parameters(), lr=1e-4, betas=(0.99, 0.999)))
     eng = TrainStep(model, opt, None, use_graph=use_graph)
     z = golden(f"singa_L{L}_B3.npz")
     batch = product_batch(NAMES, z)
@@ -64,3 +66,11 @@ def test_graph_replay_gradients_match_eager_per_parameter():
         if not (err < 2e-3) and float((p.grad - q.grad).abs().max()) > 1e-9:
             bad.append((n, err, float(p.grad.abs().max()), float(q.grad.abs().max())))
     assert not bad, bad[:8]
+
+
+def test_fused_adam_matches_torch_adam():
+    """The single-launch Adam follows torch.optim.Adam (eager, same init, same batch) step for step."""
+    ours, _ = _run(False, steps=5)
+    ref, _ = _run(False, steps=5, torch_adam=True)
+    for a, b in zip(ours, ref):
+        assert abs(a - b) < 1e-4 * abs(b), (ours, ref)

@@ -108,8 +108,9 @@ def main():
 
     model = SINGA(cfg, device=dev)
     o = cfg.train.optimizer
-    opt = torch.optim.Adam(model.parameters(), lr=o.lr, betas=(o.beta1, o.beta2), weight_decay=o.weight_decay,
-                           capturable=args.graph)
+    from singa_amd.optim import Adam
+    assert o.type == "adam" and o.weight_decay == 0
+    opt = Adam(model.parameters(), lr=o.lr, betas=(o.beta1, o.beta2))
     s = cfg.train.scheduler
     sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, factor=s.factor, patience=s.patience, min_lr=s.min_lr)
     start_it = 1
