@@ -49,6 +49,28 @@ def k10_algorithmic_bytes(E, N, L, CH=112, heads=7):
     return E * (lay.KR * CH * 4 + heads * 4 + lay.WSZ * 4) + N * lay.K * CH * 4 + (N + 1) * 4
 
 
+def pmc_traffic(L, n_dst):
+    """HBM bytes per launch of the scatter-TP forward kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/<round>/pmc_{FETCH,WRITE}_SIZE.csv, produced by tools/prof.sh): FETCH_SIZE x 2 (gfx950 correction
+    for this access shape, confirmed by the calibration copy in the same pass) + WRITE_SIZE, KiB -> bytes.  None if no
+    profile matches the launch geometry (grid = dst nodes x 128)."""
+    import csv
+    import glob
+    best = None
+    for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "*"))):
+        vals = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            f = os.path.join(d, f"pmc_{c}.csv")
+            if not os.path.exists(f):
+                continue
+            for r in csv.DictReader(open(f)):
+                if f"rotate_back_scatter_kernel<{L}, 2, false" in r["kernel"] and int(r["grid"]) == n_dst * 128:
+                    vals[c] = float(r["avg_value"])
+        if len(vals) == 2:
+            best = (int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), os.path.relpath(d, ROOT))
+    return best
+
+
 def host_cores():
     """CPU threads this process may really use: min(affinity, cgroup quota), capped at the one-GPU box share."""
     n = os.cpu_count() or 1
@@ -236,9 +258,13 @@ def main():
         E, N = sel[0][1], sel[0][2]
         by = k10_algorithmic_bytes(E, N, L)
         ach = by / (ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "rotate_back_scatter_kernel (k10 fwd, protein-protein edges)",
+        tr = pmc_traffic(L, N)
+        roof = {"bound": "hbm", "kernel": "rotate_back_scatter_kernel (k10 fwd on the bonded edges: protein-protein U "
+                                          "ligand-ligand pass)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "bytes_per_launch": by, "avg_launch_us": round(ms * 1e3, 2), "launches": len(sel),
+                "traffic": tr[0] if tr else None,
+                "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, {tr[1]}" if tr else None),
+                "bytes_per_launch": by, "avg_launch_us": round(ms * 1e3, 2), "launches": len(sel),
                 "edges": E, "dst_nodes": N, "timing": f"start/stop events attached to each dispatch, {args.roofline_steps} instrumented eager steps "
                           "right after the timed region (same process, same batch)"}
 
