@@ -89,6 +89,16 @@ int singa_rotate_back_scatter_bwd(const float* g_out, const singa_seg_t* msg, co
                                   int Nd, int CH, int heads, int lmax, int mmax, int m0_only, float out_scale,
                                   void* stream);
 
+/* k9a - attention logits (EF:1175-1178): x0_alpha.view(E, heads, A) -> LayerNorm(A) -> SmoothLeakyReLU(0.2) -> dot with
+ * alpha_dot[heads, A].  h0: the m = 0 SO(2)-conv output whose first heads*A columns are the alpha inputs (row stride ld).
+ * backward: g_x[E, heads*A]; part[singa_alpha_logits_nslots(E), (2+heads)*A] = per-slot partials of (d ln_w, d ln_b,
+ * d alpha_dot) which the caller reduces with singa_colsum.  heads = 7, A = 32. */
+int singa_alpha_logits_nslots(int E);
+int singa_alpha_logits_fwd(const float* h0, long long ld, const float* ln_w, const float* ln_b, const float* dot, float* logits,
+                           int E, int heads, int A, float eps, void* stream);
+int singa_alpha_logits_bwd(const float* h0, long long ld, const float* ln_w, const float* ln_b, const float* dot,
+                           const float* g_logits, float* g_x, float* part, int E, int heads, int A, float eps, void* stream);
+
 /* k9 (softmax part) — torch_geometric.utils.softmax / torch_scatter.scatter_softmax over destination segments
  * (EF:1180; CP:66): out = exp(x - segmax) / (segsum + eps).  x, out: [E, H]. */
 int singa_segment_softmax_fwd(const float* x, const int32_t* row_ptr, float* out, int N, int H, float eps,

@@ -25,6 +25,9 @@ _SIGS = {
     "singa_rotate_back_scatter_fwd": ([C.POINTER(Seg), I32, P, P, P, P, I32, I32, I32, I32, I32, I32, F32, P], I32),
     "singa_rotate_back_scatter_bwd": ([P, C.POINTER(Seg), C.POINTER(Seg), I32, P, P, P, P, I32, I32, I32, I32, I32,
                                        I32, F32, P], I32),
+    "singa_alpha_logits_nslots": ([I32], I32),
+    "singa_alpha_logits_fwd": ([P, C.c_longlong, P, P, P, P, I32, I32, I32, F32, P], I32),
+    "singa_alpha_logits_bwd": ([P, C.c_longlong, P, P, P, P, P, P, I32, I32, I32, F32, P], I32),
     "singa_segment_softmax_fwd": ([P, P, P, I32, I32, F32, P], I32),
     "singa_segment_softmax_bwd": ([P, P, P, P, I32, I32, P], I32),
     "singa_segment_wsum_fwd": ([P, P, P, P, I32, I32, I32, P], I32),

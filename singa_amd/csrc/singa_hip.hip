@@ -443,6 +443,88 @@ __global__ void __launch_bounds__(128) rotate_back_scatter_bwd_kernel(const floa
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ k9a: attention logits
+// x0_alpha.view(E, heads, 32) -> LayerNorm(32) -> SmoothLeakyReLU(0.2) -> dot with alpha_dot[heads, 32]  (EF:1175-1178).
+// 32 lanes = the 32 alpha channels of one (edge, head); a wavefront works on two edges at a time and loops over the heads.
+// Statistics and the dot product are 5-step butterflies inside each 32-lane half.
+__device__ __forceinline__ float half_sum(float v) {
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float smooth_leaky(float a) { return 0.6f * a + 0.4f * a * (2.0f / (1.0f + __expf(-a)) - 1.0f); }
+__device__ __forceinline__ float smooth_leaky_grad(float a) {
+    const float sg = 1.0f / (1.0f + __expf(-a));
+    return 0.2f + 0.8f * sg + 0.8f * a * sg * (1.0f - sg);
+}
+
+template <int HEADS>
+__global__ void __launch_bounds__(256) alpha_logits_fwd_kernel(const float* __restrict__ h0, long long ld,
+                                                               const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                               const float* __restrict__ dot, float* __restrict__ logits, int E,
+                                                               float eps) {
+    const int k = threadIdx.x & 31;
+    const long long slot = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const long long nslots = ((long long)gridDim.x * blockDim.x) >> 5;
+    const float w = ln_w[k], b = ln_b[k];
+    for (long long e = slot; e < E; e += nslots) {
+        const float* x = h0 + e * ld + k;
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) {
+            const float v = x[h * 32];
+            const float mu = half_sum(v) * (1.0f / 32.0f);
+            const float d = v - mu;
+            const float rstd = rsqrtf(half_sum(d * d) * (1.0f / 32.0f) + eps);
+            const float a = d * rstd * w + b;
+            const float lg = half_sum(smooth_leaky(a) * dot[h * 32 + k]);
+            if (k == 0) logits[e * HEADS + h] = lg;
+        }
+    }
+}
+
+// Backward (recompute): g_x [E, HEADS*32] and per-slot partial parameter gradients part[slot][(2 + HEADS) * 32] =
+// [d ln_w | d ln_b | d alpha_dot[h, :]], reduced afterwards by singa_colsum.
+template <int HEADS>
+__global__ void __launch_bounds__(256) alpha_logits_bwd_kernel(const float* __restrict__ h0, long long ld,
+                                                               const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                               const float* __restrict__ dot, const float* __restrict__ g_logits,
+                                                               float* __restrict__ g_x, float* __restrict__ part, int E,
+                                                               float eps) {
+    const int k = threadIdx.x & 31;
+    const long long slot = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const long long nslots = ((long long)gridDim.x * blockDim.x) >> 5;
+    const float w = ln_w[k], b = ln_b[k];
+    float gw = 0.f, gb = 0.f, gd[HEADS];
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) gd[h] = 0.f;
+    for (long long e = slot; e < E; e += nslots) {
+        const float* x = h0 + e * ld + k;
+#pragma unroll
+        for (int h = 0; h < HEADS; ++h) {
+            const float v = x[h * 32];
+            const float mu = half_sum(v) * (1.0f / 32.0f);
+            const float d = v - mu;
+            const float rstd = rsqrtf(half_sum(d * d) * (1.0f / 32.0f) + eps);
+            const float xh = d * rstd;
+            const float a = xh * w + b;
+            const float gl = g_logits[e * HEADS + h];
+            gd[h] = fmaf(gl, smooth_leaky(a), gd[h]);
+            const float da = gl * dot[h * 32 + k] * smooth_leaky_grad(a);
+            gw = fmaf(da, xh, gw);
+            gb += da;
+            const float dxh = da * w;
+            const float m1 = half_sum(dxh) * (1.0f / 32.0f);
+            const float m2 = half_sum(dxh * xh) * (1.0f / 32.0f);
+            g_x[e * (HEADS * 32) + h * 32 + k] = rstd * (dxh - m1 - xh * m2);
+        }
+    }
+    float* pp = part + slot * ((2 + HEADS) * 32) + k;
+    pp[0] = gw;
+    pp[32] = gb;
+#pragma unroll
+    for (int h = 0; h < HEADS; ++h) pp[(2 + h) * 32] = gd[h];
+}
+
 // ------------------------------------------------------------------------------------------------ k9: segment softmax
 __global__ void segment_softmax_fwd_kernel(const float* __restrict__ x, const int* __restrict__ row_ptr,
                                            float* __restrict__ y, int N, int H, float eps) {
@@ -1568,6 +1650,34 @@ int singa_adam_step(float* const* p, const float* const* g, float* const* m, flo
                        chunk_off, chunk, step, lr, beta1, beta2, eps);
     hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step);
     return check_launch("adam_step");
+}
+
+int singa_alpha_logits_nslots(int E) {
+    long long slots = ((long long)E + 0) < 1 ? 1 : E;
+    long long cap = 256 * 8 * 8;   // 2048 blocks of 256 threads = 16384 slots
+    return (int)(slots < cap ? ((slots + 7) / 8) * 8 : cap);
+}
+
+int singa_alpha_logits_fwd(const float* h0, long long ld, const float* ln_w, const float* ln_b, const float* dot, float* logits,
+                           int E, int heads, int A, float eps, void* stream) {
+    if (!h0 || !ln_w || !ln_b || !dot || !logits) return fail(SINGA_E_NULL, "alpha_logits_fwd: null pointer");
+    if (heads != 7 || A != 32) return fail(SINGA_E_SHAPE, "alpha_logits: built for 7 heads x 32 alpha channels");
+    if (E <= 0) return SINGA_OK;
+    int blocks = singa_alpha_logits_nslots(E) / 8;
+    hipLaunchKernelGGL((alpha_logits_fwd_kernel<7>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, h0, ld, ln_w, ln_b, dot,
+                       logits, E, eps);
+    return check_launch("alpha_logits_fwd");
+}
+
+int singa_alpha_logits_bwd(const float* h0, long long ld, const float* ln_w, const float* ln_b, const float* dot,
+                           const float* g_logits, float* g_x, float* part, int E, int heads, int A, float eps, void* stream) {
+    if (!h0 || !ln_w || !ln_b || !dot || !g_logits || !g_x || !part) return fail(SINGA_E_NULL, "alpha_logits_bwd: null pointer");
+    if (heads != 7 || A != 32) return fail(SINGA_E_SHAPE, "alpha_logits: built for 7 heads x 32 alpha channels");
+    if (E <= 0) return SINGA_OK;
+    int blocks = singa_alpha_logits_nslots(E) / 8;
+    hipLaunchKernelGGL((alpha_logits_bwd_kernel<7>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, h0, ld, ln_w, ln_b, dot,
+                       g_logits, g_x, part, E, eps);
+    return check_launch("alpha_logits_bwd");
 }
 
 long long singa_colsum_work(long long M, int n) {

@@ -359,13 +359,13 @@ class SO2EquivariantGraphAttention(nn.Module):
         X = ops.gather_rotate(x_src, x_dst, rad, wr, es, L, M)
         # first SO(2) convolution (three GEMMs); h0 = [alpha inputs | gate | m=0 rows]
         h0, h1, h2 = self.so2_conv_1(X)
-        # attention weights: LayerNorm -> smooth leaky ReLU -> dot -> softmax over each destination's edges.  Computed
-        # right after conv1 (they only need h0) so that nothing streams between the conv2 GEMMs and the scatter kernel
-        # that consumes their output: the per-m value tensors are then still largely resident in the Infinity Cache.
-        a = self.alpha_act(self.alpha_norm(h0[:, : heads * A].reshape(-1, heads, A)))
-        logits = torch.bmm(a.transpose(0, 1), self.alpha_dot.unsqueeze(-1)).squeeze(-1).t()   # [E, heads]
+        # k9a + k8 in one autograd node: attention logits (LayerNorm -> smooth leaky ReLU -> dot, EF:1175-1178) and the
+        # separable S2 activation of the gated message (EF:1156-1160).  The softmax over each destination's edges follows
+        # at once (it only needs the logits), so nothing streams between the conv2 GEMMs and the scatter kernel that
+        # consumes their output: the per-m value tensors are then still largely resident in the Infinity Cache.
+        logits, act = ops.edge_head(h0, h1, h2, self.alpha_norm.weight, self.alpha_norm.bias, self.alpha_dot, heads, A, H,
+                                    L, M, self.alpha_norm.eps)
         alpha = ops.segment_softmax(logits, es.row_ptr, 1e-16)
-        act = ops.s2act_edge(h0, h1, h2, heads * A, heads * A + H, H, L, M)
         y0, y1, y2 = self.so2_conv_2(act)
         # k10: alpha * value, rotate back, sum over incoming edges
         agg = ops.rotate_back_scatter(y0, y1, y2, alpha, wr, es, heads, L, M)

@@ -331,6 +331,69 @@ def s2act_edge(h0, h1, h2, gate_off, x_off, C, L, M=2):
     return _S2ActEdge.apply(h0, h1, h2, gate_off, x_off, C, L, M)
 
 
+class _EdgeHead(torch.autograd.Function):
+    """Everything that consumes the first SO(2) convolution (EF:1148-1178): attention logits (LayerNorm(A) ->
+    SmoothLeakyReLU -> dot with alpha_dot, k9a) from the first heads*A columns of h0, and the separable S2 activation
+    (k8) of [gate | m=0 rows] + h1 + h2.  One autograd node, so the gradient of h0 is assembled once (no zero-filled
+    full-width buffers, no add of two partial gradients)."""
+
+    @staticmethod
+    def forward(ctx, h0, h1, h2, ln_w, ln_b, dot, heads, A, C, L, M, eps):
+        h0, h1, h2 = h0.contiguous(), h1.contiguous(), h2.contiguous()
+        ln_w, ln_b, dot = ln_w.contiguous(), ln_b.contiguous(), dot.contiguous()
+        _dev(h0, h1, h2, ln_w, ln_b, dot)
+        lay = so3.layout(L, M)
+        lib = _lib.lib()
+        E = h0.shape[0]
+        gate_off, x_off = heads * A, heads * A + C
+        logits = torch.empty(E, heads, device=h0.device, dtype=torch.float32)
+        _chk(lib.singa_alpha_logits_fwd(_p(h0), h0.stride(0), _p(ln_w), _p(ln_b), _p(dot), _p(logits), E, heads, A, eps,
+                                        _stream()), "singa_alpha_logits_fwd")
+        P, Q, Az = _grid_factors(L, M, True, h0.device)
+        act = torch.empty(E, lay.KR * C, device=h0.device, dtype=torch.float32)
+        seg, n = _capi.segs([(h0.data_ptr() + 4 * x_off, h0.stride(0), lay.seg_rows[0]),
+                             (h1.data_ptr(), h1.stride(0), lay.seg_rows[1]),
+                             (h2.data_ptr(), h2.stride(0), lay.seg_rows[2])])
+        _chk(lib.singa_s2act_sep_fwd(seg, n, ctypes.c_void_p(h0.data_ptr() + 4 * gate_off), h0.stride(0), _p(P), _p(Q),
+                                     _p(Az), _p(act), E, C, L, _stream()), "singa_s2act_sep_fwd")
+        ctx.save_for_backward(h0, h1, h2, ln_w, ln_b, dot)
+        ctx.cfg = (heads, A, C, L, M, eps)
+        return logits, act
+
+    @staticmethod
+    def backward(ctx, g_logits, g_act):
+        h0, h1, h2, ln_w, ln_b, dot = ctx.saved_tensors
+        heads, A, C, L, M, eps = ctx.cfg
+        lay = so3.layout(L, M)
+        lib = _lib.lib()
+        E = h0.shape[0]
+        gate_off, x_off = heads * A, heads * A + C
+        g_logits, g_act = g_logits.contiguous(), g_act.contiguous()
+        g_alpha_in = torch.empty(E, heads * A, device=h0.device, dtype=torch.float32)
+        nslots = lib.singa_alpha_logits_nslots(E)
+        part = torch.empty(nslots, (2 + heads) * A, device=h0.device, dtype=torch.float32)
+        _chk(lib.singa_alpha_logits_bwd(_p(h0), h0.stride(0), _p(ln_w), _p(ln_b), _p(dot), _p(g_logits), _p(g_alpha_in),
+                                        _p(part), E, heads, A, eps, _stream()), "singa_alpha_logits_bwd")
+        pg = colsum(part)
+        P, Q, Az = _grid_factors(L, M, True, h0.device)
+        gx = torch.empty(E, lay.KR * C, device=h0.device, dtype=torch.float32)
+        gg = torch.empty(E, C, device=h0.device, dtype=torch.float32)
+        seg, n = _capi.segs([(h0.data_ptr() + 4 * x_off, h0.stride(0), lay.seg_rows[0]),
+                             (h1.data_ptr(), h1.stride(0), lay.seg_rows[1]),
+                             (h2.data_ptr(), h2.stride(0), lay.seg_rows[2])])
+        _chk(lib.singa_s2act_sep_bwd(seg, n, ctypes.c_void_p(h0.data_ptr() + 4 * gate_off), h0.stride(0), _p(P), _p(Q),
+                                     _p(Az), _p(g_act), _p(gx), _p(gg), E, C, L, _stream()), "singa_s2act_sep_bwd")
+        n0, n1 = lay.seg_rows[0] * C, lay.seg_rows[1] * C
+        g_h0 = torch.cat([g_alpha_in, gg, gx[:, :n0]], 1)
+        return (g_h0, gx[:, n0:n0 + n1], gx[:, n0 + n1:], pg[:A], pg[A:2 * A], pg[2 * A:].view(heads, A),
+                None, None, None, None, None, None)
+
+
+def edge_head(h0, h1, h2, ln_w, ln_b, alpha_dot, heads, A, C, L, M=2, eps=1e-5):
+    """-> (attention logits [E, heads], activated m-primary tensor [E, KR*C])"""
+    return _EdgeHead.apply(h0, h1, h2, ln_w, ln_b, alpha_dot, heads, A, C, L, M, eps)
+
+
 class _S2ActNode(torch.autograd.Function):
     """SeparableS2Activation on the FFN grid [L][L] for an l-primary node tensor [N,K,C] and gate [N,C]."""
 

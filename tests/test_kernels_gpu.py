@@ -318,3 +318,33 @@ def test_skinny_linear_split_k():
     out = ops.skinny_linear(x, w, b)
     out.backward(g)
     assert rel(out, ref) < 1e-6 and rel(x.grad, gx) < 1e-6 and rel(w.grad, gw) < 1e-5 and rel(b.grad, gb) < 1e-5
+
+
+def test_edge_head_logits_and_activation():
+    """k9a (LayerNorm -> SmoothLeakyReLU -> dot) + k8 in one node vs the torch formulation, incl. parameter grads."""
+    ops = _ops()
+    rs = np.random.RandomState(11)
+    L, heads, A, C = 2, 7, 32, 128
+    lay = so3.layout(L, 2)
+    E = 3000
+    h0 = torch.tensor(rs.randn(E, heads * A + C + lay.seg_rows[0] * C), dtype=torch.float32, requires_grad=True)
+    h1 = torch.tensor(rs.randn(E, lay.seg_rows[1] * C), dtype=torch.float32, requires_grad=True)
+    h2 = torch.tensor(rs.randn(E, lay.seg_rows[2] * C), dtype=torch.float32, requires_grad=True)
+    w = torch.tensor(1 + 0.2 * rs.randn(A), dtype=torch.float32, requires_grad=True)
+    b = torch.tensor(0.2 * rs.randn(A), dtype=torch.float32, requires_grad=True)
+    dot = torch.tensor(rs.randn(heads, A) * 0.2, dtype=torch.float32, requires_grad=True)
+    a = torch.nn.functional.layer_norm(h0[:, :heads * A].reshape(-1, heads, A), (A,), w, b, 1e-5)
+    a = 0.6 * a + 0.4 * a * (2 * torch.sigmoid(a) - 1)
+    ref_logits = (a * dot).sum(-1)
+    to_m = torch.as_tensor(lay.to_m)
+    xm = torch.cat([h0[:, heads * A + C:].view(E, -1, C), h1.view(E, -1, C), h2.view(E, -1, C)], 1)
+    ref_act = O.sep_s2_act(h0[:, heads * A:heads * A + C], xm[:, torch.argsort(to_m)], L, 2)[:, to_m].reshape(E, -1)
+    g1 = torch.tensor(rs.randn(E, heads), dtype=torch.float32)
+    g2 = torch.tensor(rs.randn(*ref_act.shape), dtype=torch.float32)
+    ((ref_logits * g1).sum() + (ref_act * g2).sum()).backward()
+    dev = [t.detach().to(DEV).requires_grad_(True) for t in (h0, h1, h2, w, b, dot)]
+    logits, act = ops.edge_head(dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], heads, A, C, L)
+    assert rel(logits, ref_logits) < 2e-5 and rel(act, ref_act) < 2e-5
+    ((logits * g1.to(DEV)).sum() + (act * g2.to(DEV)).sum()).backward()
+    for d, r in zip(dev, (h0, h1, h2, w, b, dot)):
+        assert rel(d.grad, r.grad) < 1e-4
