@@ -233,6 +233,8 @@ def main():
 
     # ---- instrumented pass for the roofline: the same step run eagerly with start/stop events attached to every
     # scatter-TP forward dispatch (graph replays cannot carry per-dispatch events); not part of `value`.
+    if use_graph and args.roofline_steps > 0:
+        engine.release()              # give the graph pool back before the eager instrumented steps
     ops.profile_start()
     for _ in range(args.roofline_steps):
         engine.eager_step(batch)

@@ -135,6 +135,7 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.opt.zero_grad(set_to_none=True)
+        torch.cuda.empty_cache()      # hand the warm-up's cached blocks back: the graph pool needs the same amount again
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # warm-up ran on the side stream
         self.g_fb = torch.cuda.CUDAGraph()
         # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
@@ -147,6 +148,14 @@ class TrainStep:
         with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             self._update()
         self.captures += 1
+
+    def release(self):
+        """Drop the captured graphs and their private memory pool (e.g. before running large eager steps)."""
+        self.g_fb = self.g_opt = self.static = self.static_prep = self.static_loss = None
+        EF_layers._edge_pinned.clear()
+        self.opt.zero_grad(set_to_none=True)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
 
     def step(self, batch):
         if not self.use_graph:
