@@ -230,6 +230,16 @@ def main():
         elapsed = float(t)
     final_loss = float(loss.detach())
     log(f"timed {args.steps} steps in {elapsed:.3f} s ({engine.captures} graph capture(s) so far)")
+    # how much of a step is per-batch graph preparation (edge sorting, kNN graphs, dense maps) - measured
+    # separately, it is already inside every timed step
+    torch.cuda.synchronize()
+    t_p = time.perf_counter()
+    for _ in range(3):
+        EF_layers._edge_cache.clear()
+        batch.extras.pop("prepared", None)
+        model.prepare(batch)
+    torch.cuda.synchronize()
+    prepare_ms = (time.perf_counter() - t_p) / 3 * 1e3
 
     # ---- instrumented pass for the roofline: the same step run eagerly with start/stop events attached to every
     # scatter-TP forward dispatch (graph replays cannot carry per-dispatch events); not part of `value`.
@@ -280,7 +290,7 @@ def main():
                           "nodes_per_graph": kw["n_protein"] + kw["n_ligand"],
                           "edges_per_graph": kw["e_pp"] + kw["e_ll"] + 2 * kw["e_x"],
                           "parallelism": f"dp{world}", "step": "prepare+zero_grad+fwd+CE+bwd+allreduce+clip+Adam",
-                          "launch": "hipGraph replay" if use_graph else "eager",
+                          "launch": "hipGraph replay" if use_graph else "eager", "prepare_ms_of_step": round(prepare_ms, 2),
                           "grad_allreduce_bytes": reducer.payload_bytes},
                "final_loss": round(final_loss, 5), "roofline": roof}
         if not args.no_cpu_baseline and world == 1:

@@ -25,6 +25,14 @@ class Config(dict):
     def __setattr__(self, k, v):
         self[k] = v
 
+    def to_dict(self):
+        """Plain nested dicts/lists (what a checkpoint stores, so that `torch.load(weights_only=True)` accepts it)."""
+        def plain(v):
+            if isinstance(v, dict):
+                return {k: plain(x) for k, x in v.items()}
+            return [plain(x) for x in v] if isinstance(v, (list, tuple)) else v
+        return plain(self)
+
     def __deepcopy__(self, memo):
         return Config({k: copy.deepcopy(v, memo) for k, v in self.items()})
 

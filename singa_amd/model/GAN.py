@@ -54,8 +54,12 @@ class SINGA(nn.Module):
         forward/backward on a prepared batch only enqueue work (and can be captured in a HIP graph)."""
         from .EF_layers import edge_set
         from ..graph import E_LL, E_LP, E_PL, E_PP
+        from ..graph import laplacian_pe_batched
         n_p, n_l = g[PA]["x"].shape[0], g[LA]["x"].shape[0]
         B = g.num_graphs
+        for nt, et in ((PA, E_PP), (LA, E_LL)):
+            if "lap_pe" not in g[nt]:      # SURVEY §8f n2: deterministic per-graph Laplacian PE, batched eigensolve on the GPU
+                g[nt]["lap_pe"] = laplacian_pe_batched(g[et]["edge_index"], g[nt]["batch"], B, self.config.model.encoder.lap_dim)
         knn = getattr(g, "extras", {}).get("knn", {})
         prep = {"p": self.model.encoder.prepare(g[PA]["pos"], g[PA]["batch"], B, knn.get(PA)),
                 "l": self.model.encoder2.prepare(g[LA]["pos"], g[LA]["batch"], B, knn.get(LA))}

@@ -130,3 +130,17 @@ def test_own_knn_graph_matches_oracle_edges():
     # and the attributes agree edge by edge
     ia, ib = torch.sort(e.row.cpu() * N + e.col.cpu()).indices, torch.sort(row * N + col).indices
     assert float((e.attr.cpu()[ia] - ea[ib]).abs().max()) < 1e-5
+
+
+def test_prepare_fills_laplacian_pe_on_gpu():
+    """SINGA.prepare computes the per-graph Laplacian PE on the device when the batch does not carry one."""
+    from singa_amd.config import load_config
+    from singa_amd.graph import LA, PA
+    from singa_amd.model.GAN import SINGA
+    model = SINGA(load_config(lmax=2), device=DEV)
+    g = product_batch(NAMES, None, with_lap=False)
+    assert "lap_pe" not in g[PA]
+    model.prepare(g)
+    assert g[PA]["lap_pe"].shape == (g[PA]["x"].shape[0], 8) and g[LA]["lap_pe"].is_cuda
+    logits = model(g)
+    assert torch.isfinite(logits).all()

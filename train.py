@@ -156,7 +156,7 @@ def main():
             sched.step(val)
             log(f"[Validate] Iter {it} | Loss {val:.6f}")
             if rank == 0:
-                torch.save({"config": dict(cfg), "model": model.state_dict(), "optimizer": opt.state_dict(),
+                torch.save({"config": cfg.to_dict(), "model": model.state_dict(), "optimizer": opt.state_dict(),
                             "scheduler": sched.state_dict(), "iteration": it}, os.path.join(ckpt_dir, f"{it}.pt"))
             if early.step(val):
                 log("Early stopping")
