@@ -378,11 +378,9 @@ def knn_edges(pos, knn_ei, stop, n_g):
     return torch.cat([row, loop]), torch.cat([col, loop]), torch.cat([-ea, deg], 0)
 
 
-def transformer_forward(sd, pre, feat_p, pos_p, batch_p, lap_p, knn_p, feat_l, pos_l, batch_l, lap_l, knn_l,
-                        tokens, prop, pad_id=110):
-    """Transformer.forward (Encoder, Encoder2, Decoder, projection). CP:289-343, 385-464."""
-    B = tokens.shape[0]
-    e1, e2, dc = pre + "encoder", pre + "encoder2", pre + "decoder"
+def encoder1_forward(sd, pre, feat_p, pos_p, batch_p, lap_p, knn_p, B):
+    """Encoder.forward: dense encoder output, padding mask [B,1,S] and the per-layer dense attention outputs. CP:289-313."""
+    e1 = pre + "encoder"
     n_g = sd[e1 + ".layers.0.enc_self_attn.weight_k_net.0.weight"].shape[1]
     h = lin(sd, e1 + ".protein_atom_emb", feat_p) + lin(sd, e1 + ".laplacian_emb", lap_p)
     row, col, ea = knn_edges(pos_p, knn_p, 15.0, n_g)
@@ -393,23 +391,15 @@ def transformer_forward(sd, pre, feat_p, pos_p, batch_p, lap_p, knn_p, feat_l, p
         h = pos_ffn(sd, f"{e1}.layers.{j}.pos_ffn", msa)
         msa_dense.append(to_dense(msa, batch_p, B)[0])
     enc1, m1, _ = to_dense(h, batch_p, B)
-    pad1 = ~m1.unsqueeze(1)
-    h = lin(sd, e2 + ".aa_emb", feat_l) + lin(sd, e2 + ".laplacian_emb", lap_l)
-    row, col, ea = knn_edges(pos_l, knn_l, 25.0, n_g)
-    for j in range(n_layers):
-        p = f"{e2}.layers.{j}"
-        msa = graph_mha(sd, p + ".enc_self_attn", h, row, col, ea)
-        if j in (2, 5):                                                       # CP:262
-            kv = lin(sd, p + ".proj", msa_dense[j])
-            qd, _, idx = to_dense(msa, batch_l, B)
-            cr = dense_mha(sd, p + ".cross_attn", qd, kv, kv, pad1)
-            msa = layer_norm(sd, p + ".layer_norm", msa + cr.reshape(-1, cr.shape[-1])[idx])
-        h = pos_ffn(sd, p + ".pos_ffn", msa)
-    enc2, m2, _ = to_dense(h, batch_l, B)
-    enc = torch.cat([enc1, enc2], 1)
-    pad = torch.cat([pad1, ~m2.unsqueeze(1)], 2)
-    # decoder, CP:385-423 (dropout off: eval mode)
-    Tn = tokens.shape[1]
+    return enc1, ~m1.unsqueeze(1), msa_dense
+
+
+def decoder_forward(sd, pre, tokens, prop, enc, pad, pad_id=110):
+    """Decoder.forward + projection on the whole prefix `tokens` [B,T]: logits [B, T+1, V] with the property token at
+    position 0.  CP:385-423, 462 (dropout off: eval mode)."""
+    dc = pre + "decoder"
+    B, Tn = tokens.shape
+    n_layers = 1 + max(int(k[len(dc) + 8:].split(".")[0]) for k in sd if k.startswith(dc + ".layers."))
     x = sd[dc + ".mol_emb.weight"][tokens] + sd[dc + ".pos_emb.pe"][:Tn, 0].unsqueeze(0) + sd[dc + ".type_emb.weight"][1]
     ptok = lin(sd, dc + ".prop_nn", prop.unsqueeze(1)) + sd[dc + ".type_emb.weight"][0]
     x = torch.cat([ptok, x], 1)
@@ -422,7 +412,31 @@ def transformer_forward(sd, pre, feat_p, pos_p, batch_p, lap_p, knn_p, feat_l, p
         x = dense_mha(sd, p + ".dec_self_attn", x, x, x, self_mask)
         x = dense_mha(sd, p + ".dec_enc_attn", x, enc, enc, cross_mask)
         x = pos_ffn(sd, p + ".pos_ffn", x)
-    logits = F.linear(x, sd[pre + "projection.weight"])[:, 1:]
+    return F.linear(x, sd[pre + "projection.weight"])
+
+
+def transformer_forward(sd, pre, feat_p, pos_p, batch_p, lap_p, knn_p, feat_l, pos_l, batch_l, lap_l, knn_l,
+                        tokens, prop, pad_id=110):
+    """Transformer.forward (Encoder, Encoder2, Decoder, projection). CP:289-343, 385-464."""
+    B = tokens.shape[0]
+    e1, e2 = pre + "encoder", pre + "encoder2"
+    n_g = sd[e1 + ".layers.0.enc_self_attn.weight_k_net.0.weight"].shape[1]
+    enc1, pad1, msa_dense = encoder1_forward(sd, pre, feat_p, pos_p, batch_p, lap_p, knn_p, B)
+    h = lin(sd, e2 + ".aa_emb", feat_l) + lin(sd, e2 + ".laplacian_emb", lap_l)
+    row, col, ea = knn_edges(pos_l, knn_l, 25.0, n_g)
+    for j in range(len(msa_dense)):
+        p = f"{e2}.layers.{j}"
+        msa = graph_mha(sd, p + ".enc_self_attn", h, row, col, ea)
+        if j in (2, 5):                                                       # CP:262
+            kv = lin(sd, p + ".proj", msa_dense[j])
+            qd, _, idx = to_dense(msa, batch_l, B)
+            cr = dense_mha(sd, p + ".cross_attn", qd, kv, kv, pad1)
+            msa = layer_norm(sd, p + ".layer_norm", msa + cr.reshape(-1, cr.shape[-1])[idx])
+        h = pos_ffn(sd, p + ".pos_ffn", msa)
+    enc2, m2, _ = to_dense(h, batch_l, B)
+    enc = torch.cat([enc1, enc2], 1)
+    pad = torch.cat([pad1, ~m2.unsqueeze(1)], 2)
+    logits = decoder_forward(sd, pre, tokens, prop, enc, pad, pad_id)[:, 1:]
     return logits.reshape(-1, logits.shape[-1])
 
 

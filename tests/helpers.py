@@ -38,3 +38,23 @@ def product_batch(names, z=None, device="cuda", with_lap=False):
             b.extras["knn"] = {G.PA: torch.tensor(z["knn_p"]), G.LA: torch.tensor(z["knn_l"])}
             b.nodes[G.PA]["lap_pe"], b.nodes[G.LA]["lap_pe"] = torch.tensor(z["lap_p"]), torch.tensor(z["lap_l"])
     return b.to(device)
+
+
+BEAM_CASES = ["b1_k20", "b2_k4", "b2_k6_eos", "b2_k5_flat"]
+SMI_VOC = None
+
+
+def smi_voc():
+    global SMI_VOC
+    if SMI_VOC is None:
+        import yaml
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        SMI_VOC = list(yaml.safe_load(open(os.path.join(root, "config", "train.yml")))["model"]["decoder"]["smiVoc"])
+    return SMI_VOC
+
+
+def apply_beam_gains(weight, z):
+    """The two documented rescalings of the vocabulary projection a beam golden was made with (oracle/make_golden_beam.py)."""
+    with torch.no_grad():
+        weight.mul_(float(z["proj_gain"]))
+        weight[smi_voc().index("$")] *= float(z["eos_gain"])

@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import singa_oracle as O
-from tests.helpers import NAMES, golden, rel_err, state_from_spec
+from tests.helpers import BEAM_CASES, NAMES, apply_beam_gains, golden, rel_err, smi_voc, state_from_spec
 
 TOL = 2e-5  # fp32 op-order noise between the reference's einsum/bmm chains and the restatement
 
@@ -96,3 +96,28 @@ def test_singa_step(L):
         elif abs(float(gr.norm()) - ref) > 2e-3 * ref + 1e-7:
             bad.append((str(n), float(gr.norm()), float(ref)))
     assert not bad, bad[:10]
+
+
+@pytest.mark.parametrize("case", BEAM_CASES)
+def test_beam_search(case):
+    """Restated beam search vs the reference's own (BeamSearch.py:38-175) on reference-embedded proteins: decoded
+    tokens, the complete final beam state, every stored hypothesis score, and the first-step log-probabilities."""
+    from oracle import beam_oracle as BO
+    z = golden(f"beam_{case}.npz")
+    sd = state_from_spec("singa_L2")
+    apply_beam_gains(sd["model.projection.weight"], z)
+    tr = {}
+    t = lambda k, dt=torch.float32: torch.as_tensor(z[k]).to(dt)
+    B = len(z["names"])
+    with torch.no_grad():
+        out = BO.beam_search(sd, smi_voc(), int(z["num_beams"]), B, int(z["max_length"]), int(z["topk"]), t("feat"), t("pos"),
+                             t("batch", torch.long), t("lap"), t("knn", torch.long), t("prop"), trace=tr)
+    assert out.shape == z["decoded"].shape and np.array_equal(out.numpy(), z["decoded"])
+    assert np.array_equal(tr["last_beams"].numpy(), z["last_beams"])
+    assert rel_err(tr["first_logp"], z["first_logp"]) < TOL
+    for b, h in enumerate(tr["hyps"]):
+        got = np.array(sorted(s for s, _ in h.items))
+        want = z["hyp_scores"][b][: len(got)]
+        assert len(got) == int((z["hyp_lens"][b] >= 0).sum())
+        assert np.allclose(got, want, rtol=1e-5, atol=1e-6)
+        assert sorted(len(x) for _, x in h.items) == [int(v) for v in z["hyp_lens"][b] if v >= 0]
