@@ -60,16 +60,22 @@ class KVDecoder:
 
     rows = proteins x beams, protein-major (row r belongs to protein r // beams, as BS:105).  Causality makes the result
     for the newest position identical to the reference's full re-run on the prefix; the padding mask of the self-
-    attention (CP:414) never fires for a live beam because a live prefix contains no '^'."""
+    attention (CP:414) never fires for a live beam because a live prefix contains no '^'.
 
-    def __init__(self, decoder, enc_outputs, enc_pad_mask, beams, max_positions):
-        self.dec, self.beams = decoder, beams
+    Every tensor has a fixed shape: the caches span `max_positions`, the current position is a device scalar, and
+    attention masks the positions that are not written yet.  A whole search step (`step`: re-rank the caches, embed
+    the chosen tokens, all decoder layers, vocabulary projection, log-softmax, candidate top-k) is therefore one HIP
+    graph, captured once per search and replayed per token."""
+
+    def __init__(self, decoder, projection, enc_outputs, enc_pad_mask, beams, max_positions, vocab_size):
+        self.dec, self.proj, self.beams, self.V = decoder, projection, beams, vocab_size
         B, S, _ = enc_outputs.shape
         a0 = decoder.layers[0].dec_self_attn
         self.heads = a0.num_heads
         self.dk, self.dv = a0.key_channels // self.heads, a0.hidden_channels // self.heads
-        self.B, self.R = B, B * beams
-        dev = enc_outputs.device
+        self.B, self.R, self.P = B, B * beams, max_positions
+        self.num = 1 if decoder.num_props else 0
+        dev = self.dev = enc_outputs.device
         self.cross_k, self.cross_v = [], []
         for layer in decoder.layers:
             c = layer.dec_enc_attn
@@ -79,17 +85,26 @@ class KVDecoder:
         n = len(decoder.layers)
         self.k = torch.zeros(n, self.R, self.heads, max_positions, self.dk, device=dev)
         self.v = torch.zeros(n, self.R, self.heads, max_positions, self.dv, device=dev)
-        self.t = 0
+        self.pos = torch.zeros(1, dtype=torch.long, device=dev)            # next position to be written
+        self.slots = torch.arange(max_positions, device=dev)
+        # the step's inputs (scores, tokens, source rows - one row each, as doubles: exact for fp32 and for indices) and
+        # outputs (2*beams ranked candidate scores and flat beam*vocab indices per protein), fixed addresses
+        self.step_in = torch.zeros(3, self.R, dtype=torch.float64, device=dev)
+        self.step_out = torch.zeros(2, B, 2 * beams, dtype=torch.float64, device=dev)
+        self.logp = torch.zeros(self.R, vocab_size, device=dev)
+        self.graph = None
+
+    def reset(self):
+        self.pos.zero_()
 
     def follow(self, src_rows):
         """Row r continues the prefix that row src_rows[r] held (BS:134-136)."""
-        t = self.t
-        self.k[:, :, :, :t] = self.k[:, :, :, :t].index_select(1, src_rows)
-        self.v[:, :, :, :t] = self.v[:, :, :, :t].index_select(1, src_rows)
+        self.k.copy_(self.k.index_select(1, src_rows))
+        self.v.copy_(self.v.index_select(1, src_rows))
 
-    def token_input(self, tokens, position):
+    def token_input(self, tokens):
         d = self.dec
-        x = d.mol_emb.weight.index_select(0, tokens) + d.pos_emb.pe[position, 0]
+        x = d.mol_emb.weight.index_select(0, tokens) + d.pos_emb.pe[:, 0].index_select(0, self.pos - self.num)
         return x + d.type_emb.weight[1] if d.num_props else x
 
     def prop_input(self, prop):
@@ -97,23 +112,67 @@ class KVDecoder:
         return d.prop_nn(prop) + d.type_emb.weight[0]
 
     def advance(self, x):
-        """x [rows, hidden]: decoder input at the next position -> decoder output at that position."""
-        R, B, H, t = self.R, self.B, self.heads, self.t
+        """x [rows, hidden]: decoder input at position `pos` -> decoder output at that position; pos += 1."""
+        R, B, H = self.R, self.B, self.heads
+        unwritten = (self.slots > self.pos).view(1, 1, 1, self.P)
         for l, layer in enumerate(self.dec.layers):
             a = layer.dec_self_attn
-            self.k[l, :, :, t] = a.W_K(x).view(R, H, self.dk)
-            self.v[l, :, :, t] = a.W_V(x).view(R, H, self.dv)
+            self.k[l].index_copy_(2, self.pos, a.W_K(x).view(R, H, 1, self.dk))
+            self.v[l].index_copy_(2, self.pos, a.W_V(x).view(R, H, 1, self.dv))
             q = a.W_Q(x).view(R, H, 1, self.dk)
-            s = torch.matmul(q, self.k[l, :, :, :t + 1].transpose(-1, -2)) / math.sqrt(self.dk)
-            ctx = torch.matmul(torch.softmax(s, dim=-1), self.v[l, :, :, :t + 1]).reshape(R, H * self.dv)
+            s = (torch.matmul(q, self.k[l].transpose(-1, -2)) / math.sqrt(self.dk)).masked_fill(unwritten, float("-inf"))
+            ctx = torch.matmul(torch.softmax(s, dim=-1), self.v[l]).reshape(R, H * self.dv)
             y = a.layer_norm(a.linear(ctx) + x)
             c = layer.dec_enc_attn
             q = c.W_Q(y).view(B, self.beams, H, self.dk).transpose(1, 2)                   # beams = query rows
             s = (torch.matmul(q, self.cross_k[l]) / math.sqrt(self.dk)).masked_fill(self.cross_mask, -1e9)
             ctx = torch.matmul(torch.softmax(s, dim=-1), self.cross_v[l]).transpose(1, 2).reshape(R, H * self.dv)
             x = layer.pos_ffn(c.layer_norm(c.linear(ctx) + y))
-        self.t = t + 1
+        self.pos += 1
         return x
+
+    def _step_body(self):
+        scores, tokens, src_rows = self.step_in[0].float(), self.step_in[1].long(), self.step_in[2].long()
+        self.follow(src_rows)
+        out = self.advance(self.token_input(tokens))
+        self.logp.copy_(F.log_softmax(self.proj(out), dim=-1))                               # BS:83-85
+        cand = (self.logp + scores[:, None]).view(self.B, self.beams * self.V)               # BS:86-89
+        cand_score, cand_flat = torch.topk(cand, 2 * self.beams, dim=1, largest=True, sorted=True)
+        self.step_out[0].copy_(cand_score)
+        self.step_out[1].copy_(cand_flat)
+
+    def capture(self):
+        """Capture `_step_body` into a HIP graph.  The warm-up and the capture itself write cache slots and advance `pos`;
+        the caller resets `pos` afterwards, and slots >= pos are never read."""
+        self.step_in.zero_()
+        self.step_in[2] = torch.arange(self.R, device=self.dev)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self.reset()
+                self.pos += self.num
+                self._step_body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.reset()
+        self.pos += self.num
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            self._step_body()
+        self.reset()
+
+    def step(self, scores, tokens, src_rows):
+        """One search step for host arrays (scores f32, tokens, source rows) -> (candidate scores f32 [B, 2*beams],
+        flat candidate indices int64 [B, 2*beams]) on the host.  One H2D copy, one graph replay, one D2H copy."""
+        host = np.stack([scores.astype(np.float64), tokens.astype(np.float64), src_rows.astype(np.float64)])
+        self.step_in.copy_(torch.from_numpy(host))
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._step_body()
+        out = self.step_out.cpu().numpy()
+        return out[0].astype(np.float32), out[1].astype(np.int64)
 
 
 def _select(cand_score, cand_flat, prefixes, hyps, done, num_beams, vocab_size, eos, pad, cur_len):
@@ -152,10 +211,12 @@ def _select(cand_score, cand_flat, prefixes, hyps, done, num_beams, vocab_size, 
 
 
 @torch.no_grad()
-def beam_search(model, smiVoc, num_beams, batch_size, max_length, topk, example, prop=None, device="cuda", trace=None):
+def beam_search(model, smiVoc, num_beams, batch_size, max_length, topk, example, prop=None, device="cuda", trace=None,
+                graph=True):
     """BS:38-175.  `model`: SINGA (uses model.model.encoder / decoder / projection); `example`: attribute bag with
     protein_element_batch, protein_atom_feature, protein_pos, protein_atom_laplacian (gen.py:176-181) and, optionally,
     protein_knn (a precomputed [2,E] kNN list; otherwise drawn on the GPU); `prop` [batch_size*num_beams, num_props].
+    `graph=False` launches the step's kernels one by one instead of replaying the captured HIP graph (same numbers).
     Returns the decoded int64 token matrix [batch_size*topk, T] on `device`."""
     tf = model.model
     vocab_size = len(smiVoc)
@@ -168,39 +229,35 @@ def beam_search(model, smiVoc, num_beams, batch_size, max_length, topk, example,
                                               getattr(example, "protein_knn", None))
     rows = batch_size * num_beams
     num = 1 if tf.decoder.num_props else 0
-    kv = KVDecoder(tf.decoder, enc_outputs, enc_pad_mask, num_beams, max_length + num)
+    kv = KVDecoder(tf.decoder, tf.projection, enc_outputs, enc_pad_mask, num_beams, max_length + num, vocab_size)
+    if graph:
+        kv.capture()
     if num:
         kv.advance(kv.prop_input(prop.to(dev).float()))                # position 0 is the property prompt, CP:404-412
 
-    beam_scores = torch.zeros(batch_size, num_beams, device=dev)
+    beam_scores = np.zeros((batch_size, num_beams), dtype=np.float32)
     beam_scores[:, 1:] = -1e9                                          # all beams start equal: only beam 0 counts at step 1
-    beam_scores = beam_scores.view(-1)
-    prefixes = np.full((rows, 1), sos, dtype=np.int64)                 # host copy of input_ids: bookkeeping only
-    tokens = torch.full((rows,), sos, dtype=torch.long, device=dev)
+    beam_scores = beam_scores.reshape(-1)
+    prefixes = np.full((rows, 1), sos, dtype=np.int64)                 # input_ids live on the host: bookkeeping only
+    tokens, src = prefixes[:, 0].copy(), np.arange(rows, dtype=np.int64)
     done = [False] * batch_size
     hyps = [BeamHypotheses(num_beams, max_length, length_penalty=0.7) for _ in range(batch_size)]
     cur_len = 1
     while cur_len < max_length:
-        out = kv.advance(kv.token_input(tokens, cur_len - 1))
-        logp = F.log_softmax(tf.projection(out), dim=-1)
+        cand_score, cand_flat = kv.step(beam_scores, tokens, src)
         if trace is not None and "first_logp" not in trace:
-            trace["first_logp"] = logp.clone()
-        cand = (logp + beam_scores[:, None]).view(batch_size, num_beams * vocab_size)
-        cand_score, cand_flat = torch.topk(cand, 2 * num_beams, dim=1, largest=True, sorted=True)
-        packed = torch.stack([cand_score.double(), cand_flat.double()]).cpu().numpy()      # the step's one D2H copy
-        sc, tk, src = _select(packed[0].astype(np.float32), packed[1].astype(np.int64), prefixes, hyps, done,
-                              num_beams, vocab_size, eos, pad, cur_len)
+            trace["first_logp"] = kv.logp.clone()
+        beam_scores_next, tokens_next, src_next = _select(cand_score, cand_flat, prefixes, hyps, done, num_beams,
+                                                          vocab_size, eos, pad, cur_len)
         if all(done):
             break
-        step = torch.from_numpy(np.stack([sc.astype(np.float64), tk.astype(np.float64), src.astype(np.float64)])).to(dev)
-        beam_scores, tokens, src_rows = step[0].float(), step[1].long(), step[2].long()
-        kv.follow(src_rows)
-        prefixes = np.concatenate([prefixes[src], tk[:, None]], axis=1)
+        beam_scores, tokens, src = beam_scores_next, tokens_next, src_next
+        prefixes = np.concatenate([prefixes[src], tokens[:, None]], axis=1)
         cur_len += 1
     if trace is not None:
         trace["last_beams"], trace["hyps"] = prefixes.copy(), hyps
 
-    final = beam_scores.cpu().numpy()
+    final = beam_scores
     for b in range(batch_size):
         if not done[b]:                                                # BS:141-149
             for k in range(num_beams):

@@ -24,8 +24,9 @@ def build_model(z=None):
     return model, sd, Config
 
 
+@pytest.mark.parametrize("graph", [True, False], ids=["hipgraph", "eager"])
 @pytest.mark.parametrize("case", BEAM_CASES)
-def test_beam_search_matches_reference(case):
+def test_beam_search_matches_reference(case, graph):
     from singa_amd.model.BeamSearch import beam_search
     z = golden(f"beam_{case}.npz")
     model, _, Config = build_model(z)
@@ -35,7 +36,7 @@ def test_beam_search_matches_reference(case):
     ex.protein_atom_laplacian, ex.protein_knn = t("lap"), t("knn", torch.long)
     tr = {}
     out = beam_search(model, smi_voc(), int(z["num_beams"]), len(z["names"]), int(z["max_length"]), int(z["topk"]), ex,
-                      t("prop"), device=DEV, trace=tr)
+                      t("prop"), device=DEV, trace=tr, graph=graph)
     assert rel_err(tr["first_logp"].cpu(), z["first_logp"]) < 1e-4
     assert np.array_equal(tr["last_beams"], z["last_beams"])
     assert out.shape == z["decoded"].shape and np.array_equal(out.cpu().numpy(), z["decoded"])
