@@ -184,7 +184,7 @@ class MultiHeadAttention(nn.Module):
         scale = 1.0 / math.sqrt(h_keys.size(-1))
         W_k = self._edge_mlp(self.weight_k_net, edges.attr)                      # [E, 32]
         W_v = self._edge_mlp(self.weight_v_net, edges.attr)                      # [E, 64]
-        qp = torch.matmul(h_queries, self.weight_k_lin.weight)                   # (q W)[n,h,:]
+        qp = ops.linear(h_queries, self.weight_k_lin.weight.t())                 # (q W)[n,h,:]
         cterm = ops.rowdot_bias(h_queries, self.weight_k_lin.bias) * scale
         qk_ij = ops.edge_logits(qp, W_k, h_keys, cterm, edges, scale)
         alpha = ops.segment_softmax(qk_ij, edges.row_ptr, 0.0)

@@ -573,21 +573,27 @@ def bias_add(x, b):
 
 import os as _os
 
-_SPLITK_MIN_ROWS = int(_os.environ.get("SINGA_SPLITK_MIN", "16384"))
+_SPLITK_MIN_ROWS = int(_os.environ.get("SINGA_SPLITK_MIN", "8192"))
 
 
-def _splitk_tn(a, b, chunk=8192):
+def _splitk_tn(a, b):
     """a^T @ b for tall-skinny a [M,p], b [M,q] (M >> p,q): batched split-K so that the library GEMM has enough
-    workgroups (a single [p,M]x[M,q] GEMM launches p*q/tile workgroups only)."""
+    workgroups (a single [p,M]x[M,q] GEMM launches p*q/tile workgroups only).  The number of splits grows as the
+    output shrinks (about 512 workgroups in total, at most 64 splits, at least 256 rows each); rows are divided evenly,
+    so the remainder product has fewer rows than there are splits."""
     M, p = a.shape
     q = b.shape[1]
-    S = M // chunk
-    if M < _SPLITK_MIN_ROWS or S < 2:
+    if M <= _SPLITK_MIN_ROWS:
         return _mm(a.t(), b)
+    tiles = -(-p // 32) * -(-q // 32)
+    S = min(64, max(M // 8192, -(-512 // tiles)), M // 256)
+    if S < 2:
+        return _mm(a.t(), b)
+    chunk = M // S
     Mc = S * chunk
     out = colsum(torch.bmm(a[:Mc].view(S, chunk, p).transpose(1, 2), b[:Mc].view(S, chunk, q)))
     if Mc < M:
-        out = out + a[Mc:].t() @ b[Mc:]
+        out = out + _mm(a[Mc:].t(), b[Mc:])
     return out
 
 
@@ -598,7 +604,9 @@ class _blas:
     hipBLASLt.  The switch is host-side state only; under HIP-graph replay the chosen kernels are baked in."""
 
     def __init__(self, m, n, k):
-        self.use_rocblas = _ROCBLAS_SMALL and k <= 2048 and m <= 32768 and n <= 4096
+        # second clause (tools/lab/tn_probe.py): weight-gradient products a^T b with a few thousand rows and a small
+        # output, e.g. 256x6400x256: 43 us in hipBLASLt (64 workgroups), 22 us in rocBLAS; 64x5938x64: 48 vs 18 us
+        self.use_rocblas = _ROCBLAS_SMALL and ((k <= 2048 and m <= 32768 and n <= 4096) or (k <= 8192 and m * n <= 80000))
 
     def __enter__(self):
         if self.use_rocblas:

@@ -10,7 +10,8 @@ from singa_amd.model.GAN import SINGA
 wl = dict(G.WORKLOADS["cfg2_b32_l2"]); n = wl.pop("n_graphs"); L = wl.pop("lmax")
 cfg = load_config(lmax=L); torch.manual_seed(0)
 model = SINGA(cfg, device="cuda").train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-4, capturable=True)
+from singa_amd.optim import Adam
+opt = Adam(model.parameters(), lr=1e-4)
 eng = TrainStep(model, opt, None, use_graph=False)
 batch = G.synthetic_batch(n, **wl).to("cuda")
 for _ in range(3): eng.step(batch)
@@ -26,3 +27,6 @@ print("top by GPU time"); [print(f"{c:5d} calls {t:8.3f} ms  {k:28s} {s}") for c
 agg = collections.Counter(); tt = collections.Counter()
 for c, t, k, s in rows: agg[k] += c; tt[k] += t
 print("by op"); [print(f"{agg[k]:6d} calls {tt[k]:8.3f} ms {k}") for k, _ in tt.most_common(25)]
+print("all GEMM shapes")
+g = [(t, c, k, s) for c, t, k, s in rows if k in ("aten::mm", "aten::bmm", "aten::addmm")]
+for t, c, k, s in sorted(g, reverse=True): print(f"{c:5d} calls {t:8.3f} ms {t / c * 1e3:8.1f} us/call {k:12s} {s}")
