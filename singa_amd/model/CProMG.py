@@ -304,9 +304,11 @@ class EncoderLayer2(nn.Module):
         self.layer_norm = LayerNorm(config.hidden_channels, device=device)
         self.pos_ffn = PoswiseFeedForwardNet(config.hidden_channels, device=device)
 
-    def forward(self, node_attr, edges, idx, atom_msa_outputs, atom_mask, dm):
+    def forward(self, node_attr, edges, idx, atom_msa_outputs, atom_mask, dm, before_cross=None):
         msa_outputs = self.enc_self_attn(node_attr, edges)
         if idx == 2 or idx == 5:                                                   # CP:262
+            if before_cross is not None:
+                before_cross(idx)
             kv = self.proj(atom_msa_outputs[idx])
             cross = self.cross_attn(dm.dense(msa_outputs), kv, kv, atom_mask)
             msa_outputs = self.layer_norm(msa_outputs + cross.reshape(-1, cross.size(-1)).index_select(0, dm.idx))
@@ -331,15 +333,20 @@ class Encoder(nn.Module):
             knn = knn_graph(pos, self.config.knn, batch, batch_size, dm)
         return {"dense": dm, "edges": KnnEdges(pos, knn, self.distance_expansion)}
 
-    def forward(self, protein_atom_feature, pos, batch, atom_laplacian, batch_size=None, knn=None, prep=None):
+    def forward(self, protein_atom_feature, pos, batch, atom_laplacian, batch_size=None, knn=None, prep=None,
+                layer_done=None):
+        """`layer_done(idx, dense_msa)`, if given, is called right after layer idx produced its attention output (the
+        ligand encoder, running on a second stream, waits on these points - see Transformer.forward)."""
         if prep is None:
             prep = self.prepare(pos, batch, int(batch.max()) + 1 if batch_size is None else batch_size, knn)
         dm, edges = prep["dense"], prep["edges"]
         node_attr = self.protein_atom_emb(protein_atom_feature) + self.laplacian_emb(atom_laplacian)
         msa_outputs1 = []
-        for layer in self.layers:
+        for idx, layer in enumerate(self.layers):
             msa_outputs, node_attr = layer(node_attr, edges)
             msa_outputs1.append(dm.dense(msa_outputs))
+            if layer_done is not None:
+                layer_done(idx, msa_outputs1[-1])
         return dm.dense(node_attr), dm.pad_mask, msa_outputs1
 
 
@@ -361,13 +368,13 @@ class Encoder2(nn.Module):
         return {"dense": dm, "edges": KnnEdges(aa_pos, knn, self.distance_expansion)}
 
     def forward(self, aa_feature, aa_pos, aa_batch, aa_laplacian, atom_mask, atom_msa_outputs, batch_size=None, knn=None,
-                prep=None):
+                prep=None, before_cross=None):
         if prep is None:
             prep = self.prepare(aa_pos, aa_batch, int(aa_batch.max()) + 1 if batch_size is None else batch_size, knn)
         dm, edges = prep["dense"], prep["edges"]
         node_attr = self.aa_emb(aa_feature) + self.laplacian_emb(aa_laplacian)
         for idx, layer in enumerate(self.layers):
-            node_attr = layer(node_attr, edges, idx, atom_msa_outputs, atom_mask, dm)
+            node_attr = layer(node_attr, edges, idx, atom_msa_outputs, atom_mask, dm, before_cross)
         return dm.dense(node_attr), dm.pad_mask
 
 
@@ -430,14 +437,57 @@ class Transformer(nn.Module):
         self.decoder = Decoder(config.decoder, self.num_props, device=device)
         self.projection = Linear(config.hidden_channels, len(config.decoder.smiVoc), bias=False, device=device)
 
+    overlap_encoders = True
+
+    def _encoders_two_streams(self, node_attr, pos, batch, atom_laplacian, aa_node_attr, aa_pos, aa_batch, aa_laplacian,
+                              B, knn, aa_knn, prep):
+        """The ligand encoder (a few hundred launches on <= 10^3 nodes: latency-bound) runs on a second HIP stream
+        beside the protein encoder; it only needs the protein attention outputs of layers 2 and 5 (CP:262), which it
+        waits for through events.  Autograd replays the same split in the backward pass, and a HIP-graph capture records
+        the two streams as parallel branches.  Same arithmetic, same order within each encoder."""
+        cur = torch.cuda.current_stream()
+        if getattr(self, "_aux_stream", None) is None:
+            self._aux_stream = torch.cuda.Stream()
+        aux = self._aux_stream
+        if prep.get("p") is None:
+            prep = dict(prep, p=self.encoder.prepare(pos, batch, B, knn))
+        if prep.get("l") is None:
+            prep = dict(prep, l=self.encoder2.prepare(aa_pos, aa_batch, B, aa_knn))
+        start = torch.cuda.Event()
+        start.record(cur)
+        ready = {}
+
+        def layer_done(idx, dense_msa):
+            if idx in (2, 5):
+                dense_msa.record_stream(aux)
+                ready[idx] = torch.cuda.Event()
+                ready[idx].record(cur)
+
+        enc_outputs1, enc_pad_mask1, msa_outputs = self.encoder(node_attr, pos, batch, atom_laplacian, B, knn, prep["p"],
+                                                                layer_done)
+        for t in (aa_node_attr, aa_laplacian):
+            t.record_stream(aux)
+        with torch.cuda.stream(aux):
+            aux.wait_event(start)
+            enc_outputs2, enc_pad_mask2 = self.encoder2(aa_node_attr, aa_pos, aa_batch, aa_laplacian, enc_pad_mask1,
+                                                        msa_outputs, B, aa_knn, prep["l"],
+                                                        lambda idx: aux.wait_event(ready[idx]))
+        cur.wait_stream(aux)
+        enc_outputs2.record_stream(cur)
+        return enc_outputs1, enc_pad_mask1, enc_outputs2, enc_pad_mask2
+
     def forward(self, node_attr, pos, batch, atom_laplacian, smiles_index, tgt_len, aa_node_attr, aa_pos, aa_batch,
                 aa_laplacian, prop=None, knn=None, aa_knn=None, prep=None):
         B = smiles_index.shape[0]
         prep = prep or {}
-        enc_outputs1, enc_pad_mask1, msa_outputs = self.encoder(node_attr, pos, batch, atom_laplacian, B, knn,
-                                                                prep.get("p"))
-        enc_outputs2, enc_pad_mask2 = self.encoder2(aa_node_attr, aa_pos, aa_batch, aa_laplacian, enc_pad_mask1,
-                                                    msa_outputs, B, aa_knn, prep.get("l"))
+        if not (self.overlap_encoders and node_attr.is_cuda):
+            enc_outputs1, enc_pad_mask1, msa_outputs = self.encoder(node_attr, pos, batch, atom_laplacian, B, knn,
+                                                                    prep.get("p"))
+            enc_outputs2, enc_pad_mask2 = self.encoder2(aa_node_attr, aa_pos, aa_batch, aa_laplacian, enc_pad_mask1,
+                                                        msa_outputs, B, aa_knn, prep.get("l"))
+        else:
+            enc_outputs1, enc_pad_mask1, enc_outputs2, enc_pad_mask2 = self._encoders_two_streams(
+                node_attr, pos, batch, atom_laplacian, aa_node_attr, aa_pos, aa_batch, aa_laplacian, B, knn, aa_knn, prep)
         enc_outputs = torch.cat([enc_outputs1, enc_outputs2], dim=1)
         enc_pad_mask = torch.cat([enc_pad_mask1, enc_pad_mask2], dim=2)
         dec_outputs = self.decoder(smiles_index, enc_outputs, enc_pad_mask, tgt_len, prop)
