@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--workload", default="cfg2_b32_l2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
+    ap.add_argument("--no-prefetch", action="store_true",
+                    help="build each batch's graph structure inside its own step instead of on a second stream during the previous one")
     ap.add_argument("--roofline-steps", type=int, default=3, help="instrumented eager steps after the timed region")
     ap.add_argument("--cpu-graphs", type=int, default=12, help="graphs in the bounded CPU-oracle sample")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -195,6 +197,8 @@ def main():
     opt = Adam(model.parameters(), lr=cfg.train.optimizer.lr,
                betas=(cfg.train.optimizer.beta1, cfg.train.optimizer.beta2))
     batch = G.synthetic_batch(n_graphs, first_id=rank * n_graphs, **kw).to(dev)   # this rank's shard, resident in HBM
+    # a second resident copy: steps alternate between the two, so that batch i+1 can be prepared while step i computes
+    batches = [batch, batch if args.no_prefetch else G.synthetic_batch(n_graphs, first_id=rank * n_graphs, **kw).to(dev)]
     from singa_amd.engine import TrainStep
     engine = TrainStep(model, opt, reducer if world > 1 else None, use_graph=use_graph,
                        max_grad_norm=float(cfg.train.max_grad_norm))
@@ -210,15 +214,19 @@ def main():
         loss = engine.step(batch)
         torch.cuda.synchronize()
         log(f"warmup step {i}: {time.perf_counter() - t_w:.3f} s")
-    # ---- timed region: exactly K steps, barrier + synchronize on both sides, MAX over ranks.  Every step handles the
-    # batch as newly arrived: its graph structure (edge sorting, kNN graphs, dense maps) is rebuilt inside the step.
+    # ---- timed region: exactly K steps, barrier + synchronize on both sides, MAX over ranks.  Every step handles its
+    # batch as newly arrived: the graph structure (edge sorting, kNN graphs, dense maps) is rebuilt K times inside the
+    # region - by default on a second stream while the previous step computes (TrainStep.prefetch), the way a loader
+    # thread would; with --no-prefetch at the start of the step itself.
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = engine.step(batch)
+    for i in range(args.steps):
+        loss = engine.step(batches[i % 2])
+        if not args.no_prefetch:
+            engine.prefetch(batches[(i + 1) % 2])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -290,7 +298,8 @@ def main():
                           "nodes_per_graph": kw["n_protein"] + kw["n_ligand"],
                           "edges_per_graph": kw["e_pp"] + kw["e_ll"] + 2 * kw["e_x"],
                           "parallelism": f"dp{world}", "step": "prepare+zero_grad+fwd+CE+bwd+allreduce+clip+Adam",
-                          "launch": "hipGraph replay" if use_graph else "eager", "prepare_ms_of_step": round(prepare_ms, 2),
+                          "launch": "hipGraph replay" if use_graph else "eager",
+                          "prepare": "in step" if args.no_prefetch else "prefetched on a second stream during the previous step", "prepare_ms_of_step": round(prepare_ms, 2),
                           "grad_allreduce_bytes": reducer.payload_bytes},
                "final_loss": round(final_loss, 5), "roofline": roof}
         if not args.no_cpu_baseline and world == 1:

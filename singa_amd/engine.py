@@ -37,6 +37,18 @@ def _clone_tree(x):
     return x
 
 
+def _record_tree(x, stream):
+    """Tell the caching allocator that `stream` uses these tensors too (they were allocated on another stream)."""
+    if torch.is_tensor(x):
+        x.record_stream(stream)
+    elif isinstance(x, dict):
+        for v in x.values():
+            _record_tree(v, stream)
+    elif isinstance(x, (list, tuple)):
+        for v in x:
+            _record_tree(v, stream)
+
+
 def _prep_tensors(prep):
     out = {"p": prep["p"]["dense"].tensors() + prep["p"]["edges"].tensors(),
            "l": prep["l"]["dense"].tensors() + prep["l"]["edges"].tensors(),
@@ -54,6 +66,7 @@ class TrainStep:
         self.static = None
         self.g_fb = self.g_opt = None
         self.captures = 0
+        self._aux = None
 
     # ------------------------------------------------------------------------------------------------ eager pieces
     def _fwd_bwd(self, batch):
@@ -76,10 +89,39 @@ class TrainStep:
             self.opt.sync_hyper()
         self.opt.step()
 
-    def eager_step(self, batch):
+    def prefetch(self, batch):
+        """Build the graph structure of a COMING batch (edge sorting, kNN graphs, dense maps: `SINGA.prepare`, a few ms
+        with two host read-backs) on a second stream, so that it overlaps the step that is computing now.  `batch` is
+        a HeteroGraph whose tensors are complete, or a callable that makes one (run under the second stream, so a
+        host->device copy of the next batch does not queue behind the running step either).  `step` then finds the
+        batch prepared and only waits for the event."""
+        if self._aux is None:
+            self._aux = torch.cuda.Stream()
+        with torch.cuda.stream(self._aux):
+            if callable(batch):
+                batch = batch()
+            EF_layers._edge_cache.clear()      # a new batch: sort its edges again
+            batch.extras.pop("prepared", None)
+            self.model.prepare(batch)
+            batch.extras["prefetched"] = torch.cuda.Event()
+            batch.extras["prefetched"].record(self._aux)
+        return batch
+
+    def _prepared(self, batch):
+        """The batch's graph structure: taken from `prefetch` if it ran, else built now."""
+        ev = batch.extras.pop("prefetched", None)
+        if ev is not None and "prepared" in batch.extras:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            _record_tree(_prep_tensors(batch.extras["prepared"]), cur)
+            _record_tree([batch.nodes, batch.edges, batch.globals], cur)
+            return batch.extras["prepared"]
         EF_layers._edge_cache.clear()          # a new batch: sort its edges again
         batch.extras.pop("prepared", None)
-        self.model.prepare(batch)
+        return self.model.prepare(batch)
+
+    def eager_step(self, batch):
+        self._prepared(batch)
         self.opt.zero_grad(set_to_none=True)
         loss = self._fwd_bwd(batch)
         if self.reducer is not None:
@@ -94,7 +136,8 @@ class TrainStep:
         st.nodes = _clone_tree(batch.nodes)
         st.edges = _clone_tree(batch.edges)
         st.globals = _clone_tree(batch.globals)
-        st.extras = type(batch.extras)((k, _clone_tree(v)) for k, v in batch.extras.items() if k != "prepared")
+        st.extras = type(batch.extras)((k, _clone_tree(v)) for k, v in batch.extras.items()
+                                       if k not in ("prepared", "prefetched"))
         EF_layers._edge_cache.clear()
         prep = self.model.prepare(st)
         n_p, n_l = st[PA]["x"].shape[0], st[LA]["x"].shape[0]
@@ -109,14 +152,13 @@ class TrainStep:
         """Per-step work for an arriving batch: rebuild its graph structure (eager) and copy everything into the static
         buffers the captured graphs read.  False if any shape differs from the capture."""
         st = self.static
-        EF_layers._edge_cache.clear()
-        batch.extras.pop("prepared", None)
-        prep = self.model.prepare(batch)
+        prep = self._prepared(batch)
         sig = (batch[PA]["x"].shape[0], batch[LA]["x"].shape[0], prep["p"]["dense"].mx, prep["l"]["dense"].mx)
         if sig != self._sig:
             return False
         ok = _copy_tree(st.nodes, batch.nodes) and _copy_tree(st.edges, batch.edges) and _copy_tree(st.globals, batch.globals)
-        ok = ok and _copy_tree({k: v for k, v in st.extras.items()}, {k: batch.extras[k] for k in st.extras})
+        ok = ok and _copy_tree({k: v for k, v in st.extras.items() if k != "prefetched"},
+                               {k: batch.extras[k] for k in st.extras if k != "prefetched"})
         return ok and _copy_tree(_prep_tensors(self.static_prep), _prep_tensors(prep))
 
     def _capture(self, batch):
