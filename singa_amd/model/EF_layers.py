@@ -222,6 +222,23 @@ def get_normalization_layer(norm_type, lmax, num_channels, eps: float = 1e-5, af
 
 
 # ----------------------------------------------------------------------------------------------- SO(2) convolution
+_pass_token = [0, False]
+
+
+class forward_pass:
+    """`with forward_pass():` brackets one EquivariantEmbedding.forward.  Inside it, parameter-derived tensors (the SO(2)
+    block weights) are built once and shared by the homogeneous and heterogeneous passes; outside it nothing is cached
+    (the cached tensors carry the autograd history of the pass that built them)."""
+
+    def __enter__(self):
+        _pass_token[0] += 1
+        _pass_token[1] = True
+
+    def __exit__(self, *a):
+        _pass_token[1] = False
+        return False
+
+
 class SO2_m_Convolution(nn.Module):
     """Weights of the order-m SO(2) convolution (EF:677-729).  `block_weight()` returns [[Wr,-Wi],[Wi,Wr]] so that
     [x_+m | x_-m] @ block^T = [x_+ Wr^T - x_- Wi^T | x_+ Wi^T + x_- Wr^T] = (real | imag) in one GEMM."""
@@ -235,10 +252,17 @@ class SO2_m_Convolution(nn.Module):
         self.fc.weight.data.mul_(1 / math.sqrt(2))
 
     def block_weight(self) -> Tensor:
+        """Built once per forward pass of the model (`new_forward_pass`): the blocks are shared by the homogeneous and the
+        two heterogeneous passes, which would otherwise each rebuild (and back-propagate through) the same four cats."""
+        hit = getattr(self, "_bw", None)
+        if _pass_token[1] and hit is not None and hit[0] == _pass_token[0] and hit[2] == torch.is_grad_enabled():
+            return hit[1]
         w = self.fc.weight
         h = w.shape[0] // 2
         wr, wi = w[:h], w[h:]
-        return torch.cat([torch.cat([wr, -wi], 1), torch.cat([wi, wr], 1)], 0)
+        bw = torch.cat([torch.cat([wr, -wi], 1), torch.cat([wi, wr], 1)], 0)
+        object.__setattr__(self, "_bw", (_pass_token[0], bw, torch.is_grad_enabled()) if _pass_token[1] else None)
+        return bw
 
 
 class SO2_Convolution(nn.Module):
@@ -271,6 +295,9 @@ class SO2_Convolution(nn.Module):
         (y0 [E, extra + (L+1)*Cout], y1 [E, 2*L*Cout], y2 [E, 2*(L-1)*Cout]), each m-primary and contiguous."""
         c = self.sphere_channels
         st = self.layout.seg_start
+        if len(self.so2_m_conv) == 2:
+            return list(ops.so2_linear3(X, self.fc_m0.weight, self.fc_m0.bias, self.so2_m_conv[0].block_weight(),
+                                        self.so2_m_conv[1].block_weight(), st[1] * c, (st[2] - st[1]) * c))
         outs = [ops.linear(X[:, : st[1] * c], self.fc_m0.weight, self.fc_m0.bias)]
         for i, conv in enumerate(self.so2_m_conv):
             outs.append(ops.linear(X[:, st[i + 1] * c: st[i + 2] * c], conv.block_weight()))

@@ -14,7 +14,8 @@ import torch.nn as nn
 from .. import ops
 from ..graph import E_LL, E_LP, E_PL, E_PP, LA, PA
 from .EF_layers import (CoefficientMappingModule, EdgeDegreeEmbedding, GaussianSmearing, ModuleListInfo, SO3_Embedding,
-                        SO3_Grid, SO3_Rotation, TransBlockV2, get_normalization_layer, init_edge_rot_mat)
+                        SO3_Grid, SO3_Rotation, TransBlockV2, get_normalization_layer, init_edge_rot_mat,
+                        forward_pass)
 
 _AVG_NUM_MODES = 77.81317
 _AVG_DEGREE = 23.395238876342773
@@ -178,6 +179,10 @@ class EquivariantEmbedding(nn.Module):
         return mk(out[:n_p]), mk(out[n_p:])
 
     def forward(self, g, batch: Optional[int] = None, gen_mode: bool = False) -> Dict:
+        with forward_pass():
+            return self._forward(g, batch, gen_mode)
+
+    def _forward(self, g, batch: Optional[int] = None, gen_mode: bool = False) -> Dict:
         x_dict = {}
         if getattr(g, "num_graphs", 1) > 1:
             batch = 64

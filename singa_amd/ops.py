@@ -432,6 +432,16 @@ def s2act_node(x, gate, L):
 _deg_cache = {}
 
 
+def _degree_onehot(L, device):
+    """[L+1, K] 0/1 matrix that sums coefficient rows by degree: a small GEMM instead of index_add_ (atomics, ~20 us for
+    nine indices)."""
+    key = ("onehot", L, str(device))
+    if key not in _deg_cache:
+        deg = torch.as_tensor(so3.layout(L, L).degree, dtype=torch.int64)
+        _deg_cache[key] = torch.nn.functional.one_hot(deg, L + 1).t().to(torch.float32).contiguous().to(device)
+    return _deg_cache[key]
+
+
 def _degree_index(L, device):
     """degree l of every coefficient row, as a device tensor (cached: no host->device copy inside a graph capture)."""
     key = (L, str(device))
@@ -465,8 +475,7 @@ class _SO3RMSNorm(torch.autograd.Function):
         gbp = torch.empty(nparts, C, device=x.device, dtype=torch.float32)
         _chk(_lib.lib().singa_so3_rmsnorm_bwd(_p(x), _p(weight), _p(gy), _p(gx), _p(gwp), _p(gbp), N, C, L, eps,
                                               _stream()), "singa_so3_rmsnorm_bwd")
-        deg = _degree_index(L, x.device)
-        gw = torch.zeros(L + 1, C, device=x.device, dtype=torch.float32).index_add_(0, deg, colsum(gwp))
+        gw = _degree_onehot(L, x.device) @ colsum(gwp)
         return gx, gw, colsum(gbp), None, None
 
 
@@ -644,6 +653,44 @@ class _Linear(torch.autograd.Function):
         gw = _splitk_tn(g2, x2) if ctx.needs_input_grad[1] else None
         gb = colsum(g2) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb
+
+
+class _SO2Linear3(torch.autograd.Function):
+    """The three GEMMs of one SO(2) convolution (m = 0 with bias, m = 1, m = 2) on column blocks of ONE m-primary edge
+    matrix X [E, n0+n1+n2].  As separate autograd nodes every block's input gradient came back as a slice gradient:
+    a zero-filled [E, n0+n1+n2] tensor, a copy into the slice and an accumulation per block (three full-size passes
+    each).  Here the three dX products are written straight into the column blocks of one uninitialised buffer."""
+
+    @staticmethod
+    def forward(ctx, X, w0, b0, w1, w2, n0, n1):
+        blocks = (X[:, :n0], X[:, n0:n0 + n1], X[:, n0 + n1:])
+        ctx.save_for_backward(X, w0, w1, w2)
+        ctx.n0, ctx.n1 = n0, n1
+        outs = []
+        for xb, w, b in zip(blocks, (w0, w1, w2), (b0, None, None)):
+            with _blas(xb.shape[0], w.shape[0], xb.shape[1]):
+                outs.append(torch.addmm(b, xb, w.t()) if b is not None else xb @ w.t())
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        X, w0, w1, w2 = ctx.saved_tensors
+        n0, n1 = ctx.n0, ctx.n1
+        bounds = ((0, n0), (n0, n0 + n1), (n0 + n1, X.shape[1]))
+        gX = torch.empty_like(X) if ctx.needs_input_grad[0] else None
+        gws = []
+        for g, w, (a, b) in zip((g0, g1, g2), (w0, w1, w2), bounds):
+            g = g.contiguous()
+            if gX is not None:
+                with _blas(g.shape[0], w.shape[1], g.shape[1]):
+                    torch.mm(g, w, out=gX[:, a:b])
+            gws.append(_splitk_tn(g, X[:, a:b]))
+        return gX, gws[0], colsum(g0), gws[1], gws[2], None, None
+
+
+def so2_linear3(X, w0, b0, w1, w2, n0, n1):
+    """(X[:, :n0] w0^T + b0, X[:, n0:n0+n1] w1^T, X[:, n0+n1:] w2^T) - see _SO2Linear3."""
+    return _SO2Linear3.apply(X, w0, b0, w1, w2, n0, n1)
 
 
 def linear(x, w, b=None):

@@ -30,3 +30,6 @@ print("by op"); [print(f"{agg[k]:6d} calls {tt[k]:8.3f} ms {k}") for k, _ in tt.
 print("all GEMM shapes")
 g = [(t, c, k, s) for c, t, k, s in rows if k in ("aten::mm", "aten::bmm", "aten::addmm")]
 for t, c, k, s in sorted(g, reverse=True): print(f"{c:5d} calls {t:8.3f} ms {t / c * 1e3:8.1f} us/call {k:12s} {s}")
+print("top non-GEMM ops")
+g = [(t, c, k, s) for c, t, k, s in rows if k not in ("aten::mm", "aten::bmm", "aten::addmm")]
+for t, c, k, s in sorted(g, reverse=True)[:70]: print(f"{c:5d} calls {t:8.3f} ms {t / c * 1e3:8.1f} us/call {k:28s} {s}")
