@@ -1,0 +1,114 @@
+"""-m gpu: the full SINGA step on awkward batches, product (HIP path) against the CPU oracle on the same inputs: a
+single-graph batch, a ragged batch (graphs of very different sizes, a ligand with fewer atoms than the kNN degree),
+atoms without any bonded neighbour (empty CSR segments) and ligand atoms without interaction edges.  Logits at
+1e-4 relative, loss, and the total gradient norm against the oracle's autograd."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import singa_oracle as O
+from tests.helpers import state_from_spec
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def make_arrays(seed, n_p, n_l, e_pp, e_ll, e_x, isolate_p=0, isolate_l=0):
+    """One protein-ligand graph as the array dict both `singa_amd.graph.from_arrays` and the oracle's collate read."""
+    from singa_amd import graph as G
+    rng = np.random.default_rng(seed)
+    side = (n_p / 0.05) ** (1.0 / 3.0)
+    pos_p = rng.uniform(0, side, (n_p, 3)).astype(np.float32)
+    pos_l = (rng.uniform(-3, 3, (n_l, 3)) + side / 2).astype(np.float32)
+
+    def feats(n):
+        x = np.zeros((n, 59), np.float32)
+        x[np.arange(n), rng.integers(0, 44, n)] = 1.0
+        x[:, -15:] = (rng.random((n, 15)) < 0.2).astype(np.float32)
+        return x, rng.choice([6, 7, 8, 16], size=n).astype(np.int64)
+    x_p, z_p = feats(n_p)
+    x_l, z_l = feats(n_l)
+    a, b = G._closest_pairs(pos_p, pos_p, e_pp // 2, True)
+    ei_pp = np.stack([np.concatenate([a, b]), np.concatenate([b, a])])
+    a, b = G._closest_pairs(pos_l, pos_l, e_ll // 2, True)
+    ei_ll = np.stack([np.concatenate([a, b]), np.concatenate([b, a])])
+    li, pj = G._closest_pairs(pos_l, pos_p, e_x, False)
+    if isolate_p:                      # the first `isolate_p` protein atoms lose every bonded and interaction edge
+        ei_pp = ei_pp[:, (ei_pp[0] >= isolate_p) & (ei_pp[1] >= isolate_p)]
+        keep = pj >= isolate_p
+        li, pj = li[keep], pj[keep]
+    if isolate_l:                      # the last `isolate_l` ligand atoms take part in no interaction edge
+        keep = li < n_l - isolate_l
+        li, pj = li[keep], pj[keep]
+    n_tok = int(rng.integers(5, 30))
+    body = rng.integers(3, 110, n_tok)
+    tok_in = np.full(200, G.PAD_TOKEN, np.int64)
+    tok_tgt = np.full(200, G.PAD_TOKEN, np.int64)
+    tok_in[0], tok_in[1:1 + n_tok] = G.START_TOKEN, body
+    tok_tgt[:n_tok], tok_tgt[n_tok] = body, G.END_TOKEN
+    return dict(x_p=x_p, pos_p=pos_p, z_p=z_p, x_l=x_l, pos_l=pos_l, z_l=z_l, ei_pp=ei_pp, ei_ll=ei_ll,
+                ei_lp=np.stack([li, pj]), ei_pl=np.stack([pj, li]),
+                props=np.array([rng.uniform(-10, -5), rng.uniform(0.3, 0.9), rng.uniform(2, 6)]),
+                tok_in=tok_in[None], tok_tgt=tok_tgt[None])
+
+
+CASES = {
+    "single_graph": [dict(seed=1, n_p=70, n_l=14, e_pp=400, e_ll=30, e_x=50)],
+    "ragged": [dict(seed=2, n_p=40, n_l=5, e_pp=150, e_ll=8, e_x=12),        # 5 ligand atoms: fewer than the 30 kNN neighbours
+               dict(seed=3, n_p=150, n_l=33, e_pp=900, e_ll=70, e_x=90),
+               dict(seed=4, n_p=64, n_l=12, e_pp=300, e_ll=20, e_x=40)],
+    "isolated_atoms": [dict(seed=5, n_p=80, n_l=16, e_pp=420, e_ll=30, e_x=60, isolate_p=6, isolate_l=4),
+                       dict(seed=6, n_p=60, n_l=10, e_pp=300, e_ll=16, e_x=30, isolate_p=3)],
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_step_matches_oracle(case):
+    from singa_amd import graph as G
+    from singa_amd.config import load_config
+    from singa_amd.model.CProMG import DenseMap, knn_graph
+    from singa_amd.model.EF_layers import init_edge_rot_mat
+    from singa_amd.model.GAN import SINGA
+    arrays = [make_arrays(**kw) for kw in CASES[case]]
+    if case == "isolated_atoms":
+        deg = np.bincount(arrays[0]["ei_pp"][1], minlength=arrays[0]["x_p"].shape[0])
+        assert (deg[:6] == 0).all() and (deg[6:] > 0).any()
+    b = G.collate([G.from_arrays(d, with_lap=False) for d in arrays]).to(DEV)
+    B = len(arrays)
+    sd = state_from_spec("singa_L2")
+    model = SINGA(load_config(lmax=2), device=DEV)
+    model.load_state_dict(sd, strict=False)
+    model.eval()
+    # shared random choices: edge frames (Q6) drawn once, kNN lists and Laplacian PE as the product builds them
+    pos_p, pos_l = b[G.PA]["pos"], b[G.LA]["pos"]
+    torch.manual_seed(11)
+    ei = {k: b[et]["edge_index"] for k, et in (("pp", G.E_PP), ("ll", G.E_LL), ("lp", G.E_LP))}
+    rots = {"pp": init_edge_rot_mat(pos_p[ei["pp"][0]] - pos_p[ei["pp"][1]]),
+            "ll": init_edge_rot_mat(pos_l[ei["ll"][0]] - pos_l[ei["ll"][1]]),
+            "lp": init_edge_rot_mat(pos_l[ei["lp"][0]] - pos_p[ei["lp"][1]])}
+    knn = {}
+    for nt, k in ((G.PA, 48), (G.LA, 30)):
+        batch = b[nt]["batch"]
+        raw = knn_graph(b[nt]["pos"], k, batch, B, DenseMap(batch, B))
+        knn[nt] = raw[:, raw[0] >= 0]
+    b.extras["edge_rot_mat"], b.extras["knn"] = rots, knn
+    model.prepare(b)                                    # fills lap_pe on the GPU
+    logits = model(b)
+    tgt = b["ligand_data"]["smiIndices_tgt"].reshape(-1)
+    loss = torch.nn.functional.cross_entropy(logits, tgt)
+    loss.backward()
+    gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+
+    og = O.collate([{k: torch.as_tensor(v) for k, v in d.items()} for d in arrays])
+    osd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    c = lambda t: t.detach().cpu()
+    ref = O.singa_forward(osd, og, {k: c(v) for k, v in rots.items()}, 2, c(knn[G.PA]), c(knn[G.LA]),
+                          c(b[G.PA]["lap_pe"]), c(b[G.LA]["lap_pe"]))
+    ref_loss = torch.nn.functional.cross_entropy(ref, og["tok_tgt"].reshape(-1))
+    ref_loss.backward()
+    ref_gn = float(torch.sqrt(sum((v.grad.double() ** 2).sum() for v in osd.values() if v.grad is not None)))
+    assert torch.isfinite(logits).all()
+    err = float((c(logits).double() - ref.detach().double()).norm() / ref.detach().double().norm())
+    assert err < 1e-4, err
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * float(ref_loss)
+    assert abs(gn - ref_gn) < 2e-3 * ref_gn, (gn, ref_gn)

@@ -144,10 +144,15 @@ def main():
 
     max_iters = args.max_iters or cfg.train.max_iters
     log(f"model built: {sum(p.numel() for p in model.parameters())} parameters; training for {max_iters} iterations")
+    # the next batch is generated, copied and prepared (edge sorting, kNN graphs) on a second stream while the current
+    # step computes: TrainStep.prefetch
+    nxt = engine.prefetch(lambda: make_batch("train", start_it)) if start_it <= max_iters else None
     for it in range(start_it, max_iters + 1):
         model.train()
         t0 = time.perf_counter()
-        loss = engine.step(make_batch("train", it))
+        loss = engine.step(nxt)
+        if it < max_iters:
+            nxt = engine.prefetch(lambda: make_batch("train", it + 1))
         loss_v = float(loss.detach())
         log(f"[Train] Iter {it} | Loss {loss_v:.6f} | Grad {float(engine.grad_norm):.4f} | "
             f"LR {opt.param_groups[0]['lr']:.2e} | {time.perf_counter() - t0:.3f} s")
