@@ -129,6 +129,16 @@ int singa_gather_wsum_bwd(const float* g, const float* alpha, const float* wv, c
                           const int32_t* col, const int32_t* col_ptr, const int32_t* eperm, const int32_t* row,
                           float* g_alpha, float* g_wv, float* g_hv, int N, int H, int F, void* stream);
 
+/* k6a — LayerNorm over C = 16 channels followed by SiLU: the `nn.LayerNorm`, `nn.SiLU` pair inside RadialFunction
+ * (reference model/EF_layers.py:1634-1657, net.1/net.2 and net.4/net.5).  x, out, g_out, g_x: [M, C] contiguous; biased
+ * variance, eps inside the root (torch.nn.LayerNorm).  The backward recomputes the statistics and writes per-thread
+ * partial sums part[singa_ln_silu_nparts(M)][2C] = [d gamma | d beta], to be reduced with singa_colsum. */
+int singa_ln_silu_nparts(long long M);
+int singa_ln_silu_fwd(const float* x, const float* gamma, const float* beta, float* out, long long M, int C, float eps,
+                      void* stream);
+int singa_ln_silu_bwd(const float* x, const float* gamma, const float* beta, const float* g_out, float* g_x, float* part,
+                      long long M, int C, float eps, void* stream);
+
 /* k8 — SeparableS2Activation (EF:1736-1773): rows -> S2 grid (to_grid[G,KIN]) -> SiLU -> rows (from_grid[G,KIN]);
  * row 0 of the output is SiLU(gate).  x: KIN rows of C channels in `nseg` segments; gate[E, ldg]; out[E,KIN,C].
  * Grid matrices are given in the row order of x (the host permutes them for m-primary inputs). */

@@ -43,6 +43,9 @@ _SIGS = {
     "singa_edge_logits_bwd": ([P] * 13 + [I32, I32, I32, F32, P], I32),
     "singa_gather_wsum_fwd": ([P] * 6 + [I32, I32, I32, P], I32),
     "singa_gather_wsum_bwd": ([P] * 12 + [I32, I32, I32, P], I32),
+    "singa_ln_silu_nparts": ([I64], I32),
+    "singa_ln_silu_fwd": ([P] * 4 + [I64, I32, F32, P], I32),
+    "singa_ln_silu_bwd": ([P] * 6 + [I64, I32, F32, P], I32),
     "singa_colsum_work": ([C.c_longlong, I32], C.c_longlong),
     "singa_colsum": ([P, C.c_longlong, C.c_longlong, I32, P, P, P], I32),
     "singa_adam_step": ([P, P, P, P, P, P, P, I32, I32, P, P, F32, F32, F32, P], I32),

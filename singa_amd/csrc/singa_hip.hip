@@ -801,6 +801,96 @@ __global__ void __launch_bounds__(64) gather_wsum_bwd_col_kernel(const float* __
 }
 
 
+// ------------------------------------------------------------------------------------------------ narrow LayerNorm + SiLU
+// The radial MLPs (EF:1634-1657) normalise rows of only C = 16 channels; a row-per-wave LayerNorm kernel spends its time
+// on cross-lane reductions over 16 values.  Here one thread owns one row (64 B: consecutive lanes read consecutive rows),
+// LayerNorm (biased variance, eps inside the root) and the SiLU that always follows it are one pass, and the backward
+// recomputes the statistics from x.  d gamma / d beta are accumulated per thread over its rows and reduced by
+// singa_colsum over the [threads, 2C] partials.
+template <int C>
+__device__ __forceinline__ void ln_row(const float* __restrict__ x, long long r, float (&xh)[C], float& rstd, float eps) {
+    float mean = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; c += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(x + r * C + c);
+        xh[c] = v.x, xh[c + 1] = v.y, xh[c + 2] = v.z, xh[c + 3] = v.w;
+        mean += (v.x + v.y) + (v.z + v.w);
+    }
+    mean *= 1.f / C;
+    float var = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        xh[c] -= mean;
+        var = fmaf(xh[c], xh[c], var);
+    }
+    rstd = 1.f / sqrtf(var * (1.f / C) + eps);
+#pragma unroll
+    for (int c = 0; c < C; ++c) xh[c] *= rstd;
+}
+
+template <int C>
+__global__ void __launch_bounds__(64) ln_silu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ out, long long M,
+                                                         float eps) {
+    const long long stride = (long long)gridDim.x * 64;
+    for (long long r = (long long)blockIdx.x * 64 + threadIdx.x; r < M; r += stride) {
+        float xh[C], rstd;
+        ln_row<C>(x, r, xh, rstd, eps);
+        float o[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float y = fmaf(xh[c], gamma[c], beta[c]);
+            o[c] = y / (1.f + expf(-y));
+        }
+#pragma unroll
+        for (int c = 0; c < C; c += 4) *reinterpret_cast<float4*>(out + r * C + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
+    }
+}
+
+template <int C>
+__global__ void __launch_bounds__(64) ln_silu_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ g_out,
+                                                         float* __restrict__ g_x, float* __restrict__ part, long long M,
+                                                         float eps) {
+    const long long tid = (long long)blockIdx.x * 64 + threadIdx.x, stride = (long long)gridDim.x * 64;
+    float ag[C], ab[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) ag[c] = ab[c] = 0.f;
+    for (long long r = tid; r < M; r += stride) {
+        float xh[C], rstd;
+        ln_row<C>(x, r, xh, rstd, eps);
+        float gh[C], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+            const float4 v = *reinterpret_cast<const float4*>(g_out + r * C + c);
+            gh[c] = v.x, gh[c + 1] = v.y, gh[c + 2] = v.z, gh[c + 3] = v.w;
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float y = fmaf(xh[c], gamma[c], beta[c]);
+            const float sg = 1.f / (1.f + expf(-y));
+            const float gy = gh[c] * sg * (1.f + y * (1.f - sg));          // d SiLU
+            ag[c] = fmaf(gy, xh[c], ag[c]);
+            ab[c] += gy;
+            gh[c] = gy * gamma[c];                                         // d x_hat
+            m1 += gh[c];
+            m2 = fmaf(gh[c], xh[c], m2);
+        }
+        m1 *= 1.f / C, m2 *= 1.f / C;
+        float o[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[c] = rstd * (gh[c] - m1 - xh[c] * m2);
+#pragma unroll
+        for (int c = 0; c < C; c += 4) *reinterpret_cast<float4*>(g_x + r * C + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        part[tid * 2 * C + c] = ag[c];
+        part[tid * 2 * C + C + c] = ab[c];
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------------ column sums
 // out[j] = sum_i x[i*ld + j]: bias / broadcast gradients.  A fixed-shape reduction tree: every pass lets one thread add up
 // to COLSUM_R rows of one column (consecutive threads = consecutive columns, so loads coalesce), passes repeat until one
@@ -1678,6 +1768,32 @@ int singa_alpha_logits_bwd(const float* h0, long long ld, const float* ln_w, con
     hipLaunchKernelGGL((alpha_logits_bwd_kernel<7>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, h0, ld, ln_w, ln_b, dot,
                        g_logits, g_x, part, E, eps);
     return check_launch("alpha_logits_bwd");
+}
+
+int singa_ln_silu_nparts(long long M) {
+    long long blocks = (M + 63) / 64;
+    return (int)(blocks < 256 ? (blocks < 1 ? 1 : blocks) : 256) * 64;      // threads = rows of the partial buffer
+}
+
+int singa_ln_silu_fwd(const float* x, const float* gamma, const float* beta, float* out, long long M, int C, float eps,
+                      void* stream) {
+    if (!x || !gamma || !beta || !out) return fail(SINGA_E_NULL, "ln_silu_fwd: null pointer");
+    if (C != 16) return fail(SINGA_E_SHAPE, "ln_silu: built for rows of 16 channels");
+    if (M <= 0) return SINGA_OK;
+    long long blocks = (M + 63) / 64;
+    hipLaunchKernelGGL((ln_silu_fwd_kernel<16>), dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(64), 0,
+                       (hipStream_t)stream, x, gamma, beta, out, M, eps);
+    return check_launch("ln_silu_fwd");
+}
+
+int singa_ln_silu_bwd(const float* x, const float* gamma, const float* beta, const float* g_out, float* g_x, float* part,
+                      long long M, int C, float eps, void* stream) {
+    if (!x || !gamma || !beta || !g_out || !g_x || !part) return fail(SINGA_E_NULL, "ln_silu_bwd: null pointer");
+    if (C != 16) return fail(SINGA_E_SHAPE, "ln_silu: built for rows of 16 channels");
+    if (M <= 0) return SINGA_OK;
+    hipLaunchKernelGGL((ln_silu_bwd_kernel<16>), dim3(singa_ln_silu_nparts(M) / 64), dim3(64), 0, (hipStream_t)stream, x, gamma,
+                       beta, g_out, g_x, part, M, eps);
+    return check_launch("ln_silu_bwd");
 }
 
 long long singa_colsum_work(long long M, int n) {

@@ -148,7 +148,17 @@ class RadialFunction(nn.Module):
         self.net = nn.Sequential(*modules)
 
     def forward(self, inputs):
-        return self.net(inputs)
+        x, mods, i = inputs, list(self.net), 0
+        while i < len(mods):
+            m = mods[i]
+            if (isinstance(m, nn.LayerNorm) and x.is_cuda and x.shape[-1] == 16 and i + 1 < len(mods)
+                    and isinstance(mods[i + 1], nn.SiLU)):
+                x = ops.ln_silu(x, m.weight, m.bias, m.eps)              # net.1+net.2, net.4+net.5 as one kernel each
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
 
 
 class SmoothLeakyReLU(nn.Module):

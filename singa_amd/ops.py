@@ -547,6 +547,39 @@ def gather_wsum(alpha, wv, hv, edges):
     return _GatherWSum.apply(alpha, wv, hv, edges)
 
 
+class _LnSilu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x, gamma, beta = x.contiguous(), gamma.contiguous(), beta.contiguous()
+        _dev(x, gamma, beta)
+        C = x.shape[-1]
+        M = x.numel() // C
+        out = torch.empty_like(x)
+        _chk(_lib.lib().singa_ln_silu_fwd(_p(x), _p(gamma), _p(beta), _p(out), M, C, eps, _stream()), "singa_ln_silu_fwd")
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.eps = eps
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, beta = ctx.saved_tensors
+        g = g.contiguous()
+        C = x.shape[-1]
+        M = x.numel() // C
+        lib = _lib.lib()
+        gx = torch.empty_like(x)
+        part = torch.empty(lib.singa_ln_silu_nparts(M), 2 * C, device=x.device, dtype=torch.float32)
+        _chk(lib.singa_ln_silu_bwd(_p(x), _p(gamma), _p(beta), _p(g), _p(gx), _p(part), M, C, ctx.eps, _stream()),
+             "singa_ln_silu_bwd")
+        gg = colsum(part)
+        return gx, gg[:C], gg[C:], None
+
+
+def ln_silu(x, gamma, beta, eps=1e-5):
+    """SiLU(LayerNorm(x)) over the last axis of 16 channels (k6a): one pass forward, one pass backward."""
+    return _LnSilu.apply(x, gamma, beta, eps)
+
+
 def colsum(t):
     """Column sums of a [M, ...] tensor over dim 0 with the library's two-pass kernel.  torch's own long-column
     reductions (bias gradients of Linear layers, broadcast gradients, `t.sum(0)`) go through a multi-block kernel with

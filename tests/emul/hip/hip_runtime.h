@@ -19,6 +19,11 @@
 #define __launch_bounds__(...)
 #define HIP_SYMBOL(x) x
 
+struct float4 {
+    float x, y, z, w;
+};
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+
 struct dim3 {
     unsigned x, y, z;
     dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {}

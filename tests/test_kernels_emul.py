@@ -302,3 +302,27 @@ def test_s2act_separable(emul, L, edge):
         want, want_g = x.grad, gt.grad
     assert np.abs(gx - want.numpy()).max() < 1e-4 * max(1.0, float(want.abs().max()))
     assert np.abs(gg - want_g.numpy()).max() < 1e-5
+
+
+def test_ln_silu(emul):
+    """k6a: SiLU(LayerNorm(x)) over 16 channels and its backward, against torch on the CPU."""
+    rs = np.random.RandomState(5)
+    M, C = 333, 16
+    x = (rs.randn(M, C) * 2 + 0.5).astype(np.float32)
+    gamma, beta = rs.randn(C).astype(np.float32), rs.randn(C).astype(np.float32)
+    g = rs.randn(M, C).astype(np.float32)
+    out = np.zeros_like(x)
+    assert emul.singa_ln_silu_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(out), M, C, 1e-5, None) == 0
+    xt = torch.tensor(x, requires_grad=True)
+    gt, bt = torch.tensor(gamma, requires_grad=True), torch.tensor(beta, requires_grad=True)
+    ref = torch.nn.functional.silu(torch.nn.functional.layer_norm(xt, (C,), gt, bt, 1e-5))
+    ref.backward(torch.tensor(g))
+    assert np.abs(out - ref.detach().numpy()).max() < 2e-5
+    n = emul.singa_ln_silu_nparts(M)
+    gx, part = np.zeros_like(x), np.zeros((n, 2 * C), np.float32)
+    assert emul.singa_ln_silu_bwd(ptr(x), ptr(gamma), ptr(beta), ptr(g), ptr(gx), ptr(part), M, C, 1e-5, None) == 0
+    assert np.abs(gx - xt.grad.numpy()).max() < 5e-5 * np.abs(xt.grad.numpy()).max()
+    s = part.sum(0)
+    assert np.abs(s[:C] - gt.grad.numpy()).max() < 1e-4 * np.abs(gt.grad.numpy()).max()
+    assert np.abs(s[C:] - bt.grad.numpy()).max() < 1e-4 * np.abs(bt.grad.numpy()).max()
+    assert emul.singa_ln_silu_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(out), M, 32, 1e-5, None) == -3

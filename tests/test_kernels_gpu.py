@@ -348,3 +348,21 @@ def test_edge_head_logits_and_activation():
     ((logits * g1.to(DEV)).sum() + (act * g2.to(DEV)).sum()).backward()
     for d, r in zip(dev, (h0, h1, h2, w, b, dot)):
         assert rel(d.grad, r.grad) < 1e-4
+
+
+@pytest.mark.parametrize("M", [1, 63, 56448])
+def test_ln_silu_matches_torch(M):
+    """k6a against torch's LayerNorm + SiLU (outputs, input gradient, d gamma, d beta)."""
+    from singa_amd import ops
+    torch.manual_seed(M)
+    x = (torch.randn(M, 16, device="cuda") * 2 + 0.3).requires_grad_(True)
+    gamma = torch.randn(16, device="cuda", requires_grad=True)
+    beta = torch.randn(16, device="cuda", requires_grad=True)
+    g = torch.randn(M, 16, device="cuda")
+    want = torch.nn.functional.silu(torch.nn.functional.layer_norm(x, (16,), gamma, beta, 1e-5))
+    want_g = torch.autograd.grad(want, (x, gamma, beta), g)
+    got = ops.ln_silu(x, gamma, beta, 1e-5)
+    got_g = torch.autograd.grad(got, (x, gamma, beta), g)
+    assert float((got - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
+    for a, b in zip(got_g, want_g):
+        assert float((a - b).abs().max()) < 1e-4 * max(1e-3, float(b.abs().max())), a.shape
