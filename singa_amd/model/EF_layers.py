@@ -197,6 +197,8 @@ class SO3_LinearV2(nn.Module):
         self._deg = None
 
     def apply_tensor(self, x: Tensor) -> Tensor:
+        if x.is_cuda:
+            return ops.so3_linear(x, self.weight, self.bias, self.lmax)
         if self._deg is None or self._deg.device != x.device:
             self._deg = torch.as_tensor(so3.layout(self.lmax, self.lmax).degree, device=x.device, dtype=torch.int64)
         w = self.weight.index_select(0, self._deg)                               # [K, out, in]

@@ -726,6 +726,42 @@ def so2_linear3(X, w0, b0, w1, w2, n0, n1):
     return _SO2Linear3.apply(X, w0, b0, w1, w2, n0, n1)
 
 
+class _SO3Linear(torch.autograd.Function):
+    """SO3_LinearV2 (EF:624-674) on [N, K, C] coefficient rows: one batched GEMM over the K rows with the per-degree weight
+    expanded by row, written straight into the [N, K, out] result through a transposed view (the library takes the row
+    and batch strides as they are), bias on the l = 0 row only.  The backward does the same for dX; the per-degree
+    weight gradient is the per-row gradient summed by degree with a one-hot GEMM.  No transposed copies, no zero-filled
+    select / slice gradients."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, L):
+        x = x.contiguous()
+        N, K, _ = x.shape
+        w = weight.index_select(0, _degree_index(L, x.device))                    # [K, out, in]
+        out = torch.empty(N, K, weight.shape[1], device=x.device, dtype=x.dtype)
+        torch.bmm(x.transpose(0, 1), w.transpose(1, 2), out=out.transpose(0, 1))
+        out[:, 0, :] += bias
+        ctx.save_for_backward(x, w)
+        ctx.L = L
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.contiguous()
+        K = x.shape[1]
+        gT = g.transpose(0, 1)                                                    # [K, N, out] view
+        gx = torch.empty_like(x)
+        torch.bmm(gT, w, out=gx.transpose(0, 1))
+        gw_rows = torch.bmm(gT.transpose(1, 2), x.transpose(0, 1))               # [K, out, in]
+        gw = (_degree_onehot(ctx.L, x.device) @ gw_rows.view(K, -1)).view(ctx.L + 1, *gw_rows.shape[1:])
+        return gx, gw, colsum(g[:, 0, :]), None
+
+
+def so3_linear(x, weight, bias, L):
+    return _SO3Linear.apply(x, weight, bias, L)
+
+
 def linear(x, w, b=None):
     """y = x W^T + b with gradients that are all GEMMs: dW by batched split-K when the row count is large (per-edge
     layers: 10^4..10^6 rows against <= 10^3 columns), db as a ones-row GEMM (see colsum)."""
