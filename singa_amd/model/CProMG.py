@@ -169,6 +169,8 @@ class MultiHeadAttention(nn.Module):
         N, heads = h.shape[0], self.num_heads
         w = conv.weight[:, :, 0]
         og, ig = w.shape[0] // heads, w.shape[1]
+        if h.is_cuda:
+            return ops.grouped_linear(h, w.view(heads, og, ig))
         return torch.bmm(h.view(N, heads, ig).transpose(0, 1), w.view(heads, og, ig).transpose(1, 2)).transpose(0, 1)
 
     def _edge_mlp(self, net, x):

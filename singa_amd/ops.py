@@ -762,6 +762,38 @@ def so3_linear(x, weight, bias, L):
     return _SO3Linear.apply(x, weight, bias, L)
 
 
+class _GroupedLinear(torch.autograd.Function):
+    """Grouped 1x1 Conv1d on node rows (CP:27-29, 55-57): h [N, heads*ig] x w [heads, og, ig] -> [N, heads, og], one
+    batched GEMM over the heads reading and writing the node-major tensors through transposed views (no head-major
+    copies forward or backward)."""
+
+    @staticmethod
+    def forward(ctx, h, w):
+        h = h.contiguous()
+        heads, og, ig = w.shape
+        N = h.shape[0]
+        out = torch.empty(N, heads, og, device=h.device, dtype=h.dtype)
+        torch.bmm(h.view(N, heads, ig).transpose(0, 1), w.transpose(1, 2), out=out.transpose(0, 1))
+        ctx.save_for_backward(h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, w = ctx.saved_tensors
+        heads, og, ig = w.shape
+        N = h.shape[0]
+        g = g.contiguous()
+        gT = g.transpose(0, 1)                                                    # [heads, N, og] view
+        gh = torch.empty(N, heads, ig, device=h.device, dtype=h.dtype)
+        torch.bmm(gT, w, out=gh.transpose(0, 1))
+        gw = torch.bmm(gT.transpose(1, 2), h.view(N, heads, ig).transpose(0, 1))
+        return gh.view(N, heads * ig), gw
+
+
+def grouped_linear(h, w):
+    return _GroupedLinear.apply(h, w)
+
+
 def linear(x, w, b=None):
     """y = x W^T + b with gradients that are all GEMMs: dW by batched split-K when the row count is large (per-edge
     layers: 10^4..10^6 rows against <= 10^3 columns), db as a ones-row GEMM (see colsum)."""
