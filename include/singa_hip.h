@@ -129,6 +129,12 @@ int singa_gather_wsum_bwd(const float* g, const float* alpha, const float* wv, c
                           const int32_t* col, const int32_t* col_ptr, const int32_t* eperm, const int32_t* row,
                           float* g_alpha, float* g_wv, float* g_hv, int N, int H, int F, void* stream);
 
+/* k15d — y[M,n] = softplus(u + b) - ln 2 and gu = g * sigmoid(u + b): `ShiftedSoftplus` between the two Linears of
+ * `weight_k_net` / `weight_v_net` (reference model/CProMG.py:33-48) with the first Linear's bias folded in (the GEMM then
+ * needs no bias epilogue; d b = colsum(gu)).  n a multiple of 4, rows contiguous. */
+int singa_bias_ssp_fwd(const float* u, const float* b, float* y, long long M, int n, void* stream);
+int singa_bias_ssp_bwd(const float* u, const float* b, const float* g, float* gu, long long M, int n, void* stream);
+
 /* k6a — LayerNorm over C = 16 channels followed by SiLU: the `nn.LayerNorm`, `nn.SiLU` pair inside RadialFunction
  * (reference model/EF_layers.py:1634-1657, net.1/net.2 and net.4/net.5).  x, out, g_out, g_x: [M, C] contiguous; biased
  * variance, eps inside the root (torch.nn.LayerNorm).  The backward recomputes the statistics and writes per-thread

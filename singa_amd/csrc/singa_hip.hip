@@ -891,6 +891,35 @@ __global__ void __launch_bounds__(64) ln_silu_bwd_kernel(const float* __restrict
 }
 
 
+// ------------------------------------------------------------------------------------------------ bias + shifted softplus
+// y = softplus(u + b) - ln 2 on [M, n] rows (CP:41-48: the activation between the two Linears of the edge MLPs, with the
+// first Linear's bias folded in so that its GEMM needs no epilogue) and gu = g * sigmoid(u + b).  float4 per thread.
+__global__ void __launch_bounds__(256) bias_ssp_fwd_kernel(const float* __restrict__ u, const float* __restrict__ b,
+                                                           float* __restrict__ y, long long total4, int n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int c = (int)((i * 4) % n);
+    const float4 v = *reinterpret_cast<const float4*>(u + i * 4);
+    const float4 bb = *reinterpret_cast<const float4*>(b + c);
+    auto f = [](float x) { return (x > 20.f ? x : log1pf(expf(x))) - 0.69314718055994530942f; };
+    *reinterpret_cast<float4*>(y + i * 4) = make_float4(f(v.x + bb.x), f(v.y + bb.y), f(v.z + bb.z), f(v.w + bb.w));
+}
+
+__global__ void __launch_bounds__(256) bias_ssp_bwd_kernel(const float* __restrict__ u, const float* __restrict__ b,
+                                                           const float* __restrict__ g, float* __restrict__ gu,
+                                                           long long total4, int n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int c = (int)((i * 4) % n);
+    const float4 v = *reinterpret_cast<const float4*>(u + i * 4);
+    const float4 bb = *reinterpret_cast<const float4*>(b + c);
+    const float4 gg = *reinterpret_cast<const float4*>(g + i * 4);
+    auto s = [](float x) { return x > 20.f ? 1.f : 1.f / (1.f + expf(-x)); };
+    *reinterpret_cast<float4*>(gu + i * 4) = make_float4(gg.x * s(v.x + bb.x), gg.y * s(v.y + bb.y), gg.z * s(v.z + bb.z),
+                                                         gg.w * s(v.w + bb.w));
+}
+
+
 // ------------------------------------------------------------------------------------------------ column sums
 // out[j] = sum_i x[i*ld + j]: bias / broadcast gradients.  A fixed-shape reduction tree: every pass lets one thread add up
 // to COLSUM_R rows of one column (consecutive threads = consecutive columns, so loads coalesce), passes repeat until one
@@ -1794,6 +1823,26 @@ int singa_ln_silu_bwd(const float* x, const float* gamma, const float* beta, con
     hipLaunchKernelGGL((ln_silu_bwd_kernel<16>), dim3(singa_ln_silu_nparts(M) / 64), dim3(64), 0, (hipStream_t)stream, x, gamma,
                        beta, g_out, g_x, part, M, eps);
     return check_launch("ln_silu_bwd");
+}
+
+int singa_bias_ssp_fwd(const float* u, const float* b, float* y, long long M, int n, void* stream) {
+    if (!u || !b || !y) return fail(SINGA_E_NULL, "bias_ssp_fwd: null pointer");
+    if (n <= 0 || n % 4) return fail(SINGA_E_SHAPE, "bias_ssp: row length must be a positive multiple of 4");
+    if (M <= 0) return SINGA_OK;
+    const long long total4 = M * n / 4;
+    hipLaunchKernelGGL(bias_ssp_fwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, b, y,
+                       total4, n);
+    return check_launch("bias_ssp_fwd");
+}
+
+int singa_bias_ssp_bwd(const float* u, const float* b, const float* g, float* gu, long long M, int n, void* stream) {
+    if (!u || !b || !g || !gu) return fail(SINGA_E_NULL, "bias_ssp_bwd: null pointer");
+    if (n <= 0 || n % 4) return fail(SINGA_E_SHAPE, "bias_ssp: row length must be a positive multiple of 4");
+    if (M <= 0) return SINGA_OK;
+    const long long total4 = M * n / 4;
+    hipLaunchKernelGGL(bias_ssp_bwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, b, g, gu,
+                       total4, n);
+    return check_launch("bias_ssp_bwd");
 }
 
 long long singa_colsum_work(long long M, int n) {

@@ -580,6 +580,32 @@ def ln_silu(x, gamma, beta, eps=1e-5):
     return _LnSilu.apply(x, gamma, beta, eps)
 
 
+class _BiasSsp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, b):
+        u, b = u.contiguous(), b.contiguous()
+        _dev(u, b)
+        n = u.shape[-1]
+        y = torch.empty_like(u)
+        _chk(_lib.lib().singa_bias_ssp_fwd(_p(u), _p(b), _p(y), u.numel() // n, n, _stream()), "singa_bias_ssp_fwd")
+        ctx.save_for_backward(u, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        u, b = ctx.saved_tensors
+        g = g.contiguous()
+        n = u.shape[-1]
+        gu = torch.empty_like(u)
+        _chk(_lib.lib().singa_bias_ssp_bwd(_p(u), _p(b), _p(g), _p(gu), u.numel() // n, n, _stream()), "singa_bias_ssp_bwd")
+        return gu, colsum(gu.reshape(-1, n))
+
+
+def bias_ssp(u, b):
+    """softplus(u + b) - ln 2 (k15d): ShiftedSoftplus with the preceding Linear's bias folded in."""
+    return _BiasSsp.apply(u, b)
+
+
 def colsum(t):
     """Column sums of a [M, ...] tensor over dim 0 with the library's two-pass kernel.  torch's own long-column
     reductions (bias gradients of Linear layers, broadcast gradients, `t.sum(0)`) go through a multi-block kernel with
@@ -648,7 +674,10 @@ class _blas:
     def __init__(self, m, n, k):
         # second clause (tools/lab/tn_probe.py): weight-gradient products a^T b with a few thousand rows and a small
         # output, e.g. 256x6400x256: 43 us in hipBLASLt (64 workgroups), 22 us in rocBLAS; 64x5938x64: 48 vs 18 us
-        self.use_rocblas = _ROCBLAS_SMALL and ((k <= 2048 and m <= 32768 and n <= 4096) or (k <= 8192 and m * n <= 80000))
+        # third clause (tools/lab/addmm_probe.py): the per-edge products of the CProMG attention, 374578x64x64: 37 us in
+        # rocBLAS, 75 us in hipBLASLt (x64x32: 23 vs 40) - but x32x32: 104 vs 32 and x16x192: 42 vs 19, hence k == 64 only
+        self.use_rocblas = _ROCBLAS_SMALL and ((k <= 2048 and m <= 32768 and n <= 4096) or (k <= 8192 and m * n <= 80000)
+                                               or (m > 32768 and k == 64 and n <= 64))
 
     def __enter__(self):
         if self.use_rocblas:
@@ -674,8 +703,14 @@ class _Linear(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         ctx.save_for_backward(x2, w)
         ctx.xshape, ctx.has_bias = x.shape, b is not None
-        with _blas(x2.shape[0], w.shape[0], x2.shape[1]):
-            y = torch.addmm(b, x2, w.t()) if b is not None else x2 @ w.t()
+        lib = _blas(x2.shape[0], w.shape[0], x2.shape[1])
+        with lib:
+            if b is not None and lib.use_rocblas and x2.is_cuda and x2.shape[0] * w.shape[0] <= (1 << 23):
+                # addmm always takes hipBLASLt's bias epilogue, whatever library is preferred; where rocBLAS is the
+                # faster GEMM (6400x256x1024: 37 vs 65 us) the bias is a separate in-place pass over a small output
+                y = (x2 @ w.t()).add_(b)
+            else:
+                y = torch.addmm(b, x2, w.t()) if b is not None else x2 @ w.t()
         return y.view(*x.shape[:-1], w.shape[0])
 
     @staticmethod

@@ -366,3 +366,20 @@ def test_ln_silu_matches_torch(M):
     assert float((got - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
     for a, b in zip(got_g, want_g):
         assert float((a - b).abs().max()) < 1e-4 * max(1e-3, float(b.abs().max())), a.shape
+
+
+def test_bias_ssp_matches_torch():
+    """k15d: softplus(u + b) - ln 2 and its gradients against torch (including the x > 20 branch)."""
+    import math
+    from singa_amd import ops
+    torch.manual_seed(2)
+    u = (torch.randn(5003, 64, device="cuda") * 6).requires_grad_(True)
+    b = torch.randn(64, device="cuda", requires_grad=True)
+    g = torch.randn(5003, 64, device="cuda")
+    want = torch.nn.functional.softplus(u + b) - math.log(2.0)
+    want_g = torch.autograd.grad(want, (u, b), g)
+    got = ops.bias_ssp(u, b)
+    got_g = torch.autograd.grad(got, (u, b), g)
+    assert float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
+    for a, c in zip(got_g, want_g):
+        assert float((a - c).abs().max()) < 1e-4 * float(c.abs().max())
