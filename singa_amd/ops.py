@@ -671,13 +671,14 @@ class _blas:
     collapses on tall reductions (64x28800x64: 1.5 ms).  Small-K / moderate-M products go to rocBLAS, the rest to
     hipBLASLt.  The switch is host-side state only; under HIP-graph replay the chosen kernels are baked in."""
 
-    def __init__(self, m, n, k):
+    def __init__(self, m, n, k, b_transposed=False):
         # second clause (tools/lab/tn_probe.py): weight-gradient products a^T b with a few thousand rows and a small
         # output, e.g. 256x6400x256: 43 us in hipBLASLt (64 workgroups), 22 us in rocBLAS; 64x5938x64: 48 vs 18 us
         # third clause (tools/lab/addmm_probe.py): the per-edge products of the CProMG attention, 374578x64x64: 37 us in
-        # rocBLAS, 75 us in hipBLASLt (x64x32: 23 vs 40) - but x32x32: 104 vs 32 and x16x192: 42 vs 19, hence k == 64 only
+        # rocBLAS, 75 us in hipBLASLt (x64x32: 23 vs 40) - but x32x32: 104 vs 32 and x16x192: 42 vs 19, hence k == 64 only,
+        # and only for x @ w^T: the non-transposed product g @ w of the same size takes 164 us in rocBLAS (92 us in Lt)
         self.use_rocblas = _ROCBLAS_SMALL and ((k <= 2048 and m <= 32768 and n <= 4096) or (k <= 8192 and m * n <= 80000)
-                                               or (m > 32768 and k == 64 and n <= 64))
+                                               or (b_transposed and m > 32768 and k == 64 and n <= 64))
 
     def __enter__(self):
         if self.use_rocblas:
@@ -693,7 +694,7 @@ _ROCBLAS_SMALL = _os.environ.get("SINGA_ROCBLAS_SMALL", "1") == "1"
 
 
 def _mm(a, b):
-    with _blas(a.shape[0], b.shape[1], a.shape[1]):
+    with _blas(a.shape[0], b.shape[1], a.shape[1], b.stride(0) == 1 and b.stride(1) != 1):
         return a @ b
 
 
@@ -703,7 +704,7 @@ class _Linear(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         ctx.save_for_backward(x2, w)
         ctx.xshape, ctx.has_bias = x.shape, b is not None
-        lib = _blas(x2.shape[0], w.shape[0], x2.shape[1])
+        lib = _blas(x2.shape[0], w.shape[0], x2.shape[1], True)
         with lib:
             if b is not None and lib.use_rocblas and x2.is_cuda and x2.shape[0] * w.shape[0] <= (1 << 23):
                 # addmm always takes hipBLASLt's bias epilogue, whatever library is preferred; where rocBLAS is the
