@@ -204,9 +204,16 @@ def _dense_attention(module, Q, K, V, attn_mask, key_channels, hidden_channels):
     q_s = module.W_Q(Q).view(B, -1, heads, key_channels // heads).transpose(1, 2)
     k_s = module.W_K(K).view(B, -1, heads, key_channels // heads).transpose(1, 2)
     v_s = module.W_V(V).view(B, -1, heads, hidden_channels // heads).transpose(1, 2)
-    scores = torch.matmul(q_s, k_s.transpose(-1, -2)) / np.sqrt(q_s.size(-1))
-    scores = scores.masked_fill(attn_mask.unsqueeze(1), -1e9)
-    context = torch.matmul(torch.softmax(scores, dim=-1), v_s)
+    if Q.is_cuda:
+        T, S = q_s.size(2), k_s.size(2)
+        flat = lambda t: t.reshape(B * heads, t.size(2), t.size(3))
+        scores = ops.bmm_small(flat(q_s), flat(k_s).transpose(1, 2)).view(B, heads, T, S) / np.sqrt(q_s.size(-1))
+        scores = scores.masked_fill(attn_mask.unsqueeze(1), -1e9)
+        context = ops.bmm_small(torch.softmax(scores, dim=-1).view(B * heads, T, S), flat(v_s)).view(B, heads, T, -1)
+    else:
+        scores = torch.matmul(q_s, k_s.transpose(-1, -2)) / np.sqrt(q_s.size(-1))
+        scores = scores.masked_fill(attn_mask.unsqueeze(1), -1e9)
+        context = torch.matmul(torch.softmax(scores, dim=-1), v_s)
     context = context.transpose(1, 2).contiguous().view(B, -1, hidden_channels)
     return module.layer_norm(module.linear(context) + Q)
 

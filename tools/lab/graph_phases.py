@@ -71,6 +71,17 @@ def full():
     model.zero_grad(set_to_none=True)
     torch.nn.functional.cross_entropy(model(batch), tgt).backward()
 tf_inputs()
+if len(sys.argv) > 1 and sys.argv[1] == "dec":
+    tfm = model.model
+    enc_out = torch.randn(n, 230, 256, device="cuda"); enc_mask = torch.zeros(n, 1, 230, dtype=torch.bool, device="cuda")
+    def dec():
+        model.zero_grad(set_to_none=True)
+        e = enc_out.detach().requires_grad_(True)
+        d = tfm.decoder(ld["smiIndices_input"], e, enc_mask, 200, torch.ones(n, 3, device="cuda"))
+        torch.nn.functional.cross_entropy(tfm.projection(d)[:, 1:].reshape(-1, 116), tgt).backward()
+    timed("decoder + projection + CE fwd+bwd", dec)
+    timed("decoder + projection + CE fwd+bwd (again)", dec)
+    sys.exit(0)
 timed("embedding forward (no grad)", emb_fwd)
 timed("embedding forward + backward", emb_fwd_bwd)
 timed("transformer forward (no grad)", tf_fwd)
