@@ -135,6 +135,16 @@ int singa_gather_wsum_bwd(const float* g, const float* alpha, const float* wv, c
 int singa_bias_ssp_fwd(const float* u, const float* b, float* y, long long M, int n, void* stream);
 int singa_bias_ssp_bwd(const float* u, const float* b, const float* g, float* gu, long long M, int n, void* stream);
 
+/* k16 — y = LayerNorm(a + r) over rows of C = 256 channels, r optional (NULL): the residual LayerNorms of the CProMG
+ * transformer (reference model/CProMG.py:78, 105, 158, 176, 191, 264; torch.nn.LayerNorm: biased variance, eps inside the
+ * root).  Backward: gs[M,C] = gradient w.r.t. the sum a + r (the gradient of both), part[singa_ln256_nparts(M)][2C] =
+ * per-wavefront partial sums [d gamma | d beta] to be reduced with singa_colsum. */
+int singa_ln256_nparts(long long M);
+int singa_ln256_fwd(const float* a, const float* r, const float* gamma, const float* beta, float* y, long long M, int C,
+                    float eps, void* stream);
+int singa_ln256_bwd(const float* a, const float* r, const float* gamma, const float* g, float* gs, float* part, long long M,
+                    int C, float eps, void* stream);
+
 /* k6a — LayerNorm over C = 16 channels followed by SiLU: the `nn.LayerNorm`, `nn.SiLU` pair inside RadialFunction
  * (reference model/EF_layers.py:1634-1657, net.1/net.2 and net.4/net.5).  x, out, g_out, g_x: [M, C] contiguous; biased
  * variance, eps inside the root (torch.nn.LayerNorm).  The backward recomputes the statistics and writes per-thread

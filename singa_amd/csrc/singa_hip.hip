@@ -920,6 +920,79 @@ __global__ void __launch_bounds__(256) bias_ssp_bwd_kernel(const float* __restri
 }
 
 
+// ------------------------------------------------------------------------------------------------ LayerNorm(256) + residual
+// y = LayerNorm(a + r) over rows of C = 256 channels (r optional): every residual LayerNorm of the CProMG transformer
+// (CP:78, 105, 158, 176, 191, 264).  One wavefront per row, four consecutive channels per lane; the sum a + r is never
+// written.  The backward recomputes the statistics from a (+ r), returns the gradient of the sum (it is the gradient of
+// both summands) and per-wave partial sums [waves][2C] = [d gamma | d beta] for singa_colsum.
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void ln256_row(const float* __restrict__ a, const float* __restrict__ r, long long row, int lane,
+                                          float (&xh)[4], float& rstd, float eps) {
+    float4 v = *reinterpret_cast<const float4*>(a + row * 256 + lane * 4);
+    if (r) {
+        const float4 w = *reinterpret_cast<const float4*>(r + row * 256 + lane * 4);
+        v.x += w.x, v.y += w.y, v.z += w.z, v.w += w.w;
+    }
+    const float mean = wave_sum64((v.x + v.y) + (v.z + v.w)) * (1.f / 256);
+    xh[0] = v.x - mean, xh[1] = v.y - mean, xh[2] = v.z - mean, xh[3] = v.w - mean;
+    const float var = wave_sum64((xh[0] * xh[0] + xh[1] * xh[1]) + (xh[2] * xh[2] + xh[3] * xh[3])) * (1.f / 256);
+    rstd = 1.f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xh[i] *= rstd;
+}
+
+__global__ void __launch_bounds__(256) ln256_fwd_kernel(const float* __restrict__ a, const float* __restrict__ r,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float* __restrict__ y, long long M, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + lane * 4), bt = *reinterpret_cast<const float4*>(beta + lane * 4);
+    for (long long row = wave; row < M; row += nwaves) {
+        float xh[4], rstd;
+        ln256_row(a, r, row, lane, xh, rstd, eps);
+        *reinterpret_cast<float4*>(y + row * 256 + lane * 4) =
+            make_float4(fmaf(xh[0], gm.x, bt.x), fmaf(xh[1], gm.y, bt.y), fmaf(xh[2], gm.z, bt.z), fmaf(xh[3], gm.w, bt.w));
+    }
+}
+
+__global__ void __launch_bounds__(256) ln256_bwd_kernel(const float* __restrict__ a, const float* __restrict__ r,
+                                                        const float* __restrict__ gamma, const float* __restrict__ g,
+                                                        float* __restrict__ gs, float* __restrict__ part, long long M,
+                                                        float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    const float4 gm4 = *reinterpret_cast<const float4*>(gamma + lane * 4);
+    const float gm[4] = {gm4.x, gm4.y, gm4.z, gm4.w};
+    float ag[4] = {0.f, 0.f, 0.f, 0.f}, ab[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long row = wave; row < M; row += nwaves) {
+        float xh[4], rstd;
+        ln256_row(a, r, row, lane, xh, rstd, eps);
+        const float4 g4 = *reinterpret_cast<const float4*>(g + row * 256 + lane * 4);
+        float gh[4] = {g4.x, g4.y, g4.z, g4.w};
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            ag[i] = fmaf(gh[i], xh[i], ag[i]);
+            ab[i] += gh[i];
+            gh[i] *= gm[i];
+            s1 += gh[i];
+            s2 = fmaf(gh[i], xh[i], s2);
+        }
+        const float m1 = wave_sum64(s1) * (1.f / 256), m2 = wave_sum64(s2) * (1.f / 256);
+        *reinterpret_cast<float4*>(gs + row * 256 + lane * 4) =
+            make_float4(rstd * (gh[0] - m1 - xh[0] * m2), rstd * (gh[1] - m1 - xh[1] * m2), rstd * (gh[2] - m1 - xh[2] * m2),
+                        rstd * (gh[3] - m1 - xh[3] * m2));
+    }
+    *reinterpret_cast<float4*>(part + wave * 512 + lane * 4) = make_float4(ag[0], ag[1], ag[2], ag[3]);
+    *reinterpret_cast<float4*>(part + wave * 512 + 256 + lane * 4) = make_float4(ab[0], ab[1], ab[2], ab[3]);
+}
+
+
 // ------------------------------------------------------------------------------------------------ column sums
 // out[j] = sum_i x[i*ld + j]: bias / broadcast gradients.  A fixed-shape reduction tree: every pass lets one thread add up
 // to COLSUM_R rows of one column (consecutive threads = consecutive columns, so loads coalesce), passes repeat until one
@@ -1843,6 +1916,32 @@ int singa_bias_ssp_bwd(const float* u, const float* b, const float* g, float* gu
     hipLaunchKernelGGL(bias_ssp_bwd_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, b, g, gu,
                        total4, n);
     return check_launch("bias_ssp_bwd");
+}
+
+int singa_ln256_nparts(long long M) {
+    long long blocks = (M + 3) / 4;
+    return (int)(blocks < 1 ? 1 : (blocks < 512 ? blocks : 512)) * 4;       // wavefronts = rows of the partial buffer
+}
+
+int singa_ln256_fwd(const float* a, const float* r, const float* gamma, const float* beta, float* y, long long M, int C,
+                    float eps, void* stream) {
+    if (!a || !gamma || !beta || !y) return fail(SINGA_E_NULL, "ln256_fwd: null pointer");
+    if (C != 256) return fail(SINGA_E_SHAPE, "ln256: built for rows of 256 channels");
+    if (M <= 0) return SINGA_OK;
+    long long blocks = (M + 3) / 4;
+    hipLaunchKernelGGL(ln256_fwd_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, a, r,
+                       gamma, beta, y, M, eps);
+    return check_launch("ln256_fwd");
+}
+
+int singa_ln256_bwd(const float* a, const float* r, const float* gamma, const float* g, float* gs, float* part, long long M,
+                    int C, float eps, void* stream) {
+    if (!a || !gamma || !g || !gs || !part) return fail(SINGA_E_NULL, "ln256_bwd: null pointer");
+    if (C != 256) return fail(SINGA_E_SHAPE, "ln256: built for rows of 256 channels");
+    if (M <= 0) return SINGA_OK;
+    hipLaunchKernelGGL(ln256_bwd_kernel, dim3(singa_ln256_nparts(M) / 4), dim3(256), 0, (hipStream_t)stream, a, r, gamma, g, gs,
+                       part, M, eps);
+    return check_launch("ln256_bwd");
 }
 
 long long singa_colsum_work(long long M, int n) {

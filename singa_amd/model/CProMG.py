@@ -196,7 +196,7 @@ class MultiHeadAttention(nn.Module):
         S = ops.gather_wsum(alpha, W_v, h_values, edges)                         # [N, heads, 64]
         aggr_msg = ops.linear(S, self.weight_v_lin.weight, self.weight_v_lin.bias).view(N, -1)
         out = self.centroid_lin(node_attr) + aggr_msg
-        return self.layer_norm(self.out_transform(self.act(out)))
+        return ops.layer_norm_residual(self.out_transform(self.act(out)), None, self.layer_norm)
 
 
 def _dense_attention(module, Q, K, V, attn_mask, key_channels, hidden_channels):
@@ -215,7 +215,7 @@ def _dense_attention(module, Q, K, V, attn_mask, key_channels, hidden_channels):
         scores = scores.masked_fill(attn_mask.unsqueeze(1), -1e9)
         context = torch.matmul(torch.softmax(scores, dim=-1), v_s)
     context = context.transpose(1, 2).contiguous().view(B, -1, hidden_channels)
-    return module.layer_norm(module.linear(context) + Q)
+    return ops.layer_norm_residual(module.linear(context), Q, module.layer_norm)
 
 
 class MultiHeadAttention2(nn.Module):
@@ -262,7 +262,7 @@ class PoswiseFeedForwardNet(nn.Module):
 
     def forward(self, inputs):
         h = F.relu(ops.linear(inputs, self.conv1.weight[:, :, 0], self.conv1.bias))
-        return self.layer_norm(ops.linear(h, self.conv2.weight[:, :, 0], self.conv2.bias) + inputs)
+        return ops.layer_norm_residual(ops.linear(h, self.conv2.weight[:, :, 0], self.conv2.bias), inputs, self.layer_norm)
 
 
 class PoswiseFeedForwardDeNet(nn.Module):
@@ -274,7 +274,7 @@ class PoswiseFeedForwardDeNet(nn.Module):
 
     def forward(self, inputs):
         h = F.relu(ops.linear(inputs, self.conv1.weight[:, :, 0], self.conv1.bias))
-        return self.layer_norm(ops.linear(h, self.conv2.weight[:, :, 0], self.conv2.bias) + inputs)
+        return ops.layer_norm_residual(ops.linear(h, self.conv2.weight[:, :, 0], self.conv2.bias), inputs, self.layer_norm)
 
 
 class PositionalEncoding(nn.Module):
@@ -323,7 +323,7 @@ class EncoderLayer2(nn.Module):
                 before_cross(idx)
             kv = self.proj(atom_msa_outputs[idx])
             cross = self.cross_attn(dm.dense(msa_outputs), kv, kv, atom_mask)
-            msa_outputs = self.layer_norm(msa_outputs + cross.reshape(-1, cross.size(-1)).index_select(0, dm.idx))
+            msa_outputs = ops.layer_norm_residual(msa_outputs, cross.reshape(-1, cross.size(-1)).index_select(0, dm.idx), self.layer_norm)
         return self.pos_ffn(msa_outputs)
 
 

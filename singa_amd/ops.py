@@ -580,6 +580,43 @@ def ln_silu(x, gamma, beta, eps=1e-5):
     return _LnSilu.apply(x, gamma, beta, eps)
 
 
+class _LayerNorm256(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, r, gamma, beta, eps):
+        a = a.contiguous()
+        r = r.contiguous() if r is not None else None
+        gamma, beta = gamma.contiguous(), beta.contiguous()
+        _dev(a, gamma, beta)
+        M = a.numel() // 256
+        y = torch.empty_like(a)
+        _chk(_lib.lib().singa_ln256_fwd(_p(a), _p(r) if r is not None else None, _p(gamma), _p(beta), _p(y), M, 256, eps,
+                                        _stream()), "singa_ln256_fwd")
+        ctx.save_for_backward(a, r, gamma)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        a, r, gamma = ctx.saved_tensors
+        g = g.contiguous()
+        M = a.numel() // 256
+        lib = _lib.lib()
+        gs = torch.empty_like(a)
+        part = torch.empty(lib.singa_ln256_nparts(M), 512, device=a.device, dtype=torch.float32)
+        _chk(lib.singa_ln256_bwd(_p(a), _p(r) if r is not None else None, _p(gamma), _p(g), _p(gs), _p(part), M, 256, ctx.eps,
+                                 _stream()), "singa_ln256_bwd")
+        gg = colsum(part)
+        return gs, (gs if r is not None else None), gg[:256], gg[256:], None
+
+
+def layer_norm_residual(a, r, ln):
+    """ln(a + r) for an nn.LayerNorm `ln` (r may be None).  256-channel rows on the GPU take the fused kernel (k16): the sum
+    is never materialised and the backward is one pass + a column sum."""
+    if a.is_cuda and a.shape[-1] == 256 and tuple(ln.normalized_shape) == (256,) and (r is None or r.shape == a.shape):
+        return _LayerNorm256.apply(a, r, ln.weight, ln.bias, ln.eps)
+    return ln(a if r is None else a + r)
+
+
 class _BiasSsp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, b):

@@ -383,3 +383,24 @@ def test_bias_ssp_matches_torch():
     assert float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
     for a, c in zip(got_g, want_g):
         assert float((a - c).abs().max()) < 1e-4 * float(c.abs().max())
+
+
+@pytest.mark.parametrize("M,res", [(1, True), (6432, True), (6400, False), (5, False)])
+def test_layer_norm_256_residual_matches_torch(M, res):
+    """k16 against torch.nn.LayerNorm on a + r: output and gradients w.r.t. a, r, gamma, beta."""
+    from singa_amd import ops
+    torch.manual_seed(M)
+    ln = torch.nn.LayerNorm(256, device="cuda")
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(256)), ln.bias.copy_(torch.randn(256))
+    a = (torch.randn(M, 256, device="cuda") * 3).requires_grad_(True)
+    r = torch.randn(M, 256, device="cuda", requires_grad=True) if res else None
+    g = torch.randn(M, 256, device="cuda")
+    ins = (a, r, ln.weight, ln.bias) if res else (a, ln.weight, ln.bias)
+    want = ln(a + r if res else a)
+    want_g = torch.autograd.grad(want, ins, g)
+    got = ops.layer_norm_residual(a, r, ln)
+    got_g = torch.autograd.grad(got, ins, g)
+    assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
+    for x, y in zip(got_g, want_g):
+        assert float((x - y).abs().max()) < 1e-4 * max(1e-3, float(y.abs().max())), x.shape
