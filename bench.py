@@ -275,6 +275,7 @@ def main():
         big = max(r[1] for r in recs)                     # dispatches with the most edges = the protein-protein passes
         sel = [r for r in recs if r[1] == big]
         ms = sum(r[0] for r in sel) / len(sel)
+        log("k10 forward launches on the bonded edges (us): " + " ".join(f"{r[0] * 1e3:.1f}" for r in sel))
         E, N = sel[0][1], sel[0][2]
         by = k10_algorithmic_bytes(E, N, L)
         ach = by / (ms * 1e-3) / 1e9
