@@ -66,3 +66,21 @@ def shard_range(n_items, rank, world):
     base, rem = divmod(n_items, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_ranges_by_cost(costs, world):
+    """Contiguous shards [lo, hi) per rank balanced by a per-graph cost (the number of edges
+    E_pp + E_ll + 2 E_x drives the step time, not the graph count).  Greedy prefix split: rank r ends where the running
+    cost passes (r+1)/world of the total; every rank gets at least one graph when there are enough."""
+    n = len(costs)
+    total = float(sum(costs))
+    bounds, acc, r = [0], 0.0, 1
+    for i, c in enumerate(costs):
+        acc += float(c)
+        if r < world and acc >= total * r / world and n - (i + 1) >= world - r:
+            bounds.append(i + 1)
+            r += 1
+    while len(bounds) < world:
+        bounds.append(max(bounds[-1], n - (world - len(bounds))))
+    bounds.append(n)
+    return [(bounds[k], bounds[k + 1]) for k in range(world)]

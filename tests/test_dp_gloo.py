@@ -81,3 +81,17 @@ def test_shard_range_covers_everything():
             assert all(parts[i][1] == parts[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in parts]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_ranges_by_cost():
+    from singa_amd.dp import shard_range, shard_ranges_by_cost
+    costs = [10, 10, 10, 10, 40, 40, 10, 10, 10, 10]                  # two heavy graphs in the middle
+    r = shard_ranges_by_cost(costs, 4)
+    assert r[0][0] == 0 and r[-1][1] == len(costs) and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    loads = [sum(costs[lo:hi]) for lo, hi in r]
+    by_count = [sum(costs[slice(*shard_range(len(costs), k, 4))]) for k in range(4)]
+    assert max(loads) <= max(by_count) and all(hi > lo for lo, hi in r)
+    assert shard_ranges_by_cost([5, 5, 5], 3) == [(0, 1), (1, 2), (2, 3)]
+    assert shard_ranges_by_cost([1, 1, 1, 1], 1) == [(0, 4)]
+    one_heavy = shard_ranges_by_cost([100, 1, 1, 1], 4)
+    assert one_heavy == [(0, 1), (1, 2), (2, 3), (3, 4)]
