@@ -169,15 +169,11 @@ class MultiHeadAttention(nn.Module):
         N, heads = h.shape[0], self.num_heads
         w = conv.weight[:, :, 0]
         og, ig = w.shape[0] // heads, w.shape[1]
-        if h.is_cuda:
-            return ops.grouped_linear(h, w.view(heads, og, ig))
-        return torch.bmm(h.view(N, heads, ig).transpose(0, 1), w.view(heads, og, ig).transpose(1, 2)).transpose(0, 1)
+        return ops.grouped_linear(h, w.view(heads, og, ig))
 
     def _edge_mlp(self, net, x):
-        if x.is_cuda and net[0].out_features % 4 == 0:
-            # first Linear as a plain GEMM, its bias inside the activation kernel (one pass instead of three)
-            return net[2](ops.bias_ssp(ops.linear(x, net[0].weight), net[0].bias))
-        return net[2](self.act(net[0](x)))
+        # first Linear as a plain GEMM, its bias inside the activation kernel (one pass instead of three)
+        return net[2](ops.bias_ssp(ops.linear(x, net[0].weight), net[0].bias))
 
     def forward(self, node_attr, edges: KnnEdges):
         """CP:50-78.  weight_k_lin and weight_v_lin act on the last axis only, so they commute with the per-edge
@@ -204,16 +200,11 @@ def _dense_attention(module, Q, K, V, attn_mask, key_channels, hidden_channels):
     q_s = module.W_Q(Q).view(B, -1, heads, key_channels // heads).transpose(1, 2)
     k_s = module.W_K(K).view(B, -1, heads, key_channels // heads).transpose(1, 2)
     v_s = module.W_V(V).view(B, -1, heads, hidden_channels // heads).transpose(1, 2)
-    if Q.is_cuda:
-        T, S = q_s.size(2), k_s.size(2)
-        flat = lambda t: t.reshape(B * heads, t.size(2), t.size(3))
-        scores = ops.bmm_small(flat(q_s), flat(k_s).transpose(1, 2)).view(B, heads, T, S) / np.sqrt(q_s.size(-1))
-        scores = scores.masked_fill(attn_mask.unsqueeze(1), -1e9)
-        context = ops.bmm_small(torch.softmax(scores, dim=-1).view(B * heads, T, S), flat(v_s)).view(B, heads, T, -1)
-    else:
-        scores = torch.matmul(q_s, k_s.transpose(-1, -2)) / np.sqrt(q_s.size(-1))
-        scores = scores.masked_fill(attn_mask.unsqueeze(1), -1e9)
-        context = torch.matmul(torch.softmax(scores, dim=-1), v_s)
+    T, S = q_s.size(2), k_s.size(2)
+    flat = lambda t: t.reshape(B * heads, t.size(2), t.size(3))
+    scores = ops.bmm_small(flat(q_s), flat(k_s).transpose(1, 2)).view(B, heads, T, S) / np.sqrt(q_s.size(-1))
+    scores = scores.masked_fill(attn_mask.unsqueeze(1), -1e9)
+    context = ops.bmm_small(torch.softmax(scores, dim=-1).view(B * heads, T, S), flat(v_s)).view(B, heads, T, -1)
     context = context.transpose(1, 2).contiguous().view(B, -1, hidden_channels)
     return ops.layer_norm_residual(module.linear(context), Q, module.layer_norm)
 
@@ -492,7 +483,7 @@ class Transformer(nn.Module):
                 aa_laplacian, prop=None, knn=None, aa_knn=None, prep=None):
         B = smiles_index.shape[0]
         prep = prep or {}
-        if not (self.overlap_encoders and node_attr.is_cuda):
+        if not self.overlap_encoders:
             enc_outputs1, enc_pad_mask1, msa_outputs = self.encoder(node_attr, pos, batch, atom_laplacian, B, knn,
                                                                     prep.get("p"))
             enc_outputs2, enc_pad_mask2 = self.encoder2(aa_node_attr, aa_pos, aa_batch, aa_laplacian, enc_pad_mask1,

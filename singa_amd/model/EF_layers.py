@@ -151,7 +151,7 @@ class RadialFunction(nn.Module):
         x, mods, i = inputs, list(self.net), 0
         while i < len(mods):
             m = mods[i]
-            if (isinstance(m, nn.LayerNorm) and x.is_cuda and x.shape[-1] == 16 and i + 1 < len(mods)
+            if (isinstance(m, nn.LayerNorm) and x.shape[-1] == 16 and i + 1 < len(mods)
                     and isinstance(mods[i + 1], nn.SiLU)):
                 x = ops.ln_silu(x, m.weight, m.bias, m.eps)              # net.1+net.2, net.4+net.5 as one kernel each
                 i += 2
@@ -197,14 +197,7 @@ class SO3_LinearV2(nn.Module):
         self._deg = None
 
     def apply_tensor(self, x: Tensor) -> Tensor:
-        if x.is_cuda:
-            return ops.so3_linear(x, self.weight, self.bias, self.lmax)
-        if self._deg is None or self._deg.device != x.device:
-            self._deg = torch.as_tensor(so3.layout(self.lmax, self.lmax).degree, device=x.device, dtype=torch.int64)
-        w = self.weight.index_select(0, self._deg)                               # [K, out, in]
-        out = torch.bmm(x.transpose(0, 1), w.transpose(1, 2)).transpose(0, 1).contiguous()    # [N, K, out]
-        out[:, 0, :] = ops.bias_add(out[:, 0, :], self.bias)                     # bias on l = 0 only (EF:658-659)
-        return out
+        return ops.so3_linear(x, self.weight, self.bias, self.lmax)
 
     def forward(self, input_embedding: SO3_Embedding) -> SO3_Embedding:
         out = self.apply_tensor(input_embedding.embedding)
