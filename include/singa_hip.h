@@ -145,6 +145,24 @@ int singa_ln256_fwd(const float* a, const float* r, const float* gamma, const fl
 int singa_ln256_bwd(const float* a, const float* r, const float* gamma, const float* g, float* gs, float* part, long long M,
                     int C, float eps, void* stream);
 
+/* k17 — one new position of a CProMG decoder layer for every live row of a beam search (reference model/CProMG.py:134-191,
+ * 346-383 evaluated incrementally; the reference's model/BeamSearch.py:82 re-runs the whole decoder on the prefix).  Rows R =
+ * proteins x beams, one workgroup per row.  All weight matrices are passed TRANSPOSED, wT[in][out].  Built for hidden 256,
+ * 4 heads, 32 key / 64 value channels per head, FFN 1024.
+ *   self-attention: wqkv_t[256][512] = [W_Q | W_K | W_V]^T, k_cache[R][4][P][32], v_cache[R][4][P][64]; the new key / value
+ *     are written at *pos (device scalar) and the row attends positions 0..*pos; y = LN(W_O ctx + b_O + x).  P <= 256.
+ *   cross-attention: ck[B][4][32][S] / cv[B][4][S][64] = encoder keys (transposed) / values projected once per protein,
+ *     pad[B][S] != 0 = padding (score -1e9), row r uses protein r / beams; z = LN(W_O ctx + b_O + y).  S <= 1024.
+ *   ffn: out = LN(W_2 relu(W_1 z + b_1) + b_2 + z), w1_t[256][1024], w2_t[1024][256]. */
+int singa_dec_self_attn(const float* x, const float* wqkv_t, const float* bqkv, const float* wo_t, const float* bo,
+                        const float* gamma, const float* beta, float* k_cache, float* v_cache, const long long* pos, int R, int P,
+                        float* y, float eps, void* stream);
+int singa_dec_cross_attn(const float* y, const float* wq_t, const float* bq, const float* ck, const float* cv,
+                         const unsigned char* pad, const float* wo_t, const float* bo, const float* gamma, const float* beta,
+                         int R, int beams, int S, float* z, float eps, void* stream);
+int singa_dec_ffn(const float* z, const float* w1_t, const float* b1, const float* w2_t, const float* b2, const float* gamma,
+                  const float* beta, int R, float* out, float eps, void* stream);
+
 /* k6a — LayerNorm over C = 16 channels followed by SiLU: the `nn.LayerNorm`, `nn.SiLU` pair inside RadialFunction
  * (reference model/EF_layers.py:1634-1657, net.1/net.2 and net.4/net.5).  x, out, g_out, g_x: [M, C] contiguous; biased
  * variance, eps inside the root (torch.nn.LayerNorm).  The backward recomputes the statistics and writes per-thread

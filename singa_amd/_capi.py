@@ -45,6 +45,9 @@ _SIGS = {
     "singa_gather_wsum_bwd": ([P] * 12 + [I32, I32, I32, P], I32),
     "singa_bias_ssp_fwd": ([P] * 3 + [I64, I32, P], I32),
     "singa_bias_ssp_bwd": ([P] * 4 + [I64, I32, P], I32),
+    "singa_dec_self_attn": ([P] * 10 + [I32, I32, P, F32, P], I32),
+    "singa_dec_cross_attn": ([P] * 10 + [I32, I32, I32, P, F32, P], I32),
+    "singa_dec_ffn": ([P] * 7 + [I32, P, F32, P], I32),
     "singa_ln256_nparts": ([I64], I32),
     "singa_ln256_fwd": ([P] * 5 + [I64, I32, F32, P], I32),
     "singa_ln256_bwd": ([P] * 6 + [I64, I32, F32, P], I32),

@@ -994,6 +994,226 @@ __global__ void __launch_bounds__(256) ln256_bwd_kernel(const float* __restrict_
 }
 
 
+// ------------------------------------------------------------------------------------------------ incremental decoder
+// One new position of the CProMG decoder (CP:134-191, 346-383) for every live row of a beam search (rows = proteins x
+// beams, a few dozen): the three sub-blocks of a decoder layer as three kernels, one workgroup of 1024 threads per row.
+// With ~20 rows every library GEMM of the step is a 20-row product that pays a full launch for microseconds of work
+// (~200 launches per token).  Here the input row sits in LDS and the weights are read once per workgroup as TRANSPOSED
+// matrices wT[in][out]: thread (col = t % 256, part = t / 256) accumulates its output channel(s) over a quarter of the
+// input channels (64 lanes read 64 consecutive outputs; sixteen wavefronts keep enough loads in flight for a
+// latency-bound 20-workgroup launch), the four partial sums meet in LDS in a fixed order.
+// Hidden 256, 4 heads, 32 key / 64 value channels per head, FFN 1024 - the shipped configuration.
+__device__ __forceinline__ float wave_max64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// sum over the first four wavefronts (threads 0..255) of a 1024-thread workgroup; every thread calls it
+__device__ __forceinline__ float block_sum_first256(float v, float* red) {
+    if (threadIdx.x < 256) {
+        v = wave_sum64(v);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    const float s = (red[0] + red[1]) + (red[2] + red[3]);
+    __syncthreads();
+    return s;
+}
+
+// LayerNorm(256) of the row held one channel per thread by threads 0..255 (o); result valid in those threads
+__device__ __forceinline__ float block_layer_norm256(float o, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* red, float eps) {
+    const int c = threadIdx.x & 255;
+    const float mean = block_sum_first256(o, red) * (1.f / 256);
+    const float d = o - mean;
+    const float var = block_sum_first256(d * d, red) * (1.f / 256);
+    return d * (1.f / sqrtf(var + eps)) * gamma[c] + beta[c];
+}
+
+// partial[part][j*256 + col] = sum over k in this thread's quarter of in[k] * wT[k*N + j*256 + col], j < NJ (N = 256*NJ)
+template <int NJ>
+__device__ __forceinline__ void gemv_quarter(const float* in, int K, const float* __restrict__ wT, float* partial) {
+    const int col = threadIdx.x & 255, part = threadIdx.x >> 8, kq = K / 4;
+    constexpr int N = 256 * NJ;
+    float acc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[j] = 0.f;
+    const float* w = wT + (long long)part * kq * N + col;
+    const float* x = in + part * kq;
+#pragma unroll 8
+    for (int k = 0; k < kq; ++k) {
+        const float xv = x[k];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[j] = fmaf(xv, w[(long long)k * N + j * 256], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) partial[part * N + j * 256 + col] = acc[j];
+}
+
+__device__ __forceinline__ float sum4(const float* partial, int N, int c) {
+    return (partial[c] + partial[N + c]) + (partial[2 * N + c] + partial[3 * N + c]);
+}
+
+// self-attention sub-block: q,k,v projections of the new position, k/v appended to the caches at `pos`, attention of
+// each head (wavefront h of the first four) over positions 0..pos, output projection + residual + LayerNorm.
+__global__ void __launch_bounds__(1024) dec_self_attn_kernel(const float* __restrict__ x, const float* __restrict__ wqkv_t,
+                                                             const float* __restrict__ bqkv, const float* __restrict__ wo_t,
+                                                             const float* __restrict__ bo, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ kc,
+                                                             float* __restrict__ vc, const long long* __restrict__ pos_ptr, int P,
+                                                             float* __restrict__ y, float eps) {
+    __shared__ float xs[256], qkv[512], ps[4][256], ctx[256], partial[4 * 512], red[4];
+    const int r = blockIdx.x, t = threadIdx.x, c = t & 255, part = t >> 8, h = c >> 6, lane = c & 63;
+    const int pos = (int)pos_ptr[0];
+    if (t < 256) xs[t] = x[(long long)r * 256 + t];
+    __syncthreads();
+    gemv_quarter<2>(xs, 256, wqkv_t, partial);
+    __syncthreads();
+    if (t < 512) {
+        const float v = bqkv[t] + sum4(partial, 512, t);              // [0,128): q   [128,256): k   [256,512): v
+        qkv[t] = v;
+        if (t >= 256) vc[(((long long)r * 4 + (t - 256) / 64) * P + pos) * 64 + (t - 256) % 64] = v;
+        else if (t >= 128) kc[(((long long)r * 4 + (t - 128) / 32) * P + pos) * 32 + (t - 128) % 32] = v;
+    }
+    __syncthreads();
+    if (t < 256) {
+        const float* q = qkv + h * 32;
+        const float* krow = kc + ((long long)r * 4 + h) * P * 32;
+        float sc[4], mx = -INFINITY;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int tt = lane + 64 * m;
+            float sv = -INFINITY;
+            if (tt <= pos) {
+                const float* kr = tt == pos ? qkv + 128 + h * 32 : krow + (long long)tt * 32;
+                float acc = 0.f;
+#pragma unroll
+                for (int d = 0; d < 32; ++d) acc = fmaf(q[d], kr[d], acc);
+                sv = acc * 0.17677669529663687f;       // 1 / sqrt(32)
+            }
+            sc[m] = sv;
+            mx = fmaxf(mx, sv);
+        }
+        mx = wave_max64(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            sc[m] = lane + 64 * m <= pos ? __expf(sc[m] - mx) : 0.f;
+            sum += sc[m];
+        }
+        sum = 1.f / wave_sum64(sum);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) ps[h][lane + 64 * m] = sc[m] * sum;
+    }
+    __syncthreads();
+    {   // context: quarter `part` of the cached positions per thread, the four partial sums meet in LDS
+        const float* vrow = vc + ((long long)r * 4 + h) * P * 64;
+        float a = part == 0 ? ps[h][pos] * qkv[256 + c] : 0.f;
+#pragma unroll 4
+        for (int tt = part; tt < pos; tt += 4) a = fmaf(ps[h][tt], vrow[(long long)tt * 64 + lane], a);
+        partial[part * 256 + c] = a;
+    }
+    __syncthreads();
+    if (t < 256) ctx[t] = sum4(partial, 256, t);
+    __syncthreads();
+    gemv_quarter<1>(ctx, 256, wo_t, partial);
+    __syncthreads();
+    const float o = t < 256 ? bo[t] + xs[t] + sum4(partial, 256, t) : 0.f;
+    const float out = block_layer_norm256(o, gamma, beta, red, eps);
+    if (t < 256) y[(long long)r * 256 + t] = out;
+}
+
+// encoder-decoder attention sub-block: keys ck[B][4][32][S] and values cv[B][4][S][64] were projected once per protein;
+// row r belongs to protein r / beams; pad[B][S] != 0 marks padding positions (score -1e9, as masked_fill in CP:150).
+constexpr int DEC_MAX_S = 1024;
+
+__global__ void __launch_bounds__(1024) dec_cross_attn_kernel(const float* __restrict__ y, const float* __restrict__ wq_t,
+                                                              const float* __restrict__ bq, const float* __restrict__ ck,
+                                                              const float* __restrict__ cv, const unsigned char* __restrict__ pad,
+                                                              const float* __restrict__ wo_t, const float* __restrict__ bo,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              int beams, int S, float* __restrict__ z, float eps) {
+    __shared__ float ys[256], qs[128], ps[4][DEC_MAX_S], ctx[256], partial[4 * 256], red[4], inv[4];
+    const int r = blockIdx.x, t = threadIdx.x, c = t & 255, part = t >> 8, h = c >> 6, lane = c & 63;
+    const long long b = r / beams;
+    if (t < 256) ys[t] = y[(long long)r * 256 + t];
+    __syncthreads();
+    {   // q projection: 128 outputs, eight slices of 32 input channels
+        const int col = t & 127, slice = t >> 7;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int i = slice * 32; i < slice * 32 + 32; ++i) acc = fmaf(ys[i], wq_t[i * 128 + col], acc);
+        partial[slice * 128 + col] = acc;
+    }
+    __syncthreads();
+    if (t < 128) {
+        float acc = bq[t];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8) acc += partial[s8 * 128 + t];
+        qs[t] = acc;
+    }
+    __syncthreads();
+    if (t < 256) {
+        const float* kh = ck + (b * 4 + h) * 32 * (long long)S;
+        float mx = -INFINITY;
+        for (int s = lane; s < S; s += 64) {
+            float acc = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) acc = fmaf(qs[h * 32 + d], kh[(long long)d * S + s], acc);
+            acc = pad[b * S + s] ? -1e9f : acc * 0.17677669529663687f;
+            ps[h][s] = acc;
+            mx = fmaxf(mx, acc);
+        }
+        mx = wave_max64(mx);
+        float sum = 0.f;
+        for (int s = lane; s < S; s += 64) {
+            const float e = __expf(ps[h][s] - mx);
+            ps[h][s] = e;
+            sum += e;
+        }
+        sum = wave_sum64(sum);
+        if (lane == 0) inv[h] = 1.f / sum;
+    }
+    __syncthreads();
+    {
+        const float* vh = cv + (b * 4 + h) * (long long)S * 64;
+        float a = 0.f;
+#pragma unroll 4
+        for (int s = part; s < S; s += 4) a = fmaf(ps[h][s], vh[(long long)s * 64 + lane], a);
+        partial[part * 256 + c] = a;
+    }
+    __syncthreads();
+    if (t < 256) ctx[t] = sum4(partial, 256, t) * inv[h];
+    __syncthreads();
+    gemv_quarter<1>(ctx, 256, wo_t, partial);
+    __syncthreads();
+    const float o = t < 256 ? bo[t] + ys[t] + sum4(partial, 256, t) : 0.f;
+    const float out = block_layer_norm256(o, gamma, beta, red, eps);
+    if (t < 256) z[(long long)r * 256 + t] = out;
+}
+
+// position-wise feed-forward sub-block: 256 -> 1024 (ReLU) -> 256, residual, LayerNorm.
+__global__ void __launch_bounds__(1024) dec_ffn_kernel(const float* __restrict__ z, const float* __restrict__ w1_t,
+                                                       const float* __restrict__ b1, const float* __restrict__ w2_t,
+                                                       const float* __restrict__ b2, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ out, float eps) {
+    __shared__ float zs[256], hs[1024], partial[4 * 1024], red[4];
+    const int r = blockIdx.x, t = threadIdx.x;
+    if (t < 256) zs[t] = z[(long long)r * 256 + t];
+    __syncthreads();
+    gemv_quarter<4>(zs, 256, w1_t, partial);
+    __syncthreads();
+    hs[t] = fmaxf(b1[t] + sum4(partial, 1024, t), 0.f);
+    __syncthreads();
+    gemv_quarter<1>(hs, 1024, w2_t, partial);
+    __syncthreads();
+    const float o = t < 256 ? b2[t] + zs[t] + sum4(partial, 256, t) : 0.f;
+    const float res = block_layer_norm256(o, gamma, beta, red, eps);
+    if (t < 256) out[(long long)r * 256 + t] = res;
+}
+
+
 // ------------------------------------------------------------------------------------------------ column sums
 // out[j] = sum_i x[i*ld + j]: bias / broadcast gradients.  A fixed-shape reduction tree: every pass lets one thread add up
 // to COLSUM_R rows of one column (consecutive threads = consecutive columns, so loads coalesce), passes repeat until one
@@ -1943,6 +2163,39 @@ int singa_ln256_bwd(const float* a, const float* r, const float* gamma, const fl
     hipLaunchKernelGGL(ln256_bwd_kernel, dim3(singa_ln256_nparts(M) / 4), dim3(256), 0, (hipStream_t)stream, a, r, gamma, g, gs,
                        part, M, eps);
     return check_launch("ln256_bwd");
+}
+
+int singa_dec_self_attn(const float* x, const float* wqkv_t, const float* bqkv, const float* wo_t, const float* bo,
+                        const float* gamma, const float* beta, float* k_cache, float* v_cache, const long long* pos, int R, int P,
+                        float* y, float eps, void* stream) {
+    if (!x || !wqkv_t || !bqkv || !wo_t || !bo || !gamma || !beta || !k_cache || !v_cache || !pos || !y)
+        return fail(SINGA_E_NULL, "dec_self_attn: null pointer");
+    if (P <= 0 || P > 256) return fail(SINGA_E_SHAPE, "dec_self_attn: built for at most 256 cached positions");
+    if (R <= 0) return SINGA_OK;
+    hipLaunchKernelGGL(dec_self_attn_kernel, dim3(R), dim3(1024), 0, (hipStream_t)stream, x, wqkv_t, bqkv, wo_t, bo, gamma, beta,
+                       k_cache, v_cache, pos, P, y, eps);
+    return check_launch("dec_self_attn");
+}
+
+int singa_dec_cross_attn(const float* y, const float* wq_t, const float* bq, const float* ck, const float* cv,
+                         const unsigned char* pad, const float* wo_t, const float* bo, const float* gamma, const float* beta,
+                         int R, int beams, int S, float* z, float eps, void* stream) {
+    if (!y || !wq_t || !bq || !ck || !cv || !pad || !wo_t || !bo || !gamma || !beta || !z)
+        return fail(SINGA_E_NULL, "dec_cross_attn: null pointer");
+    if (S <= 0 || S > DEC_MAX_S) return fail(SINGA_E_SHAPE, "dec_cross_attn: built for at most 1024 encoder positions");
+    if (beams <= 0 || R % beams) return fail(SINGA_E_SHAPE, "dec_cross_attn: rows must be proteins x beams");
+    if (R <= 0) return SINGA_OK;
+    hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(R), dim3(1024), 0, (hipStream_t)stream, y, wq_t, bq, ck, cv, pad, wo_t, bo, gamma,
+                       beta, beams, S, z, eps);
+    return check_launch("dec_cross_attn");
+}
+
+int singa_dec_ffn(const float* z, const float* w1_t, const float* b1, const float* w2_t, const float* b2, const float* gamma,
+                  const float* beta, int R, float* out, float eps, void* stream) {
+    if (!z || !w1_t || !b1 || !w2_t || !b2 || !gamma || !beta || !out) return fail(SINGA_E_NULL, "dec_ffn: null pointer");
+    if (R <= 0) return SINGA_OK;
+    hipLaunchKernelGGL(dec_ffn_kernel, dim3(R), dim3(1024), 0, (hipStream_t)stream, z, w1_t, b1, w2_t, b2, gamma, beta, out, eps);
+    return check_launch("dec_ffn");
 }
 
 long long singa_colsum_work(long long M, int n) {

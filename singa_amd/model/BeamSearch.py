@@ -22,6 +22,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .. import ops
+
 
 class BeamHypotheses(object):
     """The `num_beams` best finished sequences of one protein (BS:7-35)."""
@@ -67,8 +69,12 @@ class KVDecoder:
     the chosen tokens, all decoder layers, vocabulary projection, log-softmax, candidate top-k) is therefore one HIP
     graph, captured once per search and replayed per token."""
 
-    def __init__(self, decoder, projection, enc_outputs, enc_pad_mask, beams, max_positions, vocab_size):
+    def __init__(self, decoder, projection, enc_outputs, enc_pad_mask, beams, max_positions, vocab_size, fused=True):
         self.dec, self.proj, self.beams, self.V = decoder, projection, beams, vocab_size
+        a0, f0 = decoder.layers[0].dec_self_attn, decoder.layers[0].pos_ffn
+        # the step kernels are built for the shipped decoder geometry; anything else takes the library path
+        self.fused = bool(fused and a0.hidden_channels == 256 and a0.key_channels == 128 and a0.num_heads == 4
+                          and f0.conv1.out_channels == 1024 and max_positions <= 256 and enc_outputs.shape[1] <= 1024)
         B, S, _ = enc_outputs.shape
         a0 = decoder.layers[0].dec_self_attn
         self.heads = a0.num_heads
@@ -82,6 +88,22 @@ class KVDecoder:
             self.cross_k.append(c.W_K(enc_outputs).view(B, S, self.heads, self.dk).permute(0, 2, 3, 1).contiguous())
             self.cross_v.append(c.W_V(enc_outputs).view(B, S, self.heads, self.dv).transpose(1, 2).contiguous())
         self.cross_mask = enc_pad_mask.view(B, 1, 1, S)
+        self.pad_u8 = enc_pad_mask.reshape(B, S).to(torch.uint8).contiguous()
+        # the layers' weights as the fused step kernels (k17) read them: transposed, q/k/v concatenated
+        tr = lambda w: w.detach().t().contiguous()
+        self.w = []
+        for layer in decoder.layers:
+            a, c, f = layer.dec_self_attn, layer.dec_enc_attn, layer.pos_ffn
+            self.w.append({
+                "self": dict(wqkv_t=tr(torch.cat([a.W_Q.weight, a.W_K.weight, a.W_V.weight], 0)),
+                             bqkv=torch.cat([a.W_Q.bias, a.W_K.bias, a.W_V.bias]).detach().contiguous(),
+                             wo_t=tr(a.linear.weight), bo=a.linear.bias.detach(), gamma=a.layer_norm.weight.detach(),
+                             beta=a.layer_norm.bias.detach(), eps=a.layer_norm.eps),
+                "cross": dict(wq_t=tr(c.W_Q.weight), bq=c.W_Q.bias.detach(), wo_t=tr(c.linear.weight), bo=c.linear.bias.detach(),
+                              gamma=c.layer_norm.weight.detach(), beta=c.layer_norm.bias.detach(), eps=c.layer_norm.eps),
+                "ffn": dict(w1_t=tr(f.conv1.weight[:, :, 0]), b1=f.conv1.bias.detach(), w2_t=tr(f.conv2.weight[:, :, 0]),
+                            b2=f.conv2.bias.detach(), gamma=f.layer_norm.weight.detach(), beta=f.layer_norm.bias.detach(),
+                            eps=f.layer_norm.eps)})
         n = len(decoder.layers)
         self.k = torch.zeros(n, self.R, self.heads, max_positions, self.dk, device=dev)
         self.v = torch.zeros(n, self.R, self.heads, max_positions, self.dv, device=dev)
@@ -113,6 +135,14 @@ class KVDecoder:
 
     def advance(self, x):
         """x [rows, hidden]: decoder input at position `pos` -> decoder output at that position; pos += 1."""
+        if self.fused:
+            # three hand-written launches per layer (singa_dec_*): q/k/v + cache append + attention + projection + LayerNorm,
+            # encoder-decoder attention, feed-forward - instead of ~33 library / elementwise launches on 20-row operands
+            for l in range(len(self.dec.layers)):
+                x = ops.dec_layer_step(x.contiguous(), self.w[l], self.k[l], self.v[l], self.pos, self.cross_k[l],
+                                       self.cross_v[l], self.pad_u8, self.beams)
+            self.pos += 1
+            return x
         R, B, H = self.R, self.B, self.heads
         unwritten = (self.slots > self.pos).view(1, 1, 1, self.P)
         for l, layer in enumerate(self.dec.layers):
@@ -212,11 +242,12 @@ def _select(cand_score, cand_flat, prefixes, hyps, done, num_beams, vocab_size, 
 
 @torch.no_grad()
 def beam_search(model, smiVoc, num_beams, batch_size, max_length, topk, example, prop=None, device="cuda", trace=None,
-                graph=True):
+                graph=True, fused=True):
     """BS:38-175.  `model`: SINGA (uses model.model.encoder / decoder / projection); `example`: attribute bag with
     protein_element_batch, protein_atom_feature, protein_pos, protein_atom_laplacian (gen.py:176-181) and, optionally,
     protein_knn (a precomputed [2,E] kNN list; otherwise drawn on the GPU); `prop` [batch_size*num_beams, num_props].
-    `graph=False` launches the step's kernels one by one instead of replaying the captured HIP graph (same numbers).
+    `graph=False` launches the step's kernels one by one instead of replaying the captured HIP graph (same numbers);
+    `fused=False` evaluates the decoder layers with library GEMMs / elementwise ops instead of the k17 step kernels.
     Returns the decoded int64 token matrix [batch_size*topk, T] on `device`."""
     tf = model.model
     vocab_size = len(smiVoc)
@@ -229,7 +260,7 @@ def beam_search(model, smiVoc, num_beams, batch_size, max_length, topk, example,
                                               getattr(example, "protein_knn", None))
     rows = batch_size * num_beams
     num = 1 if tf.decoder.num_props else 0
-    kv = KVDecoder(tf.decoder, tf.projection, enc_outputs, enc_pad_mask, num_beams, max_length + num, vocab_size)
+    kv = KVDecoder(tf.decoder, tf.projection, enc_outputs, enc_pad_mask, num_beams, max_length + num, vocab_size, fused)
     if graph:
         kv.capture()
     if num:

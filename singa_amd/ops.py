@@ -580,6 +580,24 @@ def ln_silu(x, gamma, beta, eps=1e-5):
     return _LnSilu.apply(x, gamma, beta, eps)
 
 
+def dec_layer_step(x, w, k_cache, v_cache, pos, cross_k, cross_v, pad, beams):
+    """One decoder layer for one new position of every beam-search row (k17; inference only, no autograd): three launches.
+    `w`: dict of the layer's transposed weights as built by BeamSearch.KVDecoder; k_cache [R,4,P,32], v_cache [R,4,P,64];
+    pos: int64 device scalar; cross_k [B,4,32,S], cross_v [B,4,S,64], pad [B,S] uint8."""
+    _dev(x, k_cache, v_cache, cross_k, cross_v)
+    lib, st = _lib.lib(), _stream()
+    R, P, S = x.shape[0], k_cache.shape[2], cross_v.shape[2]
+    y, z, out = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    a, c, f = w["self"], w["cross"], w["ffn"]
+    _chk(lib.singa_dec_self_attn(_p(x), _p(a["wqkv_t"]), _p(a["bqkv"]), _p(a["wo_t"]), _p(a["bo"]), _p(a["gamma"]), _p(a["beta"]),
+                                 _p(k_cache), _p(v_cache), _p(pos), R, P, _p(y), a["eps"], st), "singa_dec_self_attn")
+    _chk(lib.singa_dec_cross_attn(_p(y), _p(c["wq_t"]), _p(c["bq"]), _p(cross_k), _p(cross_v), _p(pad), _p(c["wo_t"]), _p(c["bo"]),
+                                  _p(c["gamma"]), _p(c["beta"]), R, beams, S, _p(z), c["eps"], st), "singa_dec_cross_attn")
+    _chk(lib.singa_dec_ffn(_p(z), _p(f["w1_t"]), _p(f["b1"]), _p(f["w2_t"]), _p(f["b2"]), _p(f["gamma"]), _p(f["beta"]), R, _p(out),
+                           f["eps"], st), "singa_dec_ffn")
+    return out
+
+
 class _LayerNorm256(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, r, gamma, beta, eps):

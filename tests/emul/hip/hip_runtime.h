@@ -48,6 +48,12 @@ static inline float __shfl_xor(float, int, int) {
     abort();
 }
 
+#define __shared__ static
+static inline void __syncthreads() {
+    fprintf(stderr, "emul: workgroup-synchronised kernel cannot be emulated sequentially\n");
+    abort();
+}
+
 typedef void* hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t*) { return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }

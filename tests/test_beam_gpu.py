@@ -24,9 +24,10 @@ def build_model(z=None):
     return model, sd, Config
 
 
-@pytest.mark.parametrize("graph", [True, False], ids=["hipgraph", "eager"])
+@pytest.mark.parametrize("graph,fused", [(True, True), (False, True), (True, False), (False, False)],
+                         ids=["hipgraph-k17", "eager-k17", "hipgraph-library", "eager-library"])
 @pytest.mark.parametrize("case", BEAM_CASES)
-def test_beam_search_matches_reference(case, graph):
+def test_beam_search_matches_reference(case, graph, fused):
     from singa_amd.model.BeamSearch import beam_search
     z = golden(f"beam_{case}.npz")
     model, _, Config = build_model(z)
@@ -36,7 +37,7 @@ def test_beam_search_matches_reference(case, graph):
     ex.protein_atom_laplacian, ex.protein_knn = t("lap"), t("knn", torch.long)
     tr = {}
     out = beam_search(model, smi_voc(), int(z["num_beams"]), len(z["names"]), int(z["max_length"]), int(z["topk"]), ex,
-                      t("prop"), device=DEV, trace=tr, graph=graph)
+                      t("prop"), device=DEV, trace=tr, graph=graph, fused=fused)
     assert rel_err(tr["first_logp"].cpu(), z["first_logp"]) < 1e-4
     assert np.array_equal(tr["last_beams"], z["last_beams"])
     assert out.shape == z["decoded"].shape and np.array_equal(out.cpu().numpy(), z["decoded"])
@@ -90,3 +91,28 @@ def test_beam_search_matches_oracle_on_synthetic_protein():
     assert rel_err(c(tr["first_logp"]), tr_o["first_logp"]) < 1e-4
     assert np.array_equal(c(out).numpy(), want.numpy())
     assert np.array_equal(tr["last_beams"], tr_o["last_beams"].numpy())
+
+
+def test_step_kernels_match_library_decoder():
+    """k17 (three launches per decoder layer) against the same layers evaluated with library GEMMs, position by position:
+    decoder outputs and the appended key / value cache rows."""
+    from singa_amd.model.BeamSearch import KVDecoder
+    model, _, _ = build_model()
+    tf = model.model
+    torch.manual_seed(4)
+    B, beams, S, P = 2, 3, 37, 12
+    enc = torch.randn(B, S, 256, device=DEV)
+    pad = torch.zeros(B, 1, S, dtype=torch.bool, device=DEV)
+    pad[0, 0, 30:] = True                                   # ragged proteins: the first one has 30 atoms
+    with torch.no_grad():
+        kv = [KVDecoder(tf.decoder, tf.projection, enc, pad, beams, P, 116, fused=f) for f in (True, False)]
+        assert kv[0].fused and not kv[1].fused
+        for step in range(P):
+            x = torch.randn(B * beams, 256, device=DEV)
+            a, b = kv[0].advance(x), kv[1].advance(x)
+            assert rel_err(a.cpu(), b.cpu()) < 2e-5, step
+            if step % 4 == 3:                               # re-rank the rows as a search step would
+                src = torch.randperm(B * beams, device=DEV) % beams + (torch.arange(B * beams, device=DEV) // beams) * beams
+                kv[0].follow(src), kv[1].follow(src)
+        assert rel_err(kv[0].k[:, :, :, :P].cpu(), kv[1].k[:, :, :, :P].cpu()) < 2e-5
+        assert rel_err(kv[0].v[:, :, :, :P].cpu(), kv[1].v[:, :, :, :P].cpu()) < 2e-5
