@@ -73,6 +73,17 @@ def pmc_traffic(L, n_dst):
     return best
 
 
+def baseline_metric():
+    """The metric string of BASELINE.json, verbatim.  (It says "GAN step (G+D fwd+bwd)"; the reference defines no
+    discriminator - SURVEY.md F2 - so the step measured is the whole training step the reference runs: the generator's
+    forward + CrossEntropy + backward + clip + Adam, train.py:113-133; `config.step` spells it out.)"""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:
+        return "protein-ligand graphs/sec GAN step (G+D fwd+bwd); scatter-TP kernel HBM GB/s"
+
+
 def host_cores():
     """CPU threads this process may really use: min(affinity, cgroup quota), capped at the one-GPU box share."""
     n = os.cpu_count() or 1
@@ -291,14 +302,15 @@ def main():
 
     if rank == 0:
         total_graphs = n_graphs * world * args.steps
-        out = {"metric": "protein-ligand graphs/sec, full SINGA training step (fwd+bwd+Adam); scatter-TP kernel HBM GB/s",
+        out = {"metric": baseline_metric(),
                "value": round(total_graphs / elapsed, 3), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": args.workload, "graphs_per_gpu": n_graphs, "lmax": L, "mmax": 2,
                           "nodes_per_graph": kw["n_protein"] + kw["n_ligand"],
                           "edges_per_graph": kw["e_pp"] + kw["e_ll"] + 2 * kw["e_x"],
-                          "parallelism": f"dp{world}", "step": "prepare+zero_grad+fwd+CE+bwd+allreduce+clip+Adam",
+                          "parallelism": f"dp{world}",
+                          "step": "prepare+zero_grad+fwd+CE+bwd+allreduce+clip+Adam of the generator (the reference has no discriminator)",
                           "launch": "hipGraph replay" if use_graph else "eager",
                           "prepare": "in step" if args.no_prefetch else "prefetched on a second stream during the previous step", "prepare_ms_of_step": round(prepare_ms, 2),
                           "grad_allreduce_bytes": reducer.payload_bytes},
