@@ -745,31 +745,59 @@ __global__ void __launch_bounds__(64) gather_wsum_fwd_kernel(const float* __rest
 }
 
 // g_alpha[e,h] = sum_f g[n,h,f] wv[e,f] hv[col,h,f];  g_wv[e,f] = sum_h g[n,h,f] alpha[e,h] hv[col,h,f].
+// The four per-head sums over the 64 lanes are reduced together: two exchange steps fold the four values into the four
+// lane quarters (quarter q ends up owning head q), four more steps finish the sum inside each quarter - 6 cross-lane
+// steps per edge instead of 24.  Two edges are in flight per iteration, so the second edge's dependent gather
+// (col -> hv row) is issued while the first is reduced.
+__device__ __forceinline__ float quad_reduce4(float t0, float t1, float t2, float t3, int lane) {
+    const bool hi32 = lane & 32, hi16 = lane & 16;
+    // fold over lane bit 5: the lower half keeps heads 0,1, the upper half heads 2,3
+    const float a = (hi32 ? t2 : t0) + __shfl_xor(hi32 ? t0 : t2, 32, 64);
+    const float b = (hi32 ? t3 : t1) + __shfl_xor(hi32 ? t1 : t3, 32, 64);
+    // fold over lane bit 4: quarters own heads 0,1,2,3 in lane order
+    float v = (hi16 ? b : a) + __shfl_xor(hi16 ? a : b, 16, 64);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;                                            // lanes of quarter q: the complete sum of head q
+}
+
 template <int H>
 __global__ void __launch_bounds__(64) gather_wsum_bwd_row_kernel(const float* __restrict__ g, const float* __restrict__ alpha,
                                                                  const float* __restrict__ wv, const float* __restrict__ hv,
                                                                  const int* __restrict__ row_ptr, const int* __restrict__ col,
                                                                  float* __restrict__ g_alpha, float* __restrict__ g_wv, int N) {
+    static_assert(H == 4, "the four-way folded reduction is written for four heads");
     constexpr int F = 64;
-    const int f = threadIdx.x;
+    const int f = threadIdx.x, quarter = f >> 4;
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
         float gn[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) gn[h] = g[((long long)n * H + h) * F + f];
         const int beg = row_ptr[n], end = row_ptr[n + 1];
-        for (int e = beg; e < end; ++e) {
-            const int j = col[e];
-            const float w = wv[(long long)e * F + f];
-            float gw = 0.f;
+        for (int e = beg; e < end; e += 2) {
+            const bool two = e + 1 < end;
+            const int e1 = two ? e + 1 : e;
+            const int j0 = col[e], j1 = col[e1];
+            const float w0 = wv[(long long)e * F + f], w1 = wv[(long long)e1 * F + f];
+            float t0[H], t1[H], gw0 = 0.f, gw1 = 0.f;
 #pragma unroll
             for (int h = 0; h < H; ++h) {
-                const float v = hv[((long long)j * H + h) * F + f];
-                const float t = gn[h] * v;
-                gw = fmaf(t, alpha[(long long)e * H + h], gw);
-                const float pa = group_sum(t * w, 64);
-                if (f == 0) g_alpha[(long long)e * H + h] = pa;
+                t0[h] = gn[h] * hv[((long long)j0 * H + h) * F + f];
+                t1[h] = gn[h] * hv[((long long)j1 * H + h) * F + f];
             }
-            g_wv[(long long)e * F + f] = gw;
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                gw0 = fmaf(t0[h], alpha[(long long)e * H + h], gw0);
+                gw1 = fmaf(t1[h], alpha[(long long)e1 * H + h], gw1);
+            }
+            const float p0 = quad_reduce4(t0[0] * w0, t0[1] * w0, t0[2] * w0, t0[3] * w0, f);
+            const float p1 = quad_reduce4(t1[0] * w1, t1[1] * w1, t1[2] * w1, t1[3] * w1, f);
+            if ((f & 15) == 0) {
+                g_alpha[(long long)e * H + quarter] = p0;
+                if (two) g_alpha[(long long)e1 * H + quarter] = p1;
+            }
+            g_wv[(long long)e * F + f] = gw0;
+            if (two) g_wv[(long long)e1 * F + f] = gw1;
         }
     }
 }
