@@ -610,28 +610,48 @@ __device__ __forceinline__ float group_sum(float v, int width) {  // butterfly o
 }
 
 // One wavefront per centre node; lane = (slot, d) with D lanes per slot and 64/D edge slots; loop over heads.
+// four per-head sums over the 32 lanes of an edge slot, folded: two exchange steps leave head g with lane group g
+// (8 lanes each), three more finish the sum - 5 cross-lane steps instead of 20
+__device__ __forceinline__ float quad_reduce4_half(float t0, float t1, float t2, float t3, int lane) {
+    const bool b4 = lane & 16, b3 = lane & 8;
+    const float a = (b4 ? t2 : t0) + __shfl_xor(b4 ? t0 : t2, 16, 64);
+    const float b = (b4 ? t3 : t1) + __shfl_xor(b4 ? t1 : t3, 16, 64);
+    float v = (b3 ? b : a) + __shfl_xor(b3 ? a : b, 8, 64);
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;                                            // lanes of group g = (lane % 32) / 8: the complete sum of head g
+}
+
 template <int D, int H>
 __global__ void __launch_bounds__(64) edge_logits_fwd_kernel(const float* __restrict__ qp, const float* __restrict__ wk,
                                                              const float* __restrict__ hk, const float* __restrict__ cterm,
                                                              const int* __restrict__ row_ptr, const int* __restrict__ col,
                                                              float* __restrict__ qk, int N, float scale) {
+    static_assert(D == 32 && H == 4, "lane mapping and the folded reduction are written for 32 key channels, 4 heads");
     constexpr int SL = 64 / D;
-    const int lane = threadIdx.x, d = lane % D, slot = lane / D;
+    const int lane = threadIdx.x, d = lane % D, slot = lane / D, grp = d >> 3;
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
         float q[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) q[h] = qp[((long long)n * H + h) * D + d] * scale;
+        const float ct = cterm[(long long)n * H + grp];
         const int beg = row_ptr[n], end = row_ptr[n + 1];
-        for (int e0 = beg; e0 < end; e0 += SL) {
-            const int e = e0 + slot;
-            const bool ok = e < end;
-            const int j = ok ? col[e] : 0;
-            const float w = ok ? wk[(long long)e * D + d] : 0.f;
+        for (int e0 = beg; e0 < end; e0 += 2 * SL) {       // two rounds of SL edges in flight
+            const int ea = e0 + slot, eb = e0 + SL + slot;
+            const bool oka = ea < end, okb = eb < end;
+            const int ja = oka ? col[ea] : 0, jb = okb ? col[eb] : 0;
+            const float wa = oka ? wk[(long long)ea * D + d] : 0.f, wb = okb ? wk[(long long)eb * D + d] : 0.f;
+            float ta[H], tb[H];
 #pragma unroll
             for (int h = 0; h < H; ++h) {
-                float p = ok ? q[h] * w * hk[((long long)j * H + h) * D + d] : 0.f;
-                p = group_sum(p, D);
-                if (ok && d == 0) qk[(long long)e * H + h] = p + cterm[(long long)n * H + h];
+                ta[h] = q[h] * wa * hk[((long long)ja * H + h) * D + d];
+                tb[h] = q[h] * wb * hk[((long long)jb * H + h) * D + d];
+            }
+            const float pa = quad_reduce4_half(ta[0], ta[1], ta[2], ta[3], lane);
+            const float pb = quad_reduce4_half(tb[0], tb[1], tb[2], tb[3], lane);
+            if ((d & 7) == 0) {
+                if (oka) qk[(long long)ea * H + grp] = pa + ct;
+                if (okb) qk[(long long)eb * H + grp] = pb + ct;
             }
         }
     }
@@ -732,7 +752,23 @@ __global__ void __launch_bounds__(64) gather_wsum_fwd_kernel(const float* __rest
 #pragma unroll
         for (int h = 0; h < H; ++h) acc[h] = 0.f;
         const int beg = row_ptr[n], end = row_ptr[n + 1];
-        for (int e = beg; e < end; ++e) {
+        int e = beg;
+        for (; e + 1 < end; e += 2) {                      // two edges in flight: both gathers are issued before either FMA chain
+            const int j0 = col[e], j1 = col[e + 1];
+            const float w0 = wv[(long long)e * F + f], w1 = wv[(long long)(e + 1) * F + f];
+            float v0[H], v1[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                v0[h] = hv[((long long)j0 * H + h) * F + f];
+                v1[h] = hv[((long long)j1 * H + h) * F + f];
+            }
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                acc[h] = fmaf(alpha[(long long)e * H + h] * w0, v0[h], acc[h]);
+                acc[h] = fmaf(alpha[(long long)(e + 1) * H + h] * w1, v1[h], acc[h]);
+            }
+        }
+        if (e < end) {
             const int j = col[e];
             const float w = wv[(long long)e * F + f];
 #pragma unroll
