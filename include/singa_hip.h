@@ -100,11 +100,13 @@ int singa_alpha_logits_bwd(const float* h0, long long ld, const float* ln_w, con
                            const float* g_logits, float* g_x, float* part, int E, int heads, int A, float eps, void* stream);
 
 /* k9 (softmax part) — torch_geometric.utils.softmax / torch_scatter.scatter_softmax over destination segments
- * (EF:1180; CP:66): out = exp(x - segmax) / (segsum + eps).  x, out: [E, H]. */
+ * (EF:1180; CP:66): out = exp(x - segmax) / (segsum + eps).  x, out: [E, H].  dense_segments != 0 (and H == 4) selects the
+ * wavefront-per-segment variant for segments of tens of edges (the kNN graphs of CP:293-298); 0 = thread per (segment, head),
+ * right for the ~8-edge segments of the bonded graphs. */
 int singa_segment_softmax_fwd(const float* x, const int32_t* row_ptr, float* out, int N, int H, float eps,
-                              void* stream);
+                              int dense_segments, void* stream);
 int singa_segment_softmax_bwd(const float* y, const float* gy, const int32_t* row_ptr, float* gx, int N, int H,
-                              void* stream);
+                              int dense_segments, void* stream);
 
 /* k15 — alpha-weighted scatter_sum of per-edge messages (CP:71-74): out[N,H,F] = sum_e w[e,H] * v[e,H,F]. */
 int singa_segment_wsum_fwd(const float* w, const float* v, const int32_t* row_ptr, float* out, int N, int H, int F,

@@ -28,8 +28,8 @@ _SIGS = {
     "singa_alpha_logits_nslots": ([I32], I32),
     "singa_alpha_logits_fwd": ([P, C.c_longlong, P, P, P, P, I32, I32, I32, F32, P], I32),
     "singa_alpha_logits_bwd": ([P, C.c_longlong, P, P, P, P, P, P, I32, I32, I32, F32, P], I32),
-    "singa_segment_softmax_fwd": ([P, P, P, I32, I32, F32, P], I32),
-    "singa_segment_softmax_bwd": ([P, P, P, P, I32, I32, P], I32),
+    "singa_segment_softmax_fwd": ([P, P, P, I32, I32, F32, I32, P], I32),
+    "singa_segment_softmax_bwd": ([P, P, P, P, I32, I32, I32, P], I32),
     "singa_segment_wsum_fwd": ([P, P, P, P, I32, I32, I32, P], I32),
     "singa_segment_wsum_bwd": ([P, P, P, P, P, P, I32, I32, I32, P], I32),
     "singa_s2act_fwd": ([C.POINTER(Seg), I32, P, I64, P, P, P, I32, I32, I32, I32, P], I32),

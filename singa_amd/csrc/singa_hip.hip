@@ -557,6 +557,66 @@ __global__ void segment_softmax_bwd_kernel(const float* __restrict__ y, const fl
     }
 }
 
+// Dense segments (the kNN graphs of the CProMG encoders: ~58 edges per node, 4 heads): one wavefront per node, one edge
+// per lane, the four heads of an edge as one float4 - the per-thread walk above is 3 x 58 dependent loads long.
+__device__ __forceinline__ float wsum64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wmax64(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__global__ void __launch_bounds__(256) segment_softmax4_fwd_kernel(const float* __restrict__ x, const int* __restrict__ row_ptr,
+                                                                   float* __restrict__ y, int N, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int beg = row_ptr[n], end = row_ptr[n + 1];
+    if (beg >= end) return;
+    float m0 = -INFINITY, m1 = -INFINITY, m2 = -INFINITY, m3 = -INFINITY;
+    for (int e = beg + lane; e < end; e += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (long long)e * 4);
+        m0 = fmaxf(m0, v.x), m1 = fmaxf(m1, v.y), m2 = fmaxf(m2, v.z), m3 = fmaxf(m3, v.w);
+    }
+    m0 = wmax64(m0), m1 = wmax64(m1), m2 = wmax64(m2), m3 = wmax64(m3);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int e = beg + lane; e < end; e += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (long long)e * 4);
+        s0 += expf(v.x - m0), s1 += expf(v.y - m1), s2 += expf(v.z - m2), s3 += expf(v.w - m3);
+    }
+    s0 = 1.f / (wsum64(s0) + eps), s1 = 1.f / (wsum64(s1) + eps), s2 = 1.f / (wsum64(s2) + eps), s3 = 1.f / (wsum64(s3) + eps);
+    for (int e = beg + lane; e < end; e += 64) {
+        const float4 v = *reinterpret_cast<const float4*>(x + (long long)e * 4);
+        *reinterpret_cast<float4*>(y + (long long)e * 4) =
+            make_float4(expf(v.x - m0) * s0, expf(v.y - m1) * s1, expf(v.z - m2) * s2, expf(v.w - m3) * s3);
+    }
+}
+
+__global__ void __launch_bounds__(256) segment_softmax4_bwd_kernel(const float* __restrict__ y, const float* __restrict__ gy,
+                                                                   const int* __restrict__ row_ptr, float* __restrict__ gx, int N) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int beg = row_ptr[n], end = row_ptr[n + 1];
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f, d3 = 0.f;
+    for (int e = beg + lane; e < end; e += 64) {
+        const float4 a = *reinterpret_cast<const float4*>(y + (long long)e * 4);
+        const float4 g = *reinterpret_cast<const float4*>(gy + (long long)e * 4);
+        d0 = fmaf(g.x, a.x, d0), d1 = fmaf(g.y, a.y, d1), d2 = fmaf(g.z, a.z, d2), d3 = fmaf(g.w, a.w, d3);
+    }
+    d0 = wsum64(d0), d1 = wsum64(d1), d2 = wsum64(d2), d3 = wsum64(d3);
+    for (int e = beg + lane; e < end; e += 64) {
+        const float4 a = *reinterpret_cast<const float4*>(y + (long long)e * 4);
+        const float4 g = *reinterpret_cast<const float4*>(gy + (long long)e * 4);
+        *reinterpret_cast<float4*>(gx + (long long)e * 4) =
+            make_float4(a.x * (g.x - d0), a.y * (g.y - d1), a.z * (g.z - d2), a.w * (g.w - d3));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ k15: weighted segment sum
 // out[n, t] = sum_e w[e, t / F] * v[e, t];  one workgroup per node, thread t in [0, H*F).
 __global__ void segment_wsum_fwd_kernel(const float* __restrict__ w, const float* __restrict__ v,
@@ -1908,9 +1968,14 @@ int singa_rotate_back_scatter_bwd(const float* g_out, const singa_seg_t* msg, co
 }
 
 int singa_segment_softmax_fwd(const float* x, const int32_t* row_ptr, float* out, int N, int H, float eps,
-                              void* stream) {
+                              int dense_segments, void* stream) {
     if (!x || !row_ptr || !out) return fail(SINGA_E_NULL, "segment_softmax_fwd: null pointer");
     if (N <= 0 || H <= 0) return SINGA_OK;
+    if (H == 4 && dense_segments) {
+        hipLaunchKernelGGL(segment_softmax4_fwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, row_ptr, out, N,
+                           eps);
+        return check_launch("segment_softmax_fwd");
+    }
     int blocks = (int)(((long long)N * H + 255) / 256);
     hipLaunchKernelGGL(segment_softmax_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, row_ptr, out, N,
                        H, eps);
@@ -1918,9 +1983,13 @@ int singa_segment_softmax_fwd(const float* x, const int32_t* row_ptr, float* out
 }
 
 int singa_segment_softmax_bwd(const float* y, const float* gy, const int32_t* row_ptr, float* gx, int N, int H,
-                              void* stream) {
+                              int dense_segments, void* stream) {
     if (!y || !gy || !row_ptr || !gx) return fail(SINGA_E_NULL, "segment_softmax_bwd: null pointer");
     if (N <= 0 || H <= 0) return SINGA_OK;
+    if (H == 4 && dense_segments) {
+        hipLaunchKernelGGL(segment_softmax4_bwd_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, y, gy, row_ptr, gx, N);
+        return check_launch("segment_softmax_bwd");
+    }
     int blocks = (int)(((long long)N * H + 255) / 256);
     hipLaunchKernelGGL(segment_softmax_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, gy, row_ptr, gx,
                        N, H);

@@ -220,7 +220,8 @@ class _SegmentSoftmax(torch.autograd.Function):
         _dev(x, row_ptr)
         y = torch.empty_like(x)
         N = row_ptr.numel() - 1
-        _chk(_lib.lib().singa_segment_softmax_fwd(_p(x), _p(row_ptr), _p(y), N, x.shape[1], eps, _stream()),
+        ctx.dense = int(x.shape[1] == 4 and x.shape[0] >= 16 * N)      # >= 16 edges per segment on average: wave per segment
+        _chk(_lib.lib().singa_segment_softmax_fwd(_p(x), _p(row_ptr), _p(y), N, x.shape[1], eps, ctx.dense, _stream()),
              "singa_segment_softmax_fwd")
         ctx.save_for_backward(y, row_ptr)
         return y
@@ -231,7 +232,7 @@ class _SegmentSoftmax(torch.autograd.Function):
         gy = gy.contiguous()
         gx = torch.empty_like(y)
         N = row_ptr.numel() - 1
-        _chk(_lib.lib().singa_segment_softmax_bwd(_p(y), _p(gy), _p(row_ptr), _p(gx), N, y.shape[1], _stream()),
+        _chk(_lib.lib().singa_segment_softmax_bwd(_p(y), _p(gy), _p(row_ptr), _p(gx), N, y.shape[1], ctx.dense, _stream()),
              "singa_segment_softmax_bwd")
         return gx, None, None
 

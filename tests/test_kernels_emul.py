@@ -166,12 +166,12 @@ def test_segment_softmax(emul, H, eps):
     x = torch.tensor(rs.randn(E, H) * 3, dtype=torch.float32, requires_grad=True)
     ref = O.seg_softmax(x, torch.as_tensor(dst.astype(np.int64)), N, eps)
     y = np.zeros((E, H), np.float32)
-    assert emul.singa_segment_softmax_fwd(ptr(x.detach().numpy()), ptr(row_ptr), ptr(y), N, H, eps, None) == 0
+    assert emul.singa_segment_softmax_fwd(ptr(x.detach().numpy()), ptr(row_ptr), ptr(y), N, H, eps, 0, None) == 0
     assert np.abs(y - ref.detach().numpy()).max() < 1e-6
     g = torch.tensor(rs.randn(E, H), dtype=torch.float32)
     ref.backward(g)
     gx = np.zeros((E, H), np.float32)
-    assert emul.singa_segment_softmax_bwd(ptr(y), ptr(g.numpy()), ptr(row_ptr), ptr(gx), N, H, None) == 0
+    assert emul.singa_segment_softmax_bwd(ptr(y), ptr(g.numpy()), ptr(row_ptr), ptr(gx), N, H, 0, None) == 0
     assert np.abs(gx - x.grad.numpy()).max() < 1e-5
 
 

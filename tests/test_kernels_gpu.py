@@ -155,11 +155,11 @@ def test_edge_degree_scatter(L):
     assert rel(rg.grad, r.grad[order]) < 2e-5
 
 
-@pytest.mark.parametrize("H,eps", [(7, 1e-16), (4, 0.0)])
-def test_segment_softmax(H, eps):
+@pytest.mark.parametrize("H,eps,N,E", [(7, 1e-16, 300, 5000), (4, 0.0, 300, 5000), (4, 0.0, 20, 5000), (4, 1e-16, 300, 900)],
+                         ids=["7heads", "4heads-dense", "4heads-long-segments", "4heads-sparse-with-empty-segments"])
+def test_segment_softmax(H, eps, N, E):
     ops = _ops()
     rs = np.random.RandomState(5)
-    N, E = 300, 5000
     dst = torch.tensor(np.sort(rs.randint(0, N, E)), dtype=torch.int64)
     rp = torch.zeros(N + 1, dtype=torch.int64)
     rp[1:] = torch.bincount(dst, minlength=N).cumsum(0)
