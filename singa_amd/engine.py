@@ -13,18 +13,38 @@ from .graph import E_LL, E_LP, E_PL, E_PP, LA, PA
 from .model import EF_layers
 
 
-def _copy_tree(dst, src):
-    """copy_ every tensor of a nested dict/list structure; returns False on a shape mismatch."""
+def _copy_tree(dst, src, pairs=None):
+    """Copy every tensor of a nested dict/list structure into its counterpart; False on a shape mismatch.  With `pairs`
+    (a list) the (dst, src) tensors are only collected, for one multi-tensor copy afterwards (`_flush_copies`)."""
     if torch.is_tensor(dst):
         if dst.shape != src.shape:
             return False
-        dst.copy_(src)
+        if pairs is None:
+            dst.copy_(src)
+        else:
+            pairs.append((dst, src))
         return True
     if isinstance(dst, dict):
-        return all(_copy_tree(dst[k], src[k]) for k in dst)
+        return all(_copy_tree(dst[k], src[k], pairs) for k in dst)
     if isinstance(dst, (list, tuple)):
-        return len(dst) == len(src) and all(_copy_tree(a, b) for a, b in zip(dst, src))
+        return len(dst) == len(src) and all(_copy_tree(a, b, pairs) for a, b in zip(dst, src))
     return True
+
+
+def _flush_copies(pairs):
+    """All static-buffer updates of a step as a few multi-tensor copies (one per dtype) instead of ~100 launches."""
+    by_dtype = {}
+    for d, s in pairs:
+        if d.data_ptr() == s.data_ptr():
+            continue
+        if d.dtype != s.dtype or not (d.is_contiguous() and s.is_contiguous()):
+            d.copy_(s)
+        else:
+            by_dtype.setdefault(d.dtype, ([], []))
+            by_dtype[d.dtype][0].append(d)
+            by_dtype[d.dtype][1].append(s)
+    for ds, ss in by_dtype.values():
+        torch._foreach_copy_(ds, ss)
 
 
 def _clone_tree(x):
@@ -156,10 +176,15 @@ class TrainStep:
         sig = (batch[PA]["x"].shape[0], batch[LA]["x"].shape[0], prep["p"]["dense"].mx, prep["l"]["dense"].mx)
         if sig != self._sig:
             return False
-        ok = _copy_tree(st.nodes, batch.nodes) and _copy_tree(st.edges, batch.edges) and _copy_tree(st.globals, batch.globals)
+        pairs = []
+        ok = (_copy_tree(st.nodes, batch.nodes, pairs) and _copy_tree(st.edges, batch.edges, pairs)
+              and _copy_tree(st.globals, batch.globals, pairs))
         ok = ok and _copy_tree({k: v for k, v in st.extras.items() if k != "prefetched"},
-                               {k: batch.extras[k] for k in st.extras if k != "prefetched"})
-        return ok and _copy_tree(_prep_tensors(self.static_prep), _prep_tensors(prep))
+                               {k: batch.extras[k] for k in st.extras if k != "prefetched"}, pairs)
+        ok = ok and _copy_tree(_prep_tensors(self.static_prep), _prep_tensors(prep), pairs)
+        if ok:
+            _flush_copies(pairs)
+        return ok
 
     def _capture(self, batch):
         EF_layers._edge_pinned.clear()
