@@ -165,6 +165,23 @@ int singa_dec_cross_attn(const float* y, const float* wq_t, const float* bq, con
 int singa_dec_ffn(const float* z, const float* w1_t, const float* b1, const float* w2_t, const float* b2, const float* gamma,
                   const float* beta, int R, float* out, float eps, void* stream);
 
+/* k15c — the two per-edge MLPs of the CProMG graph attention (reference model/CProMG.py:41-48 `weight_k_net`,
+ * `weight_v_net` = Linear -> ShiftedSoftplus -> Linear, applied at CP:58 and CP:68): wk[E,HK] and wv[E,HV] from
+ * attr[E,CIN] in one pass on the f32 MFMA, hidden activations never stored.  All weight matrices TRANSPOSED:
+ * w1t*[CIN][H] (first Linear), w2t*[H][H] (second Linear); b1*, b2* [H].  Built for CIN = 64, HK = 32, HV = 64
+ * (config model.encoder: edge_channels 64, key_channels 128 / 4 heads, hidden_channels 256 / 4 heads). */
+int singa_edge_mlp_fwd(const float* attr, const float* w1tk, const float* b1k, const float* w2tk, const float* b2k,
+                       const float* w1tv, const float* b1v, const float* w2tv, const float* b2v, float* wk, float* wv, int E,
+                       int CIN, int HK, int HV, void* stream);
+
+/* backward of ONE of the nets of k15c (H hidden = H output units, 32 or 64): recomputes the hidden units and accumulates
+ * all four parameter gradients on the MFMA; part[singa_edge_mlp_bwd_nparts(E)][H*64 + H + H*H + H] holds one partial row
+ * [dW1 (H x 64, the first Linear's weight) | db1 | dW2 (H x H, the second Linear's weight, [out][hidden]) | db2] per
+ * workgroup, to be reduced with singa_colsum.  w1t[CIN][H] transposed as in the forward, w2[H][H] NOT transposed. */
+int singa_edge_mlp_bwd_nparts(int E);
+int singa_edge_mlp_bwd(const float* attr, const float* g_out, const float* w1t, const float* b1, const float* w2, float* part,
+                       int E, int CIN, int H, void* stream);
+
 /* k6a — LayerNorm over C = 16 channels followed by SiLU: the `nn.LayerNorm`, `nn.SiLU` pair inside RadialFunction
  * (reference model/EF_layers.py:1634-1657, net.1/net.2 and net.4/net.5).  x, out, g_out, g_x: [M, C] contiguous; biased
  * variance, eps inside the root (torch.nn.LayerNorm).  The backward recomputes the statistics and writes per-thread

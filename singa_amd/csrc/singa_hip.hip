@@ -1338,6 +1338,291 @@ __global__ void __launch_bounds__(1024) dec_ffn_kernel(const float* __restrict__
 }
 
 
+// ------------------------------------------------------------------------------------------------ CProMG edge MLPs on MFMA
+// W_k = L2k(ssp(L1k(attr))), W_v = L2v(ssp(L1v(attr))) for every kNN edge (CP:41-48, 58, 68): two chained GEMMs per net
+// whose [E, hidden] intermediates cost ~2.4 GB of HBM traffic per encoder layer as library calls.  Here a wavefront takes
+// 32 edges, the attribute rows are read once, and both GEMMs run on the f32 MFMA (v_mfma_f32_32x32x2_f32) without the
+// hidden activations ever leaving registers:
+//   GEMM 1 is computed TRANSPOSED, pre^T[hidden x edge] = W1 . attr^T: the accumulator then has the EDGE on the lane and
+//   16 hidden units in its registers (unit 8(r/4) + 4(lane/32) + r%4 in register r), which is exactly the B-operand shape
+//   of GEMM 2, out^T[out x edge] = W2 . h^T, if GEMM 2 walks its k index in that same permuted order - so step s of GEMM 2
+//   takes register s of the activated accumulator as B and W2[:, 8(s/4) + 4(lane/32) + s%4] as A (read from LDS).
+// Weights sit in LDS transposed (w1t[in][hidden], w2t[hidden][out]) so that the 32 lanes of an A operand read consecutive
+// addresses.  Biases initialise the accumulators.
+#ifndef SINGA_FLOATX16              // tests/emul supplies a plain struct so that the file still compiles with g++
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+#else
+typedef SINGA_FLOATX16 floatx16;
+#endif
+
+__device__ __forceinline__ float ssp_fast(float x) {
+    return fmaxf(x, 0.f) + __logf(1.f + __expf(-fabsf(x))) - 0.69314718055994530942f;
+}
+
+// one net on one 32-edge tile.  asel[s] = attr[edge][32 * half + s] (GEMM 1 pairs input channel s of the lower lane half
+// with channel 32 + s of the upper half in k-step s, so each half reads one contiguous 128-byte half row); w1t/w2t/b1/b2 in
+// LDS; T = H / 32 hidden tiles
+template <int H>
+__device__ __forceinline__ void edge_mlp_tile(const float (&asel)[32], const float* __restrict__ w1t, const float* __restrict__ b1,
+                                              const float* __restrict__ w2t, const float* __restrict__ b2, int lane,
+                                              floatx16 (&out)[H / 32]) {
+    constexpr int T = H / 32;
+    const int i = lane & 31, half = lane >> 5;
+    floatx16 hacc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hacc[t][r] = b1[32 * t + 8 * (r >> 2) + 4 * half + (r & 3)];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+            hacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1t[(32 * half + s) * H + 32 * t + i], asel[s], hacc[t], 0, 0, 0);
+        // keep the A-operand reads next to their MFMAs: T LDS reads, then T MFMAs (otherwise all 64 / 128 reads of the
+        // unrolled loop are hoisted to the top and the kernel spills)
+        __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, T, 0);
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hacc[t][r] = ssp_fast(hacc[t][r]);
+#pragma unroll
+    for (int u = 0; u < T; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[u][r] = b2[32 * u + 8 * (r >> 2) + 4 * half + (r & 3)];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int k = 32 * t + 8 * (s >> 2) + 4 * half + (s & 3);     // the hidden unit register s of this lane half holds
+#pragma unroll
+            for (int u = 0; u < T; ++u)
+                out[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2t[k * H + 32 * u + i], hacc[t][s], out[u], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, T, 0);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) edge_mlp_mfma_fwd_kernel(const float* __restrict__ attr, const float* __restrict__ w1tk,
+                                                                const float* __restrict__ b1k, const float* __restrict__ w2tk,
+                                                                const float* __restrict__ b2k, const float* __restrict__ w1tv,
+                                                                const float* __restrict__ b1v, const float* __restrict__ w2tv,
+                                                                const float* __restrict__ b2v, float* __restrict__ wk,
+                                                                float* __restrict__ wv, int E) {
+    __shared__ float lw1k[64 * 32], lw2k[32 * 32], lw1v[64 * 64], lw2v[64 * 64], lb[32 + 32 + 64 + 64];
+    for (int t = threadIdx.x; t < 64 * 32; t += 256) lw1k[t] = w1tk[t];
+    for (int t = threadIdx.x; t < 32 * 32; t += 256) lw2k[t] = w2tk[t];
+    for (int t = threadIdx.x; t < 64 * 64; t += 256) lw1v[t] = w1tv[t], lw2v[t] = w2tv[t];
+    if (threadIdx.x < 32) lb[threadIdx.x] = b1k[threadIdx.x], lb[32 + threadIdx.x] = b2k[threadIdx.x];
+    if (threadIdx.x < 64) lb[64 + threadIdx.x] = b1v[threadIdx.x], lb[128 + threadIdx.x] = b2v[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
+    const long long tiles = ((long long)E + 31) / 32, stride = (long long)gridDim.x * 4;
+    long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    float4 nxt[8];
+    auto fetch = [&](long long tl) {                       // this lane's half row of its edge of tile tl
+        long long ee = tl * 32 + i;
+        const float* row = attr + (ee < E ? ee : (long long)E - 1) * 64 + 32 * half;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) nxt[m] = *reinterpret_cast<const float4*>(row + 4 * m);
+    };
+    if (tile < tiles) fetch(tile);
+    for (; tile < tiles; tile += stride) {
+        const long long e = tile * 32 + i;
+        const bool ok = e < E;
+        float asel[32];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) asel[4 * m] = nxt[m].x, asel[4 * m + 1] = nxt[m].y, asel[4 * m + 2] = nxt[m].z, asel[4 * m + 3] = nxt[m].w;
+        if (tile + stride < tiles) fetch(tile + stride);   // the next tile's rows travel while this tile's 176 MFMAs run
+        {
+            floatx16 out[1];
+            edge_mlp_tile<32>(asel, lw1k, lb, lw2k, lb + 32, lane, out);
+            if (ok) {
+#pragma unroll
+                for (int blk = 0; blk < 4; ++blk)
+                    *reinterpret_cast<float4*>(wk + e * 32 + 8 * blk + 4 * half) =
+                        make_float4(out[0][4 * blk], out[0][4 * blk + 1], out[0][4 * blk + 2], out[0][4 * blk + 3]);
+            }
+        }
+        {
+            floatx16 out[2];
+            edge_mlp_tile<64>(asel, lw1v, lb + 64, lw2v, lb + 128, lane, out);
+            if (ok) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int blk = 0; blk < 4; ++blk)
+                        *reinterpret_cast<float4*>(wv + e * 64 + 32 * u + 8 * blk + 4 * half) =
+                            make_float4(out[u][4 * blk], out[u][4 * blk + 1], out[u][4 * blk + 2], out[u][4 * blk + 3]);
+            }
+        }
+    }
+}
+
+
+// Backward of one net (H hidden = H output units).  Per 32-edge tile, all on the MFMA:
+//   pre^T = W1 . attr^T (recomputed, as forward), gh^T = W2^T . g_out^T  -> both [hidden x edge] accumulators (edge on the
+//   lane), so h = ssp(pre), g_pre = gh * sigmoid(pre) are register-wise; the two tiles go to a wave-private LDS image
+//   [edge][hidden] from which the weight-gradient products read them with the edge as k index:
+//   dW2[o][j] += g_out[e][o] h[e][j],  dW1[j][c] += g_pre[e][j] attr[e][c]  (A/B operands straight from global memory for
+//   g_out / attr: 32 consecutive floats of one edge row per lane half).  db2 / db1 are column sums of g_out / g_pre.
+// The gradients accumulate in registers over all tiles of a wavefront; the four wavefronts of a workgroup are summed
+// through LDS and every workgroup writes one partial row part[block][H*64 | H | H*H | H] = [dW1 | db1 | dW2 | db2],
+// reduced afterwards with singa_colsum.  No gradient w.r.t. attr (it carries none, CP:295-298).
+template <int H>
+__global__ void __launch_bounds__(256) edge_mlp_mfma_bwd_kernel(const float* __restrict__ attr, const float* __restrict__ g_out,
+                                                                const float* __restrict__ w1t, const float* __restrict__ b1,
+                                                                const float* __restrict__ w2, float* __restrict__ part, int E) {
+    constexpr int T = H / 32, LD = H + 1, HH = H / 2;
+    constexpr int PSZ = H * 64 + H + H * H + H;
+    __shared__ float lw1[64 * H], lw2[H * H], lb1[H], tiles[4 * 2 * 32 * LD];
+    static_assert(4 * 2 * 32 * LD >= PSZ, "the tile images double as the reduction buffer");
+    for (int t = threadIdx.x; t < 64 * H; t += 256) lw1[t] = w1t[t];
+    for (int t = threadIdx.x; t < H * H; t += 256) lw2[t] = w2[t];
+    if (threadIdx.x < H) lb1[threadIdx.x] = b1[threadIdx.x];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
+    float* th = tiles + wave * 2 * 32 * LD;             // h image   [32][LD]
+    float* tg = th + 32 * LD;                           // g_pre image
+    floatx16 dw2[T][T], dw1[T][2];
+#pragma unroll
+    for (int a = 0; a < T; ++a) {
+#pragma unroll
+        for (int b = 0; b < T; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dw2[a][b][r] = 0.f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dw1[a][b][r] = 0.f;
+    }
+    float db1p = 0.f, db2p[T];
+#pragma unroll
+    for (int a = 0; a < T; ++a) db2p[a] = 0.f;
+    const long long tilesN = ((long long)E + 31) / 32;
+    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < tilesN; tile += (long long)gridDim.x * 4) {
+        const long long e0 = tile * 32, e = e0 + i;
+        const bool ok = e < E;
+        const long long er = ok ? e : (long long)E - 1;
+        float asel[32], grow[HH];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const float4 v = *reinterpret_cast<const float4*>(attr + er * 64 + 32 * half + 4 * m);
+            asel[4 * m] = v.x, asel[4 * m + 1] = v.y, asel[4 * m + 2] = v.z, asel[4 * m + 3] = v.w;
+        }
+#pragma unroll
+        for (int m = 0; m < HH / 4; ++m) {
+            const float4 v = *reinterpret_cast<const float4*>(g_out + er * H + HH * half + 4 * m);
+            grow[4 * m] = v.x, grow[4 * m + 1] = v.y, grow[4 * m + 2] = v.z, grow[4 * m + 3] = v.w;
+        }
+        floatx16 pacc[T], gacc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pacc[t][r] = lb1[32 * t + 8 * (r >> 2) + 4 * half + (r & 3)];
+                gacc[t][r] = 0.f;
+            }
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                pacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(lw1[(32 * half + s) * H + 32 * t + i], asel[s], pacc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, T, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < HH; ++s) {                  // k-step s: output unit s (lower lanes) / HH + s (upper lanes)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                gacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(lw2[(HH * half + s) * H + 32 * t + i], grow[s], gacc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, T, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
+                const float p = pacc[t][r];
+                const float sg = 1.f / (1.f + __expf(-p));
+                th[i * LD + j] = ok ? ssp_fast(p) : 0.f;
+                tg[i * LD + j] = ok ? gacc[t][r] * sg : 0.f;
+            }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < H) {
+            float c = 0.f;
+#pragma unroll 8
+            for (int row = 0; row < 32; ++row) c += tg[row * LD + lane];
+            db1p += c;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {                  // k = edges: step s takes edges 2s (lower lanes) and 2s + 1 (upper)
+            const long long ek = e0 + 2 * s + half;
+            const bool okk = ek < E;
+            const long long ekr = okk ? ek : (long long)E - 1;
+            float ga[T], hb[T], pa[T], ab[2];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                ga[t] = okk ? g_out[ekr * H + 32 * t + i] : 0.f;
+                hb[t] = th[(2 * s + half) * LD + 32 * t + i];
+                pa[t] = tg[(2 * s + half) * LD + 32 * t + i];
+                db2p[t] += ga[t];
+            }
+            ab[0] = okk ? attr[ekr * 64 + i] : 0.f;
+            ab[1] = okk ? attr[ekr * 64 + 32 + i] : 0.f;
+#pragma unroll
+            for (int a = 0; a < T; ++a) {
+#pragma unroll
+                for (int b = 0; b < T; ++b) dw2[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[a], hb[b], dw2[a][b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) dw1[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[a], ab[b], dw1[a][b], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // workgroup reduction through LDS (the tile images are free now), then one partial row per workgroup
+    __syncthreads();
+    float* red = tiles;
+    constexpr int O_B1 = H * 64, O_W2 = O_B1 + H, O_B2 = O_W2 + H * H;
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int a = 0; a < T; ++a) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * a + 8 * (r >> 2) + 4 * half + (r & 3);
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        float* q = red + row * 64 + 32 * b + i;
+                        *q = w == 0 ? dw1[a][b][r] : *q + dw1[a][b][r];
+                    }
+#pragma unroll
+                    for (int b = 0; b < T; ++b) {
+                        float* q = red + O_W2 + row * H + 32 * b + i;
+                        *q = w == 0 ? dw2[a][b][r] : *q + dw2[a][b][r];
+                    }
+                }
+                const float d2 = db2p[a] + __shfl_xor(db2p[a], 32, 64);
+                if (half == 0) {
+                    float* q = red + O_B2 + 32 * a + i;
+                    *q = w == 0 ? d2 : *q + d2;
+                }
+            }
+            if (lane < H) {
+                float* q = red + O_B1 + lane;
+                *q = w == 0 ? db1p : *q + db1p;
+            }
+        }
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < PSZ; t += 256) part[(long long)blockIdx.x * PSZ + t] = red[t];
+}
+
+
 // ------------------------------------------------------------------------------------------------ column sums
 // out[j] = sum_i x[i*ld + j]: bias / broadcast gradients.  A fixed-shape reduction tree: every pass lets one thread add up
 // to COLSUM_R rows of one column (consecutive threads = consecutive columns, so loads coalesce), passes repeat until one
@@ -2344,6 +2629,42 @@ int singa_dec_ffn(const float* z, const float* w1_t, const float* b1, const floa
     if (R <= 0) return SINGA_OK;
     hipLaunchKernelGGL(dec_ffn_kernel, dim3(R), dim3(1024), 0, (hipStream_t)stream, z, w1_t, b1, w2_t, b2, gamma, beta, out, eps);
     return check_launch("dec_ffn");
+}
+
+int singa_edge_mlp_fwd(const float* attr, const float* w1tk, const float* b1k, const float* w2tk, const float* b2k,
+                       const float* w1tv, const float* b1v, const float* w2tv, const float* b2v, float* wk, float* wv, int E,
+                       int CIN, int HK, int HV, void* stream) {
+    if (!attr || !w1tk || !b1k || !w2tk || !b2k || !w1tv || !b1v || !w2tv || !b2v || !wk || !wv)
+        return fail(SINGA_E_NULL, "edge_mlp_fwd: null pointer");
+    if (CIN != 64 || HK != 32 || HV != 64)
+        return fail(SINGA_E_SHAPE, "edge_mlp: built for 64 edge channels, 32 key / 64 value channels per head");
+    if (E <= 0) return SINGA_OK;
+    const long long tiles = ((long long)E + 31) / 32;
+    const long long blocks = (tiles + 3) / 4;
+    hipLaunchKernelGGL(edge_mlp_mfma_fwd_kernel, dim3((unsigned)(blocks < 768 ? blocks : 768)), dim3(256), 0, (hipStream_t)stream,
+                       attr, w1tk, b1k, w2tk, b2k, w1tv, b1v, w2tv, b2v, wk, wv, E);
+    return check_launch("edge_mlp_fwd");
+}
+
+int singa_edge_mlp_bwd_nparts(int E) {
+    const long long blocks = (((long long)E + 31) / 32 + 3) / 4;
+    return (int)(blocks < 256 ? (blocks < 1 ? 1 : blocks) : 256);
+}
+
+int singa_edge_mlp_bwd(const float* attr, const float* g_out, const float* w1t, const float* b1, const float* w2, float* part,
+                       int E, int CIN, int H, void* stream) {
+    if (!attr || !g_out || !w1t || !b1 || !w2 || !part) return fail(SINGA_E_NULL, "edge_mlp_bwd: null pointer");
+    if (CIN != 64 || (H != 32 && H != 64))
+        return fail(SINGA_E_SHAPE, "edge_mlp: built for 64 edge channels, 32 key / 64 value channels per head");
+    if (E <= 0) return SINGA_OK;
+    const int blocks = singa_edge_mlp_bwd_nparts(E);
+    if (H == 32)
+        hipLaunchKernelGGL((edge_mlp_mfma_bwd_kernel<32>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, attr, g_out, w1t, b1,
+                           w2, part, E);
+    else
+        hipLaunchKernelGGL((edge_mlp_mfma_bwd_kernel<64>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, attr, g_out, w1t, b1,
+                           w2, part, E);
+    return check_launch("edge_mlp_bwd");
 }
 
 long long singa_colsum_work(long long M, int n) {

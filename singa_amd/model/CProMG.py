@@ -183,8 +183,12 @@ class MultiHeadAttention(nn.Module):
         N = node_attr.size(0)
         h_keys, h_queries, h_values = (self._grouped(c, node_attr) for c in (self.k_lin, self.q_lin, self.v_lin))
         scale = 1.0 / math.sqrt(h_keys.size(-1))
-        W_k = self._edge_mlp(self.weight_k_net, edges.attr)                      # [E, 32]
-        W_v = self._edge_mlp(self.weight_v_net, edges.attr)                      # [E, 64]
+        if edges.attr.shape[1] == 64 and self.weight_k_net[0].out_features == 32 and self.weight_v_net[0].out_features == 64:
+            W_k, W_v = ops.edge_mlp_pair(edges.attr, (self.weight_k_net[0], self.weight_k_net[2]),
+                                         (self.weight_v_net[0], self.weight_v_net[2]))        # [E, 32], [E, 64]: k15c
+        else:                                    # other widths: the same two MLPs as library GEMMs + the k15d kernel
+            W_k = self._edge_mlp(self.weight_k_net, edges.attr)
+            W_v = self._edge_mlp(self.weight_v_net, edges.attr)
         qp = ops.linear(h_queries, self.weight_k_lin.weight.t())                 # (q W)[n,h,:]
         cterm = ops.rowdot_bias(h_queries, self.weight_k_lin.bias) * scale
         qk_ij = ops.edge_logits(qp, W_k, h_keys, cterm, edges, scale)

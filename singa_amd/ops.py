@@ -662,6 +662,50 @@ def bias_ssp(u, b):
     return _BiasSsp.apply(u, b)
 
 
+class _EdgeMLPPair(torch.autograd.Function):
+    """(W_k, W_v) = (L2k(ssp(L1k(attr))), L2v(ssp(L1v(attr)))) for all kNN edges (CP:41-48, 58, 68) on the f32 MFMA
+    (k15c): one kernel forward for both nets, one kernel per net backward; only the attribute rows are kept for the
+    backward pass, which recomputes the hidden units and reduces all four parameter gradients itself."""
+
+    @staticmethod
+    def forward(ctx, attr, w1k, b1k, w2k, b2k, w1v, b1v, w2v, b2v):
+        attr = attr.contiguous()
+        fw = [w1k.t().contiguous(), b1k.contiguous(), w2k.t().contiguous(), b2k.contiguous(),
+              w1v.t().contiguous(), b1v.contiguous(), w2v.t().contiguous(), b2v.contiguous()]
+        _dev(attr, *fw)
+        E, CIN = attr.shape
+        HK, HV = w1k.shape[0], w1v.shape[0]
+        wk = torch.empty(E, HK, device=attr.device, dtype=torch.float32)
+        wv = torch.empty(E, HV, device=attr.device, dtype=torch.float32)
+        _chk(_lib.lib().singa_edge_mlp_fwd(_p(attr), *[_p(t) for t in fw], _p(wk), _p(wv), E, CIN, HK, HV, _stream()),
+             "singa_edge_mlp_fwd")
+        ctx.save_for_backward(attr, fw[0], fw[1], w2k.contiguous(), fw[4], fw[5], w2v.contiguous())
+        return wk, wv
+
+    @staticmethod
+    def backward(ctx, gk, gv):
+        attr, w1tk, b1k, w2k, w1tv, b1v, w2v = ctx.saved_tensors
+        E, CIN = attr.shape
+        lib = _lib.lib()
+        grads = []
+        for g, w1t, b1, w2 in ((gk, w1tk, b1k, w2k), (gv, w1tv, b1v, w2v)):
+            g = g.contiguous()
+            H = w2.shape[0]
+            part = torch.empty(lib.singa_edge_mlp_bwd_nparts(E), H * CIN + H + H * H + H, device=attr.device, dtype=torch.float32)
+            _chk(lib.singa_edge_mlp_bwd(_p(attr), _p(g), _p(w1t), _p(b1), _p(w2), _p(part), E, CIN, H, _stream()),
+                 "singa_edge_mlp_bwd")
+            tot = colsum(part)
+            o1, o2 = H * CIN, H * CIN + H
+            grads += [tot[:o1].view(H, CIN), tot[o1:o2], tot[o2:o2 + H * H].view(H, H), tot[o2 + H * H:]]
+        return (None, *grads)
+
+
+def edge_mlp_pair(attr, k_net, v_net):
+    """k_net / v_net: (first Linear, second Linear) of `weight_k_net` / `weight_v_net`."""
+    return _EdgeMLPPair.apply(attr, k_net[0].weight, k_net[0].bias, k_net[1].weight, k_net[1].bias,
+                              v_net[0].weight, v_net[0].bias, v_net[1].weight, v_net[1].bias)
+
+
 def colsum(t):
     """Column sums of a [M, ...] tensor over dim 0 with the library's two-pass kernel.  torch's own long-column
     reductions (bias gradients of Linear layers, broadcast gradients, `t.sum(0)`) go through a multi-block kernel with

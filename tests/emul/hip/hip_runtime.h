@@ -54,6 +54,16 @@ static inline void __syncthreads() {
     abort();
 }
 
+#define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_wave_barrier() ((void)0)
+struct floatx16_emul { float v[16]; float& operator[](int i) { return v[i]; } };
+#define SINGA_FLOATX16 floatx16_emul
+static inline floatx16_emul __builtin_amdgcn_mfma_f32_32x32x2f32(float, float, floatx16_emul c, int, int, int) {
+    fprintf(stderr, "emul: matrix-core kernel cannot be emulated sequentially\n");
+    abort();
+    return c;
+}
+
 typedef void* hipEvent_t;
 static inline hipError_t hipEventCreate(hipEvent_t*) { return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }

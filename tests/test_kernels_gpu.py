@@ -404,3 +404,24 @@ def test_layer_norm_256_residual_matches_torch(M, res):
     assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
     for x, y in zip(got_g, want_g):
         assert float((x - y).abs().max()) < 1e-4 * max(1e-3, float(y.abs().max())), x.shape
+
+
+@pytest.mark.parametrize("E", [1, 31, 1000, 40_007])
+def test_edge_mlp_pair_matches_module_path(E):
+    """k15c (both per-edge MLPs on the MFMA, recomputing backward) against Linear -> softplus - ln2 -> Linear evaluated
+    with torch autograd: outputs and all eight parameter gradients, including partial 32-edge tiles."""
+    import math
+    from singa_amd import ops
+    torch.manual_seed(E)
+    attr = torch.randn(E, 64, device="cuda")
+    nets = [(torch.nn.Linear(64, H, device="cuda"), torch.nn.Linear(H, H, device="cuda")) for H in (32, 64)]
+    gk, gv = torch.randn(E, 32, device="cuda"), torch.randn(E, 64, device="cuda")
+    params = [p for l1, l2 in nets for p in (l1.weight, l1.bias, l2.weight, l2.bias)]
+    want = [l2(torch.nn.functional.softplus(l1(attr)) - math.log(2.0)) for l1, l2 in nets]
+    want_g = torch.autograd.grad(want, params, [gk, gv])
+    got = ops.edge_mlp_pair(attr, nets[0], nets[1])
+    got_g = torch.autograd.grad(list(got), params, [gk, gv])
+    for a, b in zip(got, want):
+        assert float((a - b).abs().max()) < 2e-6 * max(1.0, float(b.abs().max()))
+    for a, b in zip(got_g, want_g):
+        assert float((a - b).norm()) < 2e-5 * max(1e-6, float(b.norm())), a.shape
