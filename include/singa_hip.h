@@ -175,10 +175,12 @@ int singa_edge_mlp_fwd(const float* attr, const float* w1tk, const float* b1k, c
                        int CIN, int HK, int HV, void* stream);
 
 /* backward of ONE of the nets of k15c (H hidden = H output units, 32 or 64): recomputes the hidden units and accumulates
- * all four parameter gradients on the MFMA; part[singa_edge_mlp_bwd_nparts(E)][H*64 + H + H*H + H] holds one partial row
- * [dW1 (H x 64, the first Linear's weight) | db1 | dW2 (H x H, the second Linear's weight, [out][hidden]) | db2] per
- * workgroup, to be reduced with singa_colsum.  w1t[CIN][H] transposed as in the forward, w2[H][H] NOT transposed. */
-int singa_edge_mlp_bwd_nparts(int E);
+ * all four parameter gradients on the MFMA.  The hidden units are handled in slices of 32 (S = H/32 slices);
+ * part[singa_edge_mlp_bwd_nparts(E, H)][S][32*64 + 32 + H*32 + H] holds, per workgroup and slice s, the partial
+ * [dW1[32s:32s+32, :] (rows of the first Linear's weight) | db1[32s:32s+32] | dW2[:, 32s:32s+32] ([out][32], columns of
+ * the second Linear's weight) | db2 (the same in every slice)], to be reduced over the workgroups with singa_colsum.
+ * w1t[CIN][H] transposed as in the forward, w2[H][H] NOT transposed. */
+int singa_edge_mlp_bwd_nparts(int E, int H);
 int singa_edge_mlp_bwd(const float* attr, const float* g_out, const float* w1t, const float* b1, const float* w2, float* part,
                        int E, int CIN, int H, void* stream);
 

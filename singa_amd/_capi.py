@@ -49,7 +49,7 @@ _SIGS = {
     "singa_dec_cross_attn": ([P] * 10 + [I32, I32, I32, P, F32, P], I32),
     "singa_dec_ffn": ([P] * 7 + [I32, P, F32, P], I32),
     "singa_edge_mlp_fwd": ([P] * 11 + [I32, I32, I32, I32, P], I32),
-    "singa_edge_mlp_bwd_nparts": ([I32], I32),
+    "singa_edge_mlp_bwd_nparts": ([I32, I32], I32),
     "singa_edge_mlp_bwd": ([P] * 6 + [I32, I32, I32, P], I32),
     "singa_ln256_nparts": ([I64], I32),
     "singa_ln256_fwd": ([P] * 5 + [I64, I32, F32, P], I32),

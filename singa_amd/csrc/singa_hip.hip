@@ -1467,45 +1467,57 @@ __global__ void __launch_bounds__(256, 2) edge_mlp_mfma_fwd_kernel(const float* 
 //   lane), so h = ssp(pre), g_pre = gh * sigmoid(pre) are register-wise; the two tiles go to a wave-private LDS image
 //   [edge][hidden] from which the weight-gradient products read them with the edge as k index:
 //   dW2[o][j] += g_out[e][o] h[e][j],  dW1[j][c] += g_pre[e][j] attr[e][c]  (A/B operands straight from global memory for
-//   g_out / attr: 32 consecutive floats of one edge row per lane half).  db2 / db1 are column sums of g_out / g_pre.
+//   g_out / attr: 32 consecutive floats of one edge row per lane half, all issued at the top of the tile so that they
+//   arrive behind the first ~50 MFMAs).  db2 / db1 are column sums of g_out / g_pre.
+// A workgroup handles ONE tile of 32 hidden units (blockIdx.y): the 64-unit value net runs as two such slices, which
+// halves the accumulator registers (two wavefronts per SIMD instead of one) at no extra matrix work.
 // The gradients accumulate in registers over all tiles of a wavefront; the four wavefronts of a workgroup are summed
-// through LDS and every workgroup writes one partial row part[block][H*64 | H | H*H | H] = [dW1 | db1 | dW2 | db2],
-// reduced afterwards with singa_colsum.  No gradient w.r.t. attr (it carries none, CP:295-298).
+// through LDS and every workgroup writes one partial row part[block][slice][32*64 | 32 | H*32 | H] =
+// [dW1 rows of the slice | db1 of the slice | dW2 columns of the slice, [out][32] | db2], reduced afterwards with
+// singa_colsum.  No gradient w.r.t. attr (it carries none, CP:295-298).
 template <int H>
-__global__ void __launch_bounds__(256) edge_mlp_mfma_bwd_kernel(const float* __restrict__ attr, const float* __restrict__ g_out,
-                                                                const float* __restrict__ w1t, const float* __restrict__ b1,
-                                                                const float* __restrict__ w2, float* __restrict__ part, int E) {
-    constexpr int T = H / 32, LD = H + 1, HH = H / 2;
-    constexpr int PSZ = H * 64 + H + H * H + H;
-    __shared__ float lw1[64 * H], lw2[H * H], lb1[H], tiles[4 * 2 * 32 * LD];
+__global__ void __launch_bounds__(256, 2) edge_mlp_mfma_bwd_kernel(const float* __restrict__ attr, const float* __restrict__ g_out,
+                                                                   const float* __restrict__ w1t, const float* __restrict__ b1,
+                                                                   const float* __restrict__ w2, float* __restrict__ part, int E) {
+    constexpr int TO = H / 32, LD = 33, HH = H / 2;
+    constexpr int PSZ = 32 * 64 + 32 + H * 32 + H;
+    __shared__ float lw1[64 * 32], lw2[H * 32], lb1[32], tiles[4 * 2 * 32 * LD];
     static_assert(4 * 2 * 32 * LD >= PSZ, "the tile images double as the reduction buffer");
-    for (int t = threadIdx.x; t < 64 * H; t += 256) lw1[t] = w1t[t];
-    for (int t = threadIdx.x; t < H * H; t += 256) lw2[t] = w2[t];
-    if (threadIdx.x < H) lb1[threadIdx.x] = b1[threadIdx.x];
+    const int ht = blockIdx.y;                          // hidden units [32 ht, 32 ht + 32)
+    for (int t = threadIdx.x; t < 64 * 32; t += 256) lw1[t] = w1t[(t >> 5) * H + 32 * ht + (t & 31)];
+    for (int t = threadIdx.x; t < H * 32; t += 256) lw2[t] = w2[(t >> 5) * H + 32 * ht + (t & 31)];
+    if (threadIdx.x < 32) lb1[threadIdx.x] = b1[32 * ht + threadIdx.x];
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
-    float* th = tiles + wave * 2 * 32 * LD;             // h image   [32][LD]
+    float* th = tiles + wave * 2 * 32 * LD;             // h image   [32 edges][LD]
     float* tg = th + 32 * LD;                           // g_pre image
-    floatx16 dw2[T][T], dw1[T][2];
+    floatx16 dw2[TO], dw1[2];
 #pragma unroll
-    for (int a = 0; a < T; ++a) {
+    for (int r = 0; r < 16; ++r) {
 #pragma unroll
-        for (int b = 0; b < T; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dw2[a][b][r] = 0.f;
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dw1[a][b][r] = 0.f;
+        for (int a = 0; a < TO; ++a) dw2[a][r] = 0.f;
+        dw1[0][r] = 0.f, dw1[1][r] = 0.f;
     }
-    float db1p = 0.f, db2p[T];
+    float db1p = 0.f, db2p[TO];
 #pragma unroll
-    for (int a = 0; a < T; ++a) db2p[a] = 0.f;
+    for (int a = 0; a < TO; ++a) db2p[a] = 0.f;
     const long long tilesN = ((long long)E + 31) / 32;
     for (long long tile = (long long)blockIdx.x * 4 + wave; tile < tilesN; tile += (long long)gridDim.x * 4) {
         const long long e0 = tile * 32, e = e0 + i;
         const bool ok = e < E;
         const long long er = ok ? e : (long long)E - 1;
+        // operands of the weight-gradient products (k = edge: step s takes edge 2s in the lower lanes, 2s + 1 in the upper)
+        float ga[16][TO], ab[16][2];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const long long ek = e0 + 2 * s + half;
+            const bool okk = ek < E;
+            const long long ekr = okk ? ek : (long long)E - 1;
+#pragma unroll
+            for (int a = 0; a < TO; ++a) ga[s][a] = okk ? g_out[ekr * H + 32 * a + i] : 0.f;
+            ab[s][0] = okk ? attr[ekr * 64 + i] : 0.f;
+            ab[s][1] = okk ? attr[ekr * 64 + 32 + i] : 0.f;
+        }
         float asel[32], grow[HH];
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
@@ -1517,109 +1529,90 @@ __global__ void __launch_bounds__(256) edge_mlp_mfma_bwd_kernel(const float* __r
             const float4 v = *reinterpret_cast<const float4*>(g_out + er * H + HH * half + 4 * m);
             grow[4 * m] = v.x, grow[4 * m + 1] = v.y, grow[4 * m + 2] = v.z, grow[4 * m + 3] = v.w;
         }
-        floatx16 pacc[T], gacc[T];
+        floatx16 pacc, gacc;
 #pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                pacc[t][r] = lb1[32 * t + 8 * (r >> 2) + 4 * half + (r & 3)];
-                gacc[t][r] = 0.f;
-            }
+        for (int r = 0; r < 16; ++r) {
+            pacc[r] = lb1[8 * (r >> 2) + 4 * half + (r & 3)];
+            gacc[r] = 0.f;
+        }
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-                pacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(lw1[(32 * half + s) * H + 32 * t + i], asel[s], pacc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, T, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(lw1[(32 * half + s) * 32 + i], asel[s], pacc, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
 #pragma unroll
         for (int s = 0; s < HH; ++s) {                  // k-step s: output unit s (lower lanes) / HH + s (upper lanes)
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-                gacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(lw2[(HH * half + s) * H + 32 * t + i], grow[s], gacc[t], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, T, 0);
+            gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(lw2[(HH * half + s) * 32 + i], grow[s], gacc, 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         }
 #pragma unroll
-        for (int t = 0; t < T; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
-                const float p = pacc[t][r];
-                const float sg = 1.f / (1.f + __expf(-p));
-                th[i * LD + j] = ok ? ssp_fast(p) : 0.f;
-                tg[i * LD + j] = ok ? gacc[t][r] * sg : 0.f;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int j = 8 * (r >> 2) + 4 * half + (r & 3);
+            const float p = pacc[r];
+            const float sg = 1.f / (1.f + __expf(-p));
+            th[i * LD + j] = ok ? ssp_fast(p) : 0.f;
+            tg[i * LD + j] = ok ? gacc[r] * sg : 0.f;
+        }
         __builtin_amdgcn_wave_barrier();
-        if (lane < H) {
+        if (lane < 32) {
             float c = 0.f;
 #pragma unroll 8
             for (int row = 0; row < 32; ++row) c += tg[row * LD + lane];
             db1p += c;
         }
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {                  // k = edges: step s takes edges 2s (lower lanes) and 2s + 1 (upper)
-            const long long ek = e0 + 2 * s + half;
-            const bool okk = ek < E;
-            const long long ekr = okk ? ek : (long long)E - 1;
-            float ga[T], hb[T], pa[T], ab[2];
+        for (int s = 0; s < 16; ++s) {
+            const float hb = th[(2 * s + half) * LD + i], pa = tg[(2 * s + half) * LD + i];
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                ga[t] = okk ? g_out[ekr * H + 32 * t + i] : 0.f;
-                hb[t] = th[(2 * s + half) * LD + 32 * t + i];
-                pa[t] = tg[(2 * s + half) * LD + 32 * t + i];
-                db2p[t] += ga[t];
+            for (int a = 0; a < TO; ++a) {
+                db2p[a] += ga[s][a];
+                dw2[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s][a], hb, dw2[a], 0, 0, 0);
             }
-            ab[0] = okk ? attr[ekr * 64 + i] : 0.f;
-            ab[1] = okk ? attr[ekr * 64 + 32 + i] : 0.f;
-#pragma unroll
-            for (int a = 0; a < T; ++a) {
-#pragma unroll
-                for (int b = 0; b < T; ++b) dw2[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[a], hb[b], dw2[a][b], 0, 0, 0);
-#pragma unroll
-                for (int b = 0; b < 2; ++b) dw1[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[a], ab[b], dw1[a][b], 0, 0, 0);
-            }
+            dw1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, ab[s][0], dw1[0], 0, 0, 0);
+            dw1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, ab[s][1], dw1[1], 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
     }
-    // workgroup reduction through LDS (the tile images are free now), then one partial row per workgroup
+    // workgroup reduction through LDS (the tile images are free now), then one partial row per workgroup and slice
     __syncthreads();
     float* red = tiles;
-    constexpr int O_B1 = H * 64, O_W2 = O_B1 + H, O_B2 = O_W2 + H * H;
+    constexpr int O_B1 = 32 * 64, O_W2 = O_B1 + 32, O_B2 = O_W2 + H * 32;
 #pragma unroll 1
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
-            for (int a = 0; a < T; ++a) {
+            for (int r = 0; r < 16; ++r) {
+                const int row = 8 * (r >> 2) + 4 * half + (r & 3);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = 32 * a + 8 * (r >> 2) + 4 * half + (r & 3);
-#pragma unroll
-                    for (int b = 0; b < 2; ++b) {
-                        float* q = red + row * 64 + 32 * b + i;
-                        *q = w == 0 ? dw1[a][b][r] : *q + dw1[a][b][r];
-                    }
-#pragma unroll
-                    for (int b = 0; b < T; ++b) {
-                        float* q = red + O_W2 + row * H + 32 * b + i;
-                        *q = w == 0 ? dw2[a][b][r] : *q + dw2[a][b][r];
-                    }
+                for (int b = 0; b < 2; ++b) {
+                    float* q = red + row * 64 + 32 * b + i;                  // dW1[hidden row of the slice][input channel]
+                    *q = w == 0 ? dw1[b][r] : *q + dw1[b][r];
                 }
+#pragma unroll
+                for (int a = 0; a < TO; ++a) {
+                    float* q = red + O_W2 + (32 * a + row) * 32 + i;         // dW2[output unit][hidden unit of the slice]
+                    *q = w == 0 ? dw2[a][r] : *q + dw2[a][r];
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < TO; ++a) {
                 const float d2 = db2p[a] + __shfl_xor(db2p[a], 32, 64);
                 if (half == 0) {
                     float* q = red + O_B2 + 32 * a + i;
                     *q = w == 0 ? d2 : *q + d2;
                 }
             }
-            if (lane < H) {
+            if (lane < 32) {
                 float* q = red + O_B1 + lane;
                 *q = w == 0 ? db1p : *q + db1p;
             }
         }
         __syncthreads();
     }
-    for (int t = threadIdx.x; t < PSZ; t += 256) part[(long long)blockIdx.x * PSZ + t] = red[t];
+    float* dst = part + ((long long)blockIdx.x * gridDim.y + ht) * PSZ;
+    for (int t = threadIdx.x; t < PSZ; t += 256) dst[t] = red[t];
 }
 
 
@@ -2646,9 +2639,10 @@ int singa_edge_mlp_fwd(const float* attr, const float* w1tk, const float* b1k, c
     return check_launch("edge_mlp_fwd");
 }
 
-int singa_edge_mlp_bwd_nparts(int E) {
+int singa_edge_mlp_bwd_nparts(int E, int H) {
     const long long blocks = (((long long)E + 31) / 32 + 3) / 4;
-    return (int)(blocks < 256 ? (blocks < 1 ? 1 : blocks) : 256);
+    const long long cap = H <= 32 ? 512 : 256;         // x (H / 32) slices = two workgroups per CU (256 CUs)
+    return (int)(blocks < cap ? (blocks < 1 ? 1 : blocks) : cap);
 }
 
 int singa_edge_mlp_bwd(const float* attr, const float* g_out, const float* w1t, const float* b1, const float* w2, float* part,
@@ -2657,13 +2651,13 @@ int singa_edge_mlp_bwd(const float* attr, const float* g_out, const float* w1t, 
     if (CIN != 64 || (H != 32 && H != 64))
         return fail(SINGA_E_SHAPE, "edge_mlp: built for 64 edge channels, 32 key / 64 value channels per head");
     if (E <= 0) return SINGA_OK;
-    const int blocks = singa_edge_mlp_bwd_nparts(E);
+    const int blocks = singa_edge_mlp_bwd_nparts(E, H);
     if (H == 32)
-        hipLaunchKernelGGL((edge_mlp_mfma_bwd_kernel<32>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, attr, g_out, w1t, b1,
-                           w2, part, E);
+        hipLaunchKernelGGL((edge_mlp_mfma_bwd_kernel<32>), dim3(blocks, 1), dim3(256), 0, (hipStream_t)stream, attr, g_out, w1t,
+                           b1, w2, part, E);
     else
-        hipLaunchKernelGGL((edge_mlp_mfma_bwd_kernel<64>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, attr, g_out, w1t, b1,
-                           w2, part, E);
+        hipLaunchKernelGGL((edge_mlp_mfma_bwd_kernel<64>), dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, attr, g_out, w1t,
+                           b1, w2, part, E);
     return check_launch("edge_mlp_bwd");
 }
 

@@ -691,12 +691,15 @@ class _EdgeMLPPair(torch.autograd.Function):
         for g, w1t, b1, w2 in ((gk, w1tk, b1k, w2k), (gv, w1tv, b1v, w2v)):
             g = g.contiguous()
             H = w2.shape[0]
-            part = torch.empty(lib.singa_edge_mlp_bwd_nparts(E), H * CIN + H + H * H + H, device=attr.device, dtype=torch.float32)
+            S = H // 32                                   # slices of 32 hidden units (include/singa_hip.h)
+            psz = 32 * CIN + 32 + H * 32 + H
+            part = torch.empty(lib.singa_edge_mlp_bwd_nparts(E, H), S, psz, device=attr.device, dtype=torch.float32)
             _chk(lib.singa_edge_mlp_bwd(_p(attr), _p(g), _p(w1t), _p(b1), _p(w2), _p(part), E, CIN, H, _stream()),
                  "singa_edge_mlp_bwd")
-            tot = colsum(part)
-            o1, o2 = H * CIN, H * CIN + H
-            grads += [tot[:o1].view(H, CIN), tot[o1:o2], tot[o2:o2 + H * H].view(H, H), tot[o2 + H * H:]]
+            tot = colsum(part)                            # [S, psz]
+            o1, o2, o3 = 32 * CIN, 32 * CIN + 32, 32 * CIN + 32 + H * 32
+            grads += [tot[:, :o1].reshape(H, CIN), tot[:, o1:o2].reshape(H),
+                      tot[:, o2:o3].reshape(S, H, 32).permute(1, 0, 2).reshape(H, H), tot[0, o3:]]
         return (None, *grads)
 
 

@@ -33,16 +33,18 @@ for (l1, l2), H in zip(nets, (32, 64)):
     g = torch.randn(E, H, device="cuda")
     out = l2(torch.nn.functional.softplus(l1(attr)) - math.log(2.0))
     ref = torch.autograd.grad(out, (l1.weight, l1.bias, l2.weight, l2.bias), g)
-    n = lib.singa_edge_mlp_bwd_nparts(E)
-    psz = H * 64 + H + H * H + H
-    part = torch.full((n, psz), float("nan"), device="cuda")
+    n = lib.singa_edge_mlp_bwd_nparts(E, H)
+    S = H // 32
+    psz = 32 * 64 + 32 + H * 32 + H
+    part = torch.full((n, S, psz), float("nan"), device="cuda")
     w1t, w2 = l1.weight.detach().t().contiguous(), l2.weight.detach().contiguous()
     def runb():
         rc = lib.singa_edge_mlp_bwd(p(attr), p(g), p(w1t), p(l1.bias.detach()), p(w2), p(part), E, 64, H, st)
         assert rc == 0, rc
     runb(); torch.cuda.synchronize()
     tot = part.double().sum(0)
-    got = (tot[:H * 64].view(H, 64), tot[H * 64:H * 64 + H], tot[H * 64 + H:H * 64 + H + H * H].view(H, H), tot[-H:])
+    o1, o2, o3 = 32 * 64, 32 * 64 + 32, 32 * 64 + 32 + H * 32
+    got = (tot[:, :o1].reshape(H, 64), tot[:, o1:o2].reshape(H), tot[:, o2:o3].reshape(S, H, 32).permute(1, 0, 2).reshape(H, H), tot[0, o3:])
     for nm, a, b in zip(("dW1", "db1", "dW2", "db2"), got, ref):
         print(f"H={H} {nm}: rel err {float((a - b.double()).norm() / b.double().norm()):.2e}  nan {int(torch.isnan(a).sum())}")
     for _ in range(3): runb()
