@@ -184,6 +184,15 @@ int singa_edge_mlp_bwd_nparts(int E, int H);
 int singa_edge_mlp_bwd(const float* attr, const float* g_out, const float* w1t, const float* b1, const float* w2, float* part,
                        int E, int CIN, int H, void* stream);
 
+/* k18 — softmax(mask ? -1e9 : scale * s) over the last axis of the attention scores s[BH, T, S] (reference model/CProMG.py:
+ * 111-115, 140-146: `/ np.sqrt(d_k)`, `masked_fill_(attn_mask, -1e9)`, `Softmax(dim=-1)`), and its gradient
+ * gs = scale * p * (gp - sum_j gp_j p_j), zero at masked positions.  mask: bytes [B, T, S] addressed as
+ * mask[b * mask_stride_b + t * mask_stride_t + j] (an expanded padding mask has mask_stride_t = 0); row bh uses b = bh / heads. */
+int singa_masked_softmax_fwd(const float* s, const unsigned char* mask, long long mask_stride_b, long long mask_stride_t, float* p,
+                             int BH, int T, int S, int heads, float scale, void* stream);
+int singa_masked_softmax_bwd(const float* p, const float* gp, const unsigned char* mask, long long mask_stride_b,
+                             long long mask_stride_t, float* gs, int BH, int T, int S, int heads, float scale, void* stream);
+
 /* k6a — LayerNorm over C = 16 channels followed by SiLU: the `nn.LayerNorm`, `nn.SiLU` pair inside RadialFunction
  * (reference model/EF_layers.py:1634-1657, net.1/net.2 and net.4/net.5).  x, out, g_out, g_x: [M, C] contiguous; biased
  * variance, eps inside the root (torch.nn.LayerNorm).  The backward recomputes the statistics and writes per-thread

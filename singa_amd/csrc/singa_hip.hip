@@ -1616,6 +1616,44 @@ __global__ void __launch_bounds__(256, 2) edge_mlp_mfma_bwd_kernel(const float* 
 }
 
 
+// ------------------------------------------------------------------------------------------------ masked, scaled softmax
+// P = softmax(mask ? -1e9 : scale * s) over the last axis of s[BH, T, S] (ScaledDotProduct(De)Attention, CP:111-115,
+// 140-146: divide by sqrt(d), masked_fill(-1e9), softmax) and dS = scale * P * (dP - sum_j dP_j P_j), zero where masked.
+// One wavefront per (bh, t) row; mask[B, T, S] bytes with explicit strides (an expanded padding mask has stride 0 over t).
+__global__ void __launch_bounds__(256) masked_softmax_fwd_kernel(const float* __restrict__ s, const unsigned char* __restrict__ mask,
+                                                                 long long msb, long long mst, float* __restrict__ p, long long rows,
+                                                                 int T, int S, int heads, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long bh = row / T, t = row - bh * T;
+    const unsigned char* m = mask + (bh / heads) * msb + t * mst;
+    const float* x = s + row * S;
+    float mx = -INFINITY;
+    for (int j = lane; j < S; j += 64) mx = fmaxf(mx, m[j] ? -1e9f : x[j] * scale);
+    mx = wmax64(mx);
+    float sum = 0.f;
+    for (int j = lane; j < S; j += 64) sum += expf((m[j] ? -1e9f : x[j] * scale) - mx);
+    sum = 1.f / wsum64(sum);
+    for (int j = lane; j < S; j += 64) p[row * S + j] = expf((m[j] ? -1e9f : x[j] * scale) - mx) * sum;
+}
+
+__global__ void __launch_bounds__(256) masked_softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ gp,
+                                                                 const unsigned char* __restrict__ mask, long long msb, long long mst,
+                                                                 float* __restrict__ gs, long long rows, int T, int S, int heads,
+                                                                 float scale) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const long long bh = row / T, t = row - bh * T;
+    const unsigned char* m = mask + (bh / heads) * msb + t * mst;
+    float dot = 0.f;
+    for (int j = lane; j < S; j += 64) dot = fmaf(gp[row * S + j], p[row * S + j], dot);
+    dot = wsum64(dot);
+    for (int j = lane; j < S; j += 64) gs[row * S + j] = m[j] ? 0.f : scale * p[row * S + j] * (gp[row * S + j] - dot);
+}
+
+
 // ------------------------------------------------------------------------------------------------ column sums
 // out[j] = sum_i x[i*ld + j]: bias / broadcast gradients.  A fixed-shape reduction tree: every pass lets one thread add up
 // to COLSUM_R rows of one column (consecutive threads = consecutive columns, so loads coalesce), passes repeat until one
@@ -2659,6 +2697,28 @@ int singa_edge_mlp_bwd(const float* attr, const float* g_out, const float* w1t, 
         hipLaunchKernelGGL((edge_mlp_mfma_bwd_kernel<64>), dim3(blocks, 2), dim3(256), 0, (hipStream_t)stream, attr, g_out, w1t,
                            b1, w2, part, E);
     return check_launch("edge_mlp_bwd");
+}
+
+int singa_masked_softmax_fwd(const float* s, const unsigned char* mask, long long mask_stride_b, long long mask_stride_t, float* p,
+                             int BH, int T, int S, int heads, float scale, void* stream) {
+    if (!s || !mask || !p) return fail(SINGA_E_NULL, "masked_softmax_fwd: null pointer");
+    if (heads <= 0 || BH % heads) return fail(SINGA_E_SHAPE, "masked_softmax: BH must be batch x heads");
+    if (BH <= 0 || T <= 0 || S <= 0) return SINGA_OK;
+    const long long rows = (long long)BH * T;
+    hipLaunchKernelGGL(masked_softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, s, mask,
+                       mask_stride_b, mask_stride_t, p, rows, T, S, heads, scale);
+    return check_launch("masked_softmax_fwd");
+}
+
+int singa_masked_softmax_bwd(const float* p, const float* gp, const unsigned char* mask, long long mask_stride_b,
+                             long long mask_stride_t, float* gs, int BH, int T, int S, int heads, float scale, void* stream) {
+    if (!p || !gp || !mask || !gs) return fail(SINGA_E_NULL, "masked_softmax_bwd: null pointer");
+    if (heads <= 0 || BH % heads) return fail(SINGA_E_SHAPE, "masked_softmax: BH must be batch x heads");
+    if (BH <= 0 || T <= 0 || S <= 0) return SINGA_OK;
+    const long long rows = (long long)BH * T;
+    hipLaunchKernelGGL(masked_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, gp, mask,
+                       mask_stride_b, mask_stride_t, gs, rows, T, S, heads, scale);
+    return check_launch("masked_softmax_bwd");
 }
 
 long long singa_colsum_work(long long M, int n) {

@@ -206,9 +206,8 @@ def _dense_attention(module, Q, K, V, attn_mask, key_channels, hidden_channels):
     v_s = module.W_V(V).view(B, -1, heads, hidden_channels // heads).transpose(1, 2)
     T, S = q_s.size(2), k_s.size(2)
     flat = lambda t: t.reshape(B * heads, t.size(2), t.size(3))
-    scores = ops.bmm_small(flat(q_s), flat(k_s).transpose(1, 2)).view(B, heads, T, S) / np.sqrt(q_s.size(-1))
-    scores = scores.masked_fill(attn_mask.unsqueeze(1), -1e9)
-    context = ops.bmm_small(torch.softmax(scores, dim=-1).view(B * heads, T, S), flat(v_s)).view(B, heads, T, -1)
+    probs = ops.masked_softmax(ops.bmm_small(flat(q_s), flat(k_s).transpose(1, 2)), attn_mask, 1.0 / math.sqrt(q_s.size(-1)), heads)
+    context = ops.bmm_small(probs, flat(v_s)).view(B, heads, T, -1)
     context = context.transpose(1, 2).contiguous().view(B, -1, hidden_channels)
     return ops.layer_norm_residual(module.linear(context), Q, module.layer_norm)
 

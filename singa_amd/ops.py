@@ -599,6 +599,39 @@ def dec_layer_step(x, w, k_cache, v_cache, pos, cross_k, cross_v, pad, beams):
     return out
 
 
+class _MaskedSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s, mask, scale, heads):
+        s = s.contiguous()
+        _dev(s)
+        assert mask.dtype == torch.bool and mask.dim() == 3 and mask.stride(2) == 1 and mask.is_cuda
+        BH, T, S = s.shape
+        p = torch.empty_like(s)
+        assert mask.shape[0] * heads == BH and mask.shape[2] == S and mask.shape[1] in (1, T)
+        ctx.mst = 0 if mask.shape[1] == 1 else mask.stride(1)          # a [B, 1, S] padding mask serves every query row
+        _chk(_lib.lib().singa_masked_softmax_fwd(_p(s), _p(mask), mask.stride(0), ctx.mst, _p(p), BH, T, S, heads, scale,
+                                                 _stream()), "singa_masked_softmax_fwd")
+        ctx.save_for_backward(p, mask)
+        ctx.scale, ctx.heads = scale, heads
+        return p
+
+    @staticmethod
+    def backward(ctx, gp):
+        p, mask = ctx.saved_tensors
+        gp = gp.contiguous()
+        BH, T, S = p.shape
+        gs = torch.empty_like(p)
+        _chk(_lib.lib().singa_masked_softmax_bwd(_p(p), _p(gp), _p(mask), mask.stride(0), ctx.mst, _p(gs), BH, T, S, ctx.heads,
+                                                 ctx.scale, _stream()), "singa_masked_softmax_bwd")
+        return gs, None, None, None
+
+
+def masked_softmax(s, mask, scale, heads):
+    """softmax(masked_fill(s * scale, mask, -1e9), -1) for attention scores s[B*heads, T, S] and a boolean mask [B, T, S]
+    (k18): one pass instead of divide, masked_fill and softmax, forward and backward."""
+    return _MaskedSoftmax.apply(s, mask, scale, heads)
+
+
 class _LayerNorm256(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, r, gamma, beta, eps):

@@ -425,3 +425,26 @@ def test_edge_mlp_pair_matches_module_path(E):
         assert float((a - b).abs().max()) < 2e-6 * max(1.0, float(b.abs().max()))
     for a, b in zip(got_g, want_g):
         assert float((a - b).norm()) < 2e-5 * max(1e-6, float(b.norm())), a.shape
+
+
+@pytest.mark.parametrize("S,expanded", [(201, False), (230, True), (700, True)])
+def test_masked_softmax_matches_torch(S, expanded):
+    """k18 against divide + masked_fill(-1e9) + softmax with torch autograd, for a full [B,T,S] mask, an expanded padding
+    mask (stride 0 over the query axis), and rows longer than four wavefront passes."""
+    from singa_amd import ops
+    torch.manual_seed(S)
+    B, heads, T = 3, 4, 37
+    s = (torch.randn(B * heads, T, S, device="cuda") * 5).requires_grad_(True)
+    if expanded:
+        mask = (torch.rand(B, 1, S, device="cuda") < 0.3).expand(B, T, S)
+    else:
+        mask = (torch.rand(B, T, S, device="cuda") < 0.3) | torch.triu(torch.ones(T, S, dtype=torch.bool, device="cuda"), 1)
+        mask[:, :, 0] = False
+    g = torch.randn(B * heads, T, S, device="cuda")
+    scale = 1.0 / 32 ** 0.5
+    ref = torch.softmax((s.view(B, heads, T, S) * scale).masked_fill(mask.unsqueeze(1), -1e9), -1).view(B * heads, T, S)
+    ref_g, = torch.autograd.grad(ref, s, g)
+    got = ops.masked_softmax(s, mask, scale, heads)
+    got_g, = torch.autograd.grad(got, s, g)
+    assert float((got - ref).abs().max()) < 1e-6
+    assert float((got_g - ref_g).abs().max()) < 1e-5 * max(1e-3, float(ref_g.abs().max()))
