@@ -1654,6 +1654,269 @@ __global__ void __launch_bounds__(256) masked_softmax_bwd_kernel(const float* __
 }
 
 
+// ------------------------------------------------------------------------------------------------ dense attention on MFMA
+// ctx = softmax(mask ? -1e9 : q k^T / sqrt(32)) v for q[BH,T,32], k[BH,S,32], v[BH,S,64] (ScaledDotProduct(De)Attention,
+// CP:107-117, 136-148), flash-style on the f32 MFMA with the accumulator-as-operand chaining of k15c: a wavefront owns 32
+// queries of one (batch, head); per tile of 32 keys it forms the TRANSPOSED scores s^T[key x query] = K . Q^T, so the
+// query sits on the lane and 16 keys in its registers - the online softmax is register-wise (one cross-half exchange for
+// the running maximum) and the probabilities are the B operand of ctx^T[value x query] += V^T . P^T, whose A operand
+// v[key][value channel] is read straight from global memory in the accumulator's key order.  Nothing but ctx and, per
+// query, the row maximum and the reciprocal row sum (for the backward) is written.
+__global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                       const float* __restrict__ v, const unsigned char* __restrict__ mask,
+                                                       long long msb, long long mst, float* __restrict__ ctx,
+                                                       float* __restrict__ lse, int BH, int T, int S, int heads, float scale) {
+    const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
+    const int qtiles = (T + 31) / 32;
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (long long)BH * qtiles) return;
+    const int bh = (int)(w / qtiles), qt = (int)(w - (long long)bh * qtiles);
+    const int tq = qt * 32 + i, tqc = tq < T ? tq : T - 1;
+    float qreg[16];
+#pragma unroll
+    for (int m4 = 0; m4 < 4; ++m4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(q + ((long long)bh * T + tqc) * 32 + 16 * half + 4 * m4);
+        qreg[4 * m4] = t4.x, qreg[4 * m4 + 1] = t4.y, qreg[4 * m4 + 2] = t4.z, qreg[4 * m4 + 3] = t4.w;
+    }
+    const unsigned char* mrow = mask + (long long)(bh / heads) * msb + (long long)tqc * mst;
+    const float* kb = k + (long long)bh * S * 32;
+    const float* vb = v + (long long)bh * S * 64;
+    floatx16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = 0.f, o1[r] = 0.f;
+    float mrun = -INFINITY, lrun = 0.f;
+    for (int k0 = 0; k0 < S; k0 += 32) {
+        const int ka = k0 + i < S ? k0 + i : S - 1;
+        float kreg[16];
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(kb + (long long)ka * 32 + 16 * half + 4 * m4);
+            kreg[4 * m4] = t4.x, kreg[4 * m4 + 1] = t4.y, kreg[4 * m4 + 2] = t4.z, kreg[4 * m4 + 3] = t4.w;
+        }
+        floatx16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[s], qreg[s], sc, 0, 0, 0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kr = k0 + 8 * (r >> 2) + 4 * half + (r & 3);
+            const float val = kr < S ? (mrow[kr] ? -1e9f : sc[r] * scale) : -INFINITY;
+            sc[r] = val;
+            mx = fmaxf(mx, val);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __expf(mrun - mnew);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            sc[r] = __expf(sc[r] - mnew);
+            psum += sc[r];
+        }
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o0[r] *= alpha, o1[r] *= alpha;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int ks = k0 + 8 * (s >> 2) + 4 * half + (s & 3);
+            const float* vr = vb + (long long)(ks < S ? ks : S - 1) * 64 + i;
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], sc[s], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], sc[s], o1, 0, 0, 0);
+        }
+    }
+    lrun += __shfl_xor(lrun, 32, 64);
+    if (tq < T) {
+        const float inv = 1.f / lrun;
+        float* dst = ctx + ((long long)bh * T + tq) * 64 + 4 * half;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            *reinterpret_cast<float4*>(dst + 8 * blk) =
+                make_float4(o0[4 * blk] * inv, o0[4 * blk + 1] * inv, o0[4 * blk + 2] * inv, o0[4 * blk + 3] * inv);
+            *reinterpret_cast<float4*>(dst + 32 + 8 * blk) =
+                make_float4(o1[4 * blk] * inv, o1[4 * blk + 1] * inv, o1[4 * blk + 2] * inv, o1[4 * blk + 3] * inv);
+        }
+        if (half == 0) {                                  // (row maximum, 1 / row sum): kept apart - for a fully masked row the
+            lse[((long long)bh * T + tq) * 2] = mrun;     // maximum is -1e9 and log(sum) would vanish in its rounding
+            lse[((long long)bh * T + tq) * 2 + 1] = inv;
+        }
+    }
+}
+
+
+// Backward of k19, two passes that both recompute the scores from q, k and the stored log-sum-exp:
+//   pass A (a wavefront = 32 queries, lane = query): s^T, dP^T[key x query] = V . dO^T in the same layout, so
+//     dS^T = P^T (dP^T - D) scale is register-wise (D = rowsum(dO * ctx), computed here and stored for pass B), and
+//     dQ^T[dk x query] += K^T . dS^T takes dS^T as B operand;
+//   pass B (a wavefront = 32 keys, lane = key): s[query x key] = Q . K^T and dP = dO . V^T with the key on the lane and 16
+//     queries in registers, then dV^T[dv x key] += dO^T . P and dK^T[dk x key] += Q^T . dS with P / dS as B operands.
+__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                          const float* __restrict__ v, const unsigned char* __restrict__ mask,
+                                                          long long msb, long long mst, const float* __restrict__ ctx,
+                                                          const float* __restrict__ lse, const float* __restrict__ go,
+                                                          float* __restrict__ gq, float* __restrict__ dsum, int BH, int T, int S,
+                                                          int heads, float scale) {
+    const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
+    const int qtiles = (T + 31) / 32;
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (long long)BH * qtiles) return;
+    const int bh = (int)(w / qtiles), qt = (int)(w - (long long)bh * qtiles);
+    const int tq = qt * 32 + i, tqc = tq < T ? tq : T - 1;
+    const long long qrow = (long long)bh * T + tqc;
+    float qreg[16], goreg[32];
+#pragma unroll
+    for (int m4 = 0; m4 < 4; ++m4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(q + qrow * 32 + 16 * half + 4 * m4);
+        qreg[4 * m4] = t4.x, qreg[4 * m4 + 1] = t4.y, qreg[4 * m4 + 2] = t4.z, qreg[4 * m4 + 3] = t4.w;
+    }
+    float dpart = 0.f;
+#pragma unroll
+    for (int m4 = 0; m4 < 8; ++m4) {
+        const float4 g4 = *reinterpret_cast<const float4*>(go + qrow * 64 + 32 * half + 4 * m4);
+        const float4 c4 = *reinterpret_cast<const float4*>(ctx + qrow * 64 + 32 * half + 4 * m4);
+        goreg[4 * m4] = g4.x, goreg[4 * m4 + 1] = g4.y, goreg[4 * m4 + 2] = g4.z, goreg[4 * m4 + 3] = g4.w;
+        dpart += (g4.x * c4.x + g4.y * c4.y) + (g4.z * c4.z + g4.w * c4.w);
+    }
+    const float dq_i = dpart + __shfl_xor(dpart, 32, 64);          // D of this lane's query
+    const float m_i = lse[qrow * 2], linv_i = lse[qrow * 2 + 1];
+    if (half == 0 && tq < T) dsum[qrow] = dq_i;
+    const unsigned char* mrow = mask + (long long)(bh / heads) * msb + (long long)tqc * mst;
+    const float* kb = k + (long long)bh * S * 32;
+    const float* vb = v + (long long)bh * S * 64;
+    floatx16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+    for (int k0 = 0; k0 < S; k0 += 32) {
+        const int ka = k0 + i < S ? k0 + i : S - 1;
+        float kreg[16], vreg[32];
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(kb + (long long)ka * 32 + 16 * half + 4 * m4);
+            kreg[4 * m4] = t4.x, kreg[4 * m4 + 1] = t4.y, kreg[4 * m4 + 2] = t4.z, kreg[4 * m4 + 3] = t4.w;
+        }
+#pragma unroll
+        for (int m4 = 0; m4 < 8; ++m4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(vb + (long long)ka * 64 + 32 * half + 4 * m4);
+            vreg[4 * m4] = t4.x, vreg[4 * m4 + 1] = t4.y, vreg[4 * m4 + 2] = t4.z, vreg[4 * m4 + 3] = t4.w;
+        }
+        floatx16 sc, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f, dp[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(kreg[s], qreg[s], sc, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[s], goreg[s], dp, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kr = k0 + 8 * (r >> 2) + 4 * half + (r & 3);
+            const bool in = kr < S;
+            const bool msk = in && mrow[kr];
+            const float val = msk ? -1e9f : sc[r] * scale;
+            const float pr = in ? __expf(val - m_i) * linv_i : 0.f;
+            sc[r] = msk ? 0.f : pr * (dp[r] - dq_i) * scale;        // dS^T
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int ks = k0 + 8 * (s >> 2) + 4 * half + (s & 3);
+            dq = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[(long long)(ks < S ? ks : S - 1) * 32 + i], sc[s], dq, 0, 0, 0);
+        }
+    }
+    if (tq < T) {
+        float* dst = gq + ((long long)bh * T + tq) * 32 + 4 * half;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk)
+            *reinterpret_cast<float4*>(dst + 8 * blk) = make_float4(dq[4 * blk], dq[4 * blk + 1], dq[4 * blk + 2], dq[4 * blk + 3]);
+    }
+}
+
+__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k,
+                                                           const float* __restrict__ v, const unsigned char* __restrict__ mask,
+                                                           long long msb, long long mst, const float* __restrict__ lse,
+                                                           const float* __restrict__ dsum, const float* __restrict__ go,
+                                                           float* __restrict__ gk, float* __restrict__ gv, int BH, int T, int S,
+                                                           int heads, float scale) {
+    const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
+    const int ktiles = (S + 31) / 32;
+    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (long long)BH * ktiles) return;
+    const int bh = (int)(w / ktiles), kt = (int)(w - (long long)bh * ktiles);
+    const int key = kt * 32 + i, keyc = key < S ? key : S - 1;
+    const bool kin = key < S;
+    float kreg[16], vreg[32];
+#pragma unroll
+    for (int m4 = 0; m4 < 4; ++m4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(k + ((long long)bh * S + keyc) * 32 + 16 * half + 4 * m4);
+        kreg[4 * m4] = t4.x, kreg[4 * m4 + 1] = t4.y, kreg[4 * m4 + 2] = t4.z, kreg[4 * m4 + 3] = t4.w;
+    }
+#pragma unroll
+    for (int m4 = 0; m4 < 8; ++m4) {
+        const float4 t4 = *reinterpret_cast<const float4*>(v + ((long long)bh * S + keyc) * 64 + 32 * half + 4 * m4);
+        vreg[4 * m4] = t4.x, vreg[4 * m4 + 1] = t4.y, vreg[4 * m4 + 2] = t4.z, vreg[4 * m4 + 3] = t4.w;
+    }
+    const unsigned char* mb = mask + (long long)(bh / heads) * msb + keyc;
+    const float* qb = q + (long long)bh * T * 32;
+    const float* gob = go + (long long)bh * T * 64;
+    floatx16 dk, dv0, dv1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[r] = 0.f, dv0[r] = 0.f, dv1[r] = 0.f;
+    for (int t0 = 0; t0 < T; t0 += 32) {
+        const int ta = t0 + i < T ? t0 + i : T - 1;                // query row this lane supplies as A operand
+        float qa[16], ga[32];
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(qb + (long long)ta * 32 + 16 * half + 4 * m4);
+            qa[4 * m4] = t4.x, qa[4 * m4 + 1] = t4.y, qa[4 * m4 + 2] = t4.z, qa[4 * m4 + 3] = t4.w;
+        }
+#pragma unroll
+        for (int m4 = 0; m4 < 8; ++m4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(gob + (long long)ta * 64 + 32 * half + 4 * m4);
+            ga[4 * m4] = t4.x, ga[4 * m4 + 1] = t4.y, ga[4 * m4 + 2] = t4.z, ga[4 * m4 + 3] = t4.w;
+        }
+        floatx16 sc, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = 0.f, dp[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], kreg[s], sc, 0, 0, 0);
+#pragma unroll
+        for (int s = 0; s < 32; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s], vreg[s], dp, 0, 0, 0);
+        floatx16 pr;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tr = t0 + 8 * (r >> 2) + 4 * half + (r & 3);     // query of register r
+            const bool in = tr < T && kin;
+            const int trc = tr < T ? tr : T - 1;
+            const bool msk = in && mb[(long long)trc * mst];
+            const float val = msk ? -1e9f : sc[r] * scale;
+            const float* st = lse + ((long long)bh * T + trc) * 2;
+            const float p = in ? __expf(val - st[0]) * st[1] : 0.f;
+            pr[r] = p;
+            sc[r] = msk ? 0.f : p * (dp[r] - dsum[(long long)bh * T + trc]) * scale;      // dS
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int ts = t0 + 8 * (s >> 2) + 4 * half + (s & 3);
+            const long long tsc = ts < T ? ts : T - 1;
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(gob[tsc * 64 + i], pr[s], dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gob[tsc * 64 + 32 + i], pr[s], dv1, 0, 0, 0);
+            dk = __builtin_amdgcn_mfma_f32_32x32x2f32(qb[tsc * 32 + i], sc[s], dk, 0, 0, 0);
+        }
+    }
+    if (kin) {
+        float* dkd = gk + ((long long)bh * S + key) * 32 + 4 * half;
+        float* dvd = gv + ((long long)bh * S + key) * 64 + 4 * half;
+#pragma unroll
+        for (int blk = 0; blk < 4; ++blk) {
+            *reinterpret_cast<float4*>(dkd + 8 * blk) = make_float4(dk[4 * blk], dk[4 * blk + 1], dk[4 * blk + 2], dk[4 * blk + 3]);
+            *reinterpret_cast<float4*>(dvd + 8 * blk) = make_float4(dv0[4 * blk], dv0[4 * blk + 1], dv0[4 * blk + 2], dv0[4 * blk + 3]);
+            *reinterpret_cast<float4*>(dvd + 32 + 8 * blk) =
+                make_float4(dv1[4 * blk], dv1[4 * blk + 1], dv1[4 * blk + 2], dv1[4 * blk + 3]);
+        }
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------------ column sums
 // out[j] = sum_i x[i*ld + j]: bias / broadcast gradients.  A fixed-shape reduction tree: every pass lets one thread add up
 // to COLSUM_R rows of one column (consecutive threads = consecutive columns, so loads coalesce), passes repeat until one
@@ -2719,6 +2982,35 @@ int singa_masked_softmax_bwd(const float* p, const float* gp, const unsigned cha
     hipLaunchKernelGGL(masked_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, gp, mask,
                        mask_stride_b, mask_stride_t, gs, rows, T, S, heads, scale);
     return check_launch("masked_softmax_bwd");
+}
+
+int singa_attn_fwd(const float* q, const float* k, const float* v, const unsigned char* mask, long long mask_stride_b,
+                   long long mask_stride_t, float* ctx, float* lse, int BH, int T, int S, int heads, int DK, int DV, float scale,
+                   void* stream) {
+    if (!q || !k || !v || !mask || !ctx || !lse) return fail(SINGA_E_NULL, "attn_fwd: null pointer");
+    if (DK != 32 || DV != 64) return fail(SINGA_E_SHAPE, "attn: built for 32 key / 64 value channels per head");
+    if (heads <= 0 || BH % heads) return fail(SINGA_E_SHAPE, "attn: BH must be batch x heads");
+    if (BH <= 0 || T <= 0 || S <= 0) return SINGA_OK;
+    const long long waves = (long long)BH * ((T + 31) / 32);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, k, v, mask,
+                       mask_stride_b, mask_stride_t, ctx, lse, BH, T, S, heads, scale);
+    return check_launch("attn_fwd");
+}
+
+int singa_attn_bwd(const float* q, const float* k, const float* v, const unsigned char* mask, long long mask_stride_b,
+                   long long mask_stride_t, const float* ctx, const float* lse, const float* g_ctx, float* g_q, float* g_k,
+                   float* g_v, float* dsum, int BH, int T, int S, int heads, int DK, int DV, float scale, void* stream) {
+    if (!q || !k || !v || !mask || !ctx || !lse || !g_ctx || !g_q || !g_k || !g_v || !dsum)
+        return fail(SINGA_E_NULL, "attn_bwd: null pointer");
+    if (DK != 32 || DV != 64) return fail(SINGA_E_SHAPE, "attn: built for 32 key / 64 value channels per head");
+    if (heads <= 0 || BH % heads) return fail(SINGA_E_SHAPE, "attn: BH must be batch x heads");
+    if (BH <= 0 || T <= 0 || S <= 0) return SINGA_OK;
+    const long long wq = (long long)BH * ((T + 31) / 32), wk = (long long)BH * ((S + 31) / 32);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)((wq + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, k, v, mask,
+                       mask_stride_b, mask_stride_t, ctx, lse, g_ctx, g_q, dsum, BH, T, S, heads, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)((wk + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, k, v, mask,
+                       mask_stride_b, mask_stride_t, lse, dsum, g_ctx, g_k, g_v, BH, T, S, heads, scale);
+    return check_launch("attn_bwd");
 }
 
 long long singa_colsum_work(long long M, int n) {

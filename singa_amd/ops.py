@@ -632,6 +632,46 @@ def masked_softmax(s, mask, scale, heads):
     return _MaskedSoftmax.apply(s, mask, scale, heads)
 
 
+class _Attention(torch.autograd.Function):
+    """softmax(masked_fill(q k^T * scale, mask, -1e9)) v on the MFMA (k19): scores never leave registers; the backward
+    recomputes them from q, k and the stored log-sum-exp."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, scale, heads):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        _dev(q, k, v)
+        assert mask.dtype == torch.bool and mask.dim() == 3 and mask.stride(2) == 1 and mask.is_cuda
+        BH, T, DK = q.shape
+        S, DV = v.shape[1], v.shape[2]
+        assert mask.shape[0] * heads == BH and mask.shape[2] == S and mask.shape[1] in (1, T)
+        ctx.mst = 0 if mask.shape[1] == 1 else mask.stride(1)
+        out = torch.empty(BH, T, DV, device=q.device, dtype=torch.float32)
+        lse = torch.empty(BH, T, 2, device=q.device, dtype=torch.float32)       # (row maximum, 1 / row sum)
+        _chk(_lib.lib().singa_attn_fwd(_p(q), _p(k), _p(v), _p(mask), mask.stride(0), ctx.mst, _p(out), _p(lse), BH, T, S, heads,
+                                       DK, DV, scale, _stream()), "singa_attn_fwd")
+        ctx.save_for_backward(q, k, v, mask, out, lse)
+        ctx.scale, ctx.heads = scale, heads
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, k, v, mask, out, lse = ctx.saved_tensors
+        g = g.contiguous()
+        BH, T, DK = q.shape
+        S, DV = v.shape[1], v.shape[2]
+        gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dsum = torch.empty(BH, T, device=q.device, dtype=torch.float32)
+        _chk(_lib.lib().singa_attn_bwd(_p(q), _p(k), _p(v), _p(mask), mask.stride(0), ctx.mst, _p(out), _p(lse), _p(g), _p(gq),
+                                       _p(gk), _p(gv), _p(dsum), BH, T, S, ctx.heads, DK, DV, ctx.scale, _stream()),
+             "singa_attn_bwd")
+        return gq, gk, gv, None, None, None
+
+
+def attention(q, k, v, mask, scale, heads):
+    """Dense attention core for q[B*heads,T,32], k[B*heads,S,32], v[B*heads,S,64] and a boolean mask [B, T|1, S] (k19)."""
+    return _Attention.apply(q, k, v, mask, scale, heads)
+
+
 class _LayerNorm256(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, r, gamma, beta, eps):

@@ -448,3 +448,34 @@ def test_masked_softmax_matches_torch(S, expanded):
     got_g, = torch.autograd.grad(got, s, g)
     assert float((got - ref).abs().max()) < 1e-6
     assert float((got_g - ref_g).abs().max()) < 1e-5 * max(1e-3, float(ref_g.abs().max()))
+
+
+@pytest.mark.parametrize("T,S,kind", [(201, 201, "causal"), (201, 230, "padding"), (37, 700, "padding"), (5, 3, "none"), (64, 33, "row-masked")])
+def test_attention_matches_torch(T, S, kind):
+    """k19 (flash-style attention on the MFMA, recomputing backward) against matmul / masked_fill(-1e9) / softmax / matmul
+    with torch autograd: context and the gradients of q, k, v; partial tiles, an expanded padding mask, a fully masked row."""
+    import math
+    from singa_amd import ops
+    torch.manual_seed(T * 1000 + S)
+    B, heads = 3, 4
+    q, k, v = (torch.randn(B * heads, n, d, device="cuda", requires_grad=True) for n, d in ((T, 32), (S, 32), (S, 64)))
+    if kind == "causal":
+        mask = torch.triu(torch.ones(T, S, dtype=torch.bool, device="cuda"), 1).unsqueeze(0) | (torch.rand(B, 1, S, device="cuda") < 0.1)
+        mask[:, :, 0] = False
+    elif kind == "padding":
+        mask = (torch.rand(B, 1, S, device="cuda") < 0.3).expand(B, T, S)
+    elif kind == "row-masked":
+        mask = torch.rand(B, T, S, device="cuda") < 0.2
+        mask[1, 7] = True                                  # every key masked: the reference gives a uniform row
+    else:
+        mask = torch.zeros(B, 1, S, dtype=torch.bool, device="cuda")
+    g = torch.randn(B * heads, T, 64, device="cuda")
+    scale = 1.0 / math.sqrt(32)
+    sc = (torch.bmm(q, k.transpose(1, 2)) * scale).view(B, heads, T, S).masked_fill(mask.unsqueeze(1), -1e9)
+    want = torch.bmm(torch.softmax(sc, -1).view(B * heads, T, S), v)
+    want_g = torch.autograd.grad(want, (q, k, v), g)
+    got = ops.attention(q, k, v, mask, scale, heads)
+    got_g = torch.autograd.grad(got, (q, k, v), g)
+    assert float((got - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
+    for a, b in zip(got_g, want_g):
+        assert float((a - b).norm()) < 2e-5 * float(b.norm())
