@@ -1685,14 +1685,26 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = 0.f, o1[r] = 0.f;
     float mrun = -INFINITY, lrun = 0.f;
-    for (int k0 = 0; k0 < S; k0 += 32) {
+    float4 knext[4];
+    auto fetch_k = [&](int k0) {
         const int ka = k0 + i < S ? k0 + i : S - 1;
-        float kreg[16];
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) {
-            const float4 t4 = *reinterpret_cast<const float4*>(kb + (long long)ka * 32 + 16 * half + 4 * m4);
-            kreg[4 * m4] = t4.x, kreg[4 * m4 + 1] = t4.y, kreg[4 * m4 + 2] = t4.z, kreg[4 * m4 + 3] = t4.w;
+        for (int m4 = 0; m4 < 4; ++m4) knext[m4] = *reinterpret_cast<const float4*>(kb + (long long)ka * 32 + 16 * half + 4 * m4);
+    };
+    fetch_k(0);
+    for (int k0 = 0; k0 < S; k0 += 32) {
+        float kreg[16], vreg[32];
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4)
+            kreg[4 * m4] = knext[m4].x, kreg[4 * m4 + 1] = knext[m4].y, kreg[4 * m4 + 2] = knext[m4].z, kreg[4 * m4 + 3] = knext[m4].w;
+        // this tile's value operands and the next tile's key rows travel while the score MFMAs and the softmax run
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int ks = k0 + 8 * (s >> 2) + 4 * half + (s & 3);
+            const float* vr = vb + (long long)(ks < S ? ks : S - 1) * 64 + i;
+            vreg[2 * s] = vr[0], vreg[2 * s + 1] = vr[32];
         }
+        if (k0 + 32 < S) fetch_k(k0 + 32);
         floatx16 sc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = 0.f;
@@ -1721,10 +1733,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
         for (int r = 0; r < 16; ++r) o0[r] *= alpha, o1[r] *= alpha;
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const int ks = k0 + 8 * (s >> 2) + 4 * half + (s & 3);
-            const float* vr = vb + (long long)(ks < S ? ks : S - 1) * 64 + i;
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], sc[s], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], sc[s], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[2 * s], sc[s], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vreg[2 * s + 1], sc[s], o1, 0, 0, 0);
         }
     }
     lrun += __shfl_xor(lrun, 32, 64);
@@ -1788,19 +1798,27 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
     floatx16 dq;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-    for (int k0 = 0; k0 < S; k0 += 32) {
+    float4 kn[4], vn[8];
+    auto fetch = [&](int k0) {
         const int ka = k0 + i < S ? k0 + i : S - 1;
-        float kreg[16], vreg[32];
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) {
-            const float4 t4 = *reinterpret_cast<const float4*>(kb + (long long)ka * 32 + 16 * half + 4 * m4);
-            kreg[4 * m4] = t4.x, kreg[4 * m4 + 1] = t4.y, kreg[4 * m4 + 2] = t4.z, kreg[4 * m4 + 3] = t4.w;
-        }
+        for (int m4 = 0; m4 < 4; ++m4) kn[m4] = *reinterpret_cast<const float4*>(kb + (long long)ka * 32 + 16 * half + 4 * m4);
 #pragma unroll
-        for (int m4 = 0; m4 < 8; ++m4) {
-            const float4 t4 = *reinterpret_cast<const float4*>(vb + (long long)ka * 64 + 32 * half + 4 * m4);
-            vreg[4 * m4] = t4.x, vreg[4 * m4 + 1] = t4.y, vreg[4 * m4 + 2] = t4.z, vreg[4 * m4 + 3] = t4.w;
+        for (int m4 = 0; m4 < 8; ++m4) vn[m4] = *reinterpret_cast<const float4*>(vb + (long long)ka * 64 + 32 * half + 4 * m4);
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < S; k0 += 32) {
+        float kreg[16], vreg[32], kd[16];
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) kreg[4 * m4] = kn[m4].x, kreg[4 * m4 + 1] = kn[m4].y, kreg[4 * m4 + 2] = kn[m4].z, kreg[4 * m4 + 3] = kn[m4].w;
+#pragma unroll
+        for (int m4 = 0; m4 < 8; ++m4) vreg[4 * m4] = vn[m4].x, vreg[4 * m4 + 1] = vn[m4].y, vreg[4 * m4 + 2] = vn[m4].z, vreg[4 * m4 + 3] = vn[m4].w;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {                  // A operands of the dQ product, issued ahead of the 48 MFMAs before it
+            const int ks = k0 + 8 * (s >> 2) + 4 * half + (s & 3);
+            kd[s] = kb[(long long)(ks < S ? ks : S - 1) * 32 + i];
         }
+        if (k0 + 32 < S) fetch(k0 + 32);
         floatx16 sc, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = 0.f, dp[r] = 0.f;
@@ -1818,10 +1836,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
             sc[r] = msk ? 0.f : pr * (dp[r] - dq_i) * scale;        // dS^T
         }
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int ks = k0 + 8 * (s >> 2) + 4 * half + (s & 3);
-            dq = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[(long long)(ks < S ? ks : S - 1) * 32 + i], sc[s], dq, 0, 0, 0);
-        }
+        for (int s = 0; s < 16; ++s) dq = __builtin_amdgcn_mfma_f32_32x32x2f32(kd[s], sc[s], dq, 0, 0, 0);
     }
     if (tq < T) {
         float* dst = gq + ((long long)bh * T + tq) * 32 + 4 * half;
@@ -1861,19 +1876,28 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
     floatx16 dk, dv0, dv1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dk[r] = 0.f, dv0[r] = 0.f, dv1[r] = 0.f;
-    for (int t0 = 0; t0 < T; t0 += 32) {
+    float4 qn[4], gn[8];
+    auto fetch = [&](int t0) {
         const int ta = t0 + i < T ? t0 + i : T - 1;                // query row this lane supplies as A operand
-        float qa[16], ga[32];
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) {
-            const float4 t4 = *reinterpret_cast<const float4*>(qb + (long long)ta * 32 + 16 * half + 4 * m4);
-            qa[4 * m4] = t4.x, qa[4 * m4 + 1] = t4.y, qa[4 * m4 + 2] = t4.z, qa[4 * m4 + 3] = t4.w;
-        }
+        for (int m4 = 0; m4 < 4; ++m4) qn[m4] = *reinterpret_cast<const float4*>(qb + (long long)ta * 32 + 16 * half + 4 * m4);
 #pragma unroll
-        for (int m4 = 0; m4 < 8; ++m4) {
-            const float4 t4 = *reinterpret_cast<const float4*>(gob + (long long)ta * 64 + 32 * half + 4 * m4);
-            ga[4 * m4] = t4.x, ga[4 * m4 + 1] = t4.y, ga[4 * m4 + 2] = t4.z, ga[4 * m4 + 3] = t4.w;
+        for (int m4 = 0; m4 < 8; ++m4) gn[m4] = *reinterpret_cast<const float4*>(gob + (long long)ta * 64 + 32 * half + 4 * m4);
+    };
+    fetch(0);
+    for (int t0 = 0; t0 < T; t0 += 32) {
+        float qa[16], ga[32], ad[16][3];
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) qa[4 * m4] = qn[m4].x, qa[4 * m4 + 1] = qn[m4].y, qa[4 * m4 + 2] = qn[m4].z, qa[4 * m4 + 3] = qn[m4].w;
+#pragma unroll
+        for (int m4 = 0; m4 < 8; ++m4) ga[4 * m4] = gn[m4].x, ga[4 * m4 + 1] = gn[m4].y, ga[4 * m4 + 2] = gn[m4].z, ga[4 * m4 + 3] = gn[m4].w;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {                  // A operands of the dV / dK products, issued ahead of the 48 MFMAs before them
+            const int ts = t0 + 8 * (s >> 2) + 4 * half + (s & 3);
+            const long long tsc = ts < T ? ts : T - 1;
+            ad[s][0] = gob[tsc * 64 + i], ad[s][1] = gob[tsc * 64 + 32 + i], ad[s][2] = qb[tsc * 32 + i];
         }
+        if (t0 + 32 < T) fetch(t0 + 32);
         floatx16 sc, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = 0.f, dp[r] = 0.f;
@@ -1896,11 +1920,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
         }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const int ts = t0 + 8 * (s >> 2) + 4 * half + (s & 3);
-            const long long tsc = ts < T ? ts : T - 1;
-            dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(gob[tsc * 64 + i], pr[s], dv0, 0, 0, 0);
-            dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(gob[tsc * 64 + 32 + i], pr[s], dv1, 0, 0, 0);
-            dk = __builtin_amdgcn_mfma_f32_32x32x2f32(qb[tsc * 32 + i], sc[s], dk, 0, 0, 0);
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[s][0], pr[s], dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[s][1], pr[s], dv1, 0, 0, 0);
+            dk = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[s][2], sc[s], dk, 0, 0, 0);
         }
     }
     if (kin) {
