@@ -1,18 +1,24 @@
 #!/usr/bin/env python
 """bench.py — BASELINE.json's metric on MI355X: protein-ligand graphs/s for one full SINGA training step
 (zero_grad -> forward -> CrossEntropy -> backward -> [grad all-reduce] -> clip(inf) -> Adam), plus the achieved
-HBM GB/s of the fused alpha-scale + rotate-back + scatter kernel ("scatter-TP", k10) against the roofline, plus
-the CPU oracle timed on this box's host cores.
+HBM GB/s of the fused alpha-scale + rotate-back + scatter kernel ("scatter-TP", k10) and of gather+rotate (k4)
+against the roofline, plus the CPU oracle timed on this box's host cores.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2_b32_l2]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3_b128_l4] [--scaling weak|strong]
 
-N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL): every rank trains on its own
-shard of `n_graphs` synthetic graphs (weak scaling), gradients are averaged with one bucketed all-reduce per step.
+Default workload = BASELINE.json configs[2]: 128 CrossDocked-shaped ragged synthetic graphs,
+l_max = 4, full step, one GPU.  N > 1: one rank per GPU over RCCL.  Launched by the driver under torch.distributed.run
+the ranks are taken from the environment; launched bare (`python bench.py --gpus 8`) it starts its own ranks as child
+processes before touching the GPU and relays rank 0's JSON line.  `--scaling weak` (default): every rank trains on its
+own 128 graphs; `--scaling strong` = BASELINE.json configs[3] (config 4): the SAME 128-graph batch is split over the
+ranks by edge count (dp.shard_ranges_by_cost) and the gradients are combined token-weighted.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,6 +30,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured copy ceiling
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32 MFMA peak (MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD)
 
 
 def parse():
@@ -31,46 +38,83 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="cfg2_b32_l2")
+    ap.add_argument("--workload", default="cfg3_b128_l4")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="build each batch's graph structure inside its own step instead of on a second stream during the previous one")
-    ap.add_argument("--roofline-steps", type=int, default=3, help="instrumented eager steps after the timed region")
-    ap.add_argument("--cpu-graphs", type=int, default=12, help="graphs in the bounded CPU-oracle sample")
+    ap.add_argument("--roofline-steps", type=int, default=2, help="instrumented eager steps after the timed region")
+    ap.add_argument("--cpu-graphs", type=int, default=8, help="graphs in the bounded CPU-oracle sample")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def k10_algorithmic_bytes(E, N, L, CH=112, heads=7):
-    """SURVEY.md §8d formula for rotate_back_scatter forward, with the 36-byte frame replaced by the streamed
-    reduced Wigner rows (WSZ floats per edge), as DESIGN.md states."""
+# ------------------------------------------------------------------------------------------------ algorithmic bytes
+def kernel_bytes(tag, E, N, L, C=16, CH=112, heads=7):
+    """Algorithmic HBM bytes of one launch (SURVEY.md §8d formulas; the 36-byte edge frame of the survey's formula is
+    replaced by the WSZ*4-byte reduced Wigner rows this design streams, as DESIGN.md states).  E = edges of the launch,
+    N = node rows written / read by it (k4: N_src + N_dst, here both = the pass's node count)."""
     from singa_amd import so3
     lay = so3.layout(L, 2)
-    return E * (lay.KR * CH * 4 + heads * 4 + lay.WSZ * 4) + N * lay.K * CH * 4 + (N + 1) * 4
+    K, KR, WSZ, R = lay.K, lay.KR, lay.WSZ, lay.rad_rows * 2 * C
+    if tag == "k10_fwd":      # reads msg + alpha + Wigner rows + row_ptr, writes the node rows
+        return E * (KR * CH * 4 + heads * 4 + WSZ * 4) + N * K * CH * 4 + (N + 1) * 4
+    if tag == "k10_bwd":      # reads node-row gradients, msg, alpha, Wigner rows; writes d msg and d alpha
+        return N * K * CH * 4 + (N + 1) * 4 + E * (KR * CH * 4 + heads * 4 + WSZ * 4) + E * (KR * CH * 4 + heads * 4)
+    if tag == "k4_fwd":       # reads both endpoint rows once per node, radial weights, Wigner rows, indices; writes [E, KR, 2C]
+        return 2 * N * K * C * 4 + E * (KR * 2 * C * 4 + R * 4 + WSZ * 4 + 8)
+    if tag == "k4_bwd_rad":   # reads the same as the forward plus d out; writes d rad
+        return 2 * N * K * C * 4 + E * (KR * 2 * C * 4 + WSZ * 4 + 8) + E * R * 4
+    if tag in ("k4_bwd_dst", "k4_bwd_src"):   # reads one half of d out and of rad, Wigner rows, the CSR; writes N node rows
+        return E * (KR * C * 4 + R // 2 * 4 + WSZ * 4 + (4 if tag == "k4_bwd_src" else 0)) + N * K * C * 4 + (N + 1) * 4
+    raise KeyError(tag)
 
 
-def pmc_traffic(L, n_dst):
-    """HBM bytes per launch of the scatter-TP forward kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/<round>/pmc_{FETCH,WRITE}_SIZE.csv, produced by tools/prof.sh): FETCH_SIZE x 2 (gfx950 correction
-    for this access shape, confirmed by the calibration copy in the same pass) + WRITE_SIZE, KiB -> bytes.  None if no
-    profile matches the launch geometry (grid = dst nodes x 128)."""
-    import csv
+def lib_source_sha():
+    h = hashlib.sha1()
+    for f in ("singa_amd/csrc/singa_hip.hip", "singa_amd/csrc/so3_index.h"):
+        with open(os.path.join(ROOT, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+def committed_profile(workload):
+    """The newest profiles/<tag>/ directory that was made from THIS workload (its bench_*.json names it): PMC traffic
+    per launch and MFMA counters of the same command, produced by tools/prof.sh.  rocprofv3 --pmc cannot run inside this
+    process, so these numbers are read back; `lib_sha` tells whether the profiled library source is the current one."""
     import glob
     best = None
     for d in sorted(glob.glob(os.path.join(ROOT, "profiles", "*"))):
-        vals = {}
-        for c in ("FETCH_SIZE", "WRITE_SIZE"):
-            f = os.path.join(d, f"pmc_{c}.csv")
-            if not os.path.exists(f):
+        meta = os.path.join(d, "meta.json")
+        if os.path.isfile(meta):
+            try:
+                m = json.load(open(meta))
+            except Exception:
                 continue
-            for r in csv.DictReader(open(f)):
-                if f"rotate_back_scatter_kernel<{L}, 2, false" in r["kernel"] and int(r["grid"]) == n_dst * 128:
-                    vals[c] = float(r["avg_value"])
-        if len(vals) == 2:
-            best = (int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), os.path.relpath(d, ROOT))
+            if m.get("workload") == workload:
+                best = (d, m)
     return best
+
+
+def pmc_traffic(prof, kernel_substr, grid):
+    """HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE passes: FETCH_SIZE x 2 (gfx950 correction for this access
+    shape, confirmed by the calibration copy of the same pass) + WRITE_SIZE, KiB -> bytes."""
+    import csv
+    if prof is None:
+        return None
+    vals = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        f = os.path.join(prof[0], f"pmc_{c}.csv")
+        if not os.path.exists(f):
+            return None
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["kernel"] and int(r["grid"]) == grid:
+                vals[c] = float(r["avg_value"])
+    if len(vals) != 2:
+        return None
+    return int((2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024)
 
 
 def baseline_metric():
@@ -100,10 +144,11 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+# ------------------------------------------------------------------------------------------------ CPU baseline (oracle)
 def cpu_baseline_worker(workload, n_graphs, threads):
     """Runs in a child process that never touches the GPU: times the CPU oracle (kind 'port':
     oracle/singa_oracle.py, pinned to the reference by tests/golden) on a bounded sample of the same workload -
-    forward + CrossEntropy + backward of `n_graphs` synthetic graphs - and prints one JSON object."""
+    forward + CrossEntropy + backward of the first `n_graphs` synthetic graphs - and prints one JSON object."""
     torch.set_num_threads(threads)
     from oracle import singa_oracle as O
     from singa_amd import graph as G
@@ -115,24 +160,8 @@ def cpu_baseline_worker(workload, n_graphs, threads):
     cfg = load_config(lmax=L)
     torch.manual_seed(cfg.train.seed)
     model = SINGA(cfg, device="cpu")          # parameter container only; the product forward is never called here
-    graphs = [G.synthetic_graph(10_000 + i, **kw) for i in range(n_graphs)]
-    og = []
-    for g in graphs:
-        og.append({"x_p": g[G.PA]["x"], "pos_p": g[G.PA]["pos"], "z_p": g["atomicnum"][G.PA],
-                   "x_l": g[G.LA]["x"], "pos_l": g[G.LA]["pos"], "z_l": g["atomicnum"][G.LA],
-                   "ei_pp": g[G.E_PP]["edge_index"], "ei_ll": g[G.E_LL]["edge_index"],
-                   "ei_lp": g[G.E_LP]["edge_index"], "ei_pl": g[G.E_PL]["edge_index"],
-                   "tok_in": g["ligand_data"]["smiIndices_input"], "tok_tgt": g["ligand_data"]["smiIndices_tgt"],
-                   "props": torch.tensor([g["ligand_data"][k] for k in ("vina_score", "qed", "sas")],
-                                         dtype=torch.float64)})
-    b = O.collate(og)
-    rand = {k: torch.cat([g.extras["rot_rand"][k] for g in graphs], 0) for k in ("pp", "ll", "lp")}
-    vec = {"pp": b["pos_p"][b["ei_pp"][0]] - b["pos_p"][b["ei_pp"][1]],
-           "ll": b["pos_l"][b["ei_ll"][0]] - b["pos_l"][b["ei_ll"][1]],
-           "lp": b["pos_l"][b["ei_lp"][0]] - b["pos_p"][b["ei_lp"][1]]}
-    rots = {k: O.edge_rot_mat(vec[k], rand[k]) for k in vec}
-    lap_p = torch.cat([g[G.PA]["lap_pe"] for g in graphs], 0)
-    lap_l = torch.cat([g[G.LA]["lap_pe"] for g in graphs], 0)
+    graphs = [G.synthetic_graph(i, **G.graph_sizes(i, **kw)) for i in range(n_graphs)]
+    b, rots, lap_p, lap_l = O.batch_from_graphs(graphs)
     sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
     times = []
     for it in range(2):   # first pass warms the table caches; the second is reported
@@ -144,12 +173,11 @@ def cpu_baseline_worker(workload, n_graphs, threads):
         times.append(time.perf_counter() - t0)
         print(f"[cpu-baseline] pass {it}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
     print(json.dumps({"value": round(n_graphs / times[-1], 4), "unit": "graphs/s", "cores": threads, "kind": "port",
-                      "sample": f"{n_graphs} graphs of {workload}: oracle forward+CE+backward (no Adam), "
+                      "sample": f"first {n_graphs} graphs of {workload}: oracle forward+CE+backward (no Adam), "
                                 f"{threads} torch threads, {times[-1]:.1f} s"}), flush=True)
 
 
 def cpu_baseline(workload, n_graphs, limit_s=300):
-    import subprocess
     threads = host_cores()
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads),
                MKL_NUM_THREADS=str(threads))
@@ -163,10 +191,27 @@ def cpu_baseline(workload, n_graphs, limit_s=300):
                 "sample": f"not measured: {type(e).__name__}"}
 
 
+# ------------------------------------------------------------------------------------------------ launching N ranks
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process (this
+    process has not touched the GPU and never will) and pass its output through."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args.workload, args.cpu_graphs, args.cpu_threads or host_cores())
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -207,19 +252,33 @@ def main():
     from singa_amd.optim import Adam
     opt = Adam(model.parameters(), lr=cfg.train.optimizer.lr,
                betas=(cfg.train.optimizer.beta1, cfg.train.optimizer.beta2))
-    batch = G.synthetic_batch(n_graphs, first_id=rank * n_graphs, **kw).to(dev)   # this rank's shard, resident in HBM
-    # a second resident copy: steps alternate between the two, so that batch i+1 can be prepared while step i computes
-    batches = [batch, batch if args.no_prefetch else G.synthetic_batch(n_graphs, first_id=rank * n_graphs, **kw).to(dev)]
-    from singa_amd.engine import TrainStep
-    engine = TrainStep(model, opt, reducer if world > 1 else None, use_graph=use_graph,
-                       max_grad_norm=float(cfg.train.max_grad_norm))
 
     def log(msg):
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-    log(f"workload {args.workload}: {n_graphs} graphs/GPU, L={L}; model + batch ready; "
-        f"{'HIP-graph replay' if use_graph else 'eager'} step")
+    # ---- this rank's graphs (resident in HBM before the timed region starts)
+    if args.scaling == "strong" and world > 1:
+        costs = [G.graph_cost(G.graph_sizes(i, **kw)) for i in range(n_graphs)]
+        lo, hi = dp.shard_ranges_by_cost(costs, world)[rank]
+        ids = list(range(lo, hi))
+        reducer.set_shard_weight(len(ids), n_graphs)
+        graphs_per_step = n_graphs
+    else:
+        ids = list(range(rank * n_graphs, (rank + 1) * n_graphs))
+        graphs_per_step = n_graphs * world
+    t_gen = time.perf_counter()
+    batch = G.synthetic_batch(len(ids), ids=ids, **kw).to(dev)
+    # a second resident copy: steps alternate between the two, so that batch i+1 can be prepared while step i computes
+    import copy
+    batches = [batch, batch if args.no_prefetch else copy.deepcopy(batch)]
+    from singa_amd.engine import TrainStep
+    engine = TrainStep(model, opt, reducer if world > 1 else None, use_graph=use_graph,
+                       max_grad_norm=float(cfg.train.max_grad_norm))
+    n_nodes = batch[G.PA]["x"].shape[0] + batch[G.LA]["x"].shape[0]
+    n_edges = sum(int(batch[et]["edge_index"].shape[1]) for et in (G.E_PP, G.E_LL, G.E_LP, G.E_PL))
+    log(f"workload {args.workload}: {len(ids)} graphs on this GPU ({n_nodes} atoms, {n_edges} edges), L={L}, generated in "
+        f"{time.perf_counter() - t_gen:.1f} s; {'HIP-graph replay' if use_graph else 'eager'} step")
     for i in range(args.warmup):
         t_w = time.perf_counter()
         loss = engine.step(batch)
@@ -261,58 +320,82 @@ def main():
     prepare_ms = (time.perf_counter() - t_p) / 3 * 1e3
 
     # ---- instrumented pass for the roofline: the same step run eagerly with start/stop events attached to every
-    # scatter-TP forward dispatch (graph replays cannot carry per-dispatch events); not part of `value`.
-    if use_graph and args.roofline_steps > 0:
-        engine.release()              # give the graph pool back before the eager instrumented steps
-    ops.profile_start()
-    for _ in range(args.roofline_steps):
-        engine.eager_step(batch)
-    torch.cuda.synchronize()
-    recs = ops.profile_collect()
-    if os.environ.get("SINGA_CALIB") == "1" and rank == 0:
-        # known-byte launches for calibrating FETCH_SIZE / WRITE_SIZE under `rocprofv3 --pmc`
-        import ctypes
-        from singa_amd import _lib
-        n = 64 * 1024 * 1024
-        a = torch.randn(n, device=dev)
-        b = torch.empty_like(a)
-        for _ in range(3):
-            _lib.lib().singa_calib_copy(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n,
-                                        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
-        torch.cuda.synchronize()
-
+    # k4 / k10 dispatch (graph replays cannot carry per-dispatch events); not part of `value`.
     roof = None
-    if recs:
-        big = max(r[1] for r in recs)                     # dispatches with the most edges = the protein-protein passes
-        sel = [r for r in recs if r[1] == big]
-        ms = sum(r[0] for r in sel) / len(sel)
-        log("k10 forward launches on the bonded edges (us): " + " ".join(f"{r[0] * 1e3:.1f}" for r in sel))
-        E, N = sel[0][1], sel[0][2]
-        by = k10_algorithmic_bytes(E, N, L)
-        ach = by / (ms * 1e-3) / 1e9
-        tr = pmc_traffic(L, N)
-        roof = {"bound": "hbm", "kernel": "rotate_back_scatter_kernel (k10 fwd on the bonded edges: protein-protein U "
-                                          "ligand-ligand pass)",
-                "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": tr[0] if tr else None,
-                "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, {tr[1]}" if tr else None),
-                "bytes_per_launch": by, "avg_launch_us": round(ms * 1e3, 2), "launches": len(sel),
-                "edges": E, "dst_nodes": N, "timing": f"start/stop events attached to each dispatch, {args.roofline_steps} instrumented eager steps "
-                          "right after the timed region (same process, same batch)"}
+    if args.roofline_steps > 0:
+        if use_graph:
+            engine.release()              # give the graph pool back before the eager instrumented steps
+        engine.eager_step(batch)          # one un-instrumented eager step first (allocator warm-up)
+        ops.profile_start()
+        for _ in range(args.roofline_steps):
+            engine.eager_step(batch)
+        torch.cuda.synchronize()
+        recs = ops.profile_collect()
+        if os.environ.get("SINGA_CALIB") == "1" and rank == 0:
+            # known-byte launches for calibrating FETCH_SIZE / WRITE_SIZE under `rocprofv3 --pmc`
+            import ctypes
+            from singa_amd import _lib
+            n = 64 * 1024 * 1024
+            a = torch.randn(n, device=dev)
+            b = torch.empty_like(a)
+            for _ in range(3):
+                _lib.lib().singa_calib_copy(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n,
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+        prof = committed_profile(args.workload)
+        per = {}
+        if recs:
+            big = max(r[2] for r in recs)                 # dispatches with the most edges = the bonded-edge union pass
+            n_union = max(r[3] for r in recs if r[2] == big and r[0] == "k10_fwd")
+            for tag in ("k10_fwd", "k10_bwd", "k4_fwd", "k4_bwd_rad", "k4_bwd_dst", "k4_bwd_src"):
+                sel = [r for r in recs if r[0] == tag and r[2] == big]
+                if not sel:
+                    continue
+                us = 1e3 * sum(r[1] for r in sel) / len(sel)
+                by = kernel_bytes(tag, big, n_union, L)
+                ach = by / (us * 1e-6) / 1e9
+                per[tag] = {"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_us": round(us, 2),
+                            "bytes_per_launch": by, "launches": len(sel)}
+            log("bonded-edge launches (us): " + "; ".join(f"{k} {v['avg_launch_us']}" for k, v in per.items()))
+        if "k10_fwd" in per:
+            k = per["k10_fwd"]
+            tr = pmc_traffic(prof, f"rotate_back_scatter_kernel<{L}, 2, false", n_union * 128)
+            sha = lib_source_sha()
+            roof = {"bound": "hbm", "kernel": "rotate_back_scatter_kernel (k10 fwd, 'scatter-TP', on the bonded edges: "
+                                              "protein-protein U ligand-ligand pass)",
+                    "achieved": k["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["frac"],
+                    "traffic": tr,
+                    "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command: "
+                                       f"{os.path.relpath(prof[0], ROOT)} (library source sha {prof[1].get('lib_sha')}; "
+                                       f"{'same as' if prof[1].get('lib_sha') == sha else 'OLDER than'} this build {sha})"
+                                       if tr else None),
+                    "bytes_per_launch": k["bytes_per_launch"], "avg_launch_us": k["avg_launch_us"], "launches": k["launches"],
+                    "edges": big, "dst_nodes": n_union,
+                    "timing": f"start/stop events attached to each dispatch, {args.roofline_steps} instrumented eager steps "
+                              "right after the timed region (same process, same batch)",
+                    "other_kernels": {t: v for t, v in per.items() if t != "k10_fwd"}}
+            if prof and prof[1].get("mfma"):
+                roof["mfma"] = dict(prof[1]["mfma"], source=os.path.relpath(prof[0], ROOT), peak_tflops=MFMA_F32_PEAK_TFLOPS)
 
     if rank == 0:
-        total_graphs = n_graphs * world * args.steps
+        sizes = [G.graph_sizes(i, **kw) for i in ids]
+        mean = lambda k: round(sum(s[k] for s in sizes) / len(sizes), 1)
         out = {"metric": baseline_metric(),
-               "value": round(total_graphs / elapsed, 3), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": args.workload, "graphs_per_gpu": n_graphs, "lmax": L, "mmax": 2,
-                          "nodes_per_graph": kw["n_protein"] + kw["n_ligand"],
-                          "edges_per_graph": kw["e_pp"] + kw["e_ll"] + 2 * kw["e_x"],
+               "value": round(graphs_per_step * args.steps / elapsed, 3), "unit": "graphs/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+               "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic",
+               "config": {"workload": args.workload, "global_batch": graphs_per_step, "graphs_per_gpu": len(ids), "lmax": L,
+                          "mmax": 2, "ragged": "ragged" in kw,
+                          "atoms_on_this_gpu": n_nodes, "edges_on_this_gpu": n_edges,
+                          "mean_protein_atoms": mean("n_protein"), "mean_ligand_atoms": mean("n_ligand"),
+                          "mean_edges_per_graph": round(n_edges / len(ids), 1),
                           "parallelism": f"dp{world}",
                           "step": "prepare+zero_grad+fwd+CE+bwd+allreduce+clip+Adam of the generator (the reference has no discriminator)",
                           "launch": "hipGraph replay" if use_graph else "eager",
-                          "prepare": "in step" if args.no_prefetch else "prefetched on a second stream during the previous step", "prepare_ms_of_step": round(prepare_ms, 2),
+                          "batches": "one resident batch per GPU, its graph structure rebuilt every step",
+                          "prepare": "in step" if args.no_prefetch else "prefetched on a second stream during the previous step",
+                          "prepare_ms_of_step": round(prepare_ms, 2), "graph_captures": engine.captures,
                           "grad_allreduce_bytes": reducer.payload_bytes},
                "final_loss": round(final_loss, 5), "roofline": roof}
         if not args.no_cpu_baseline and world == 1:
@@ -325,4 +408,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -263,6 +263,14 @@ int singa_adam_step(float* const* p, const float* const* g, float* const* m, flo
 int singa_prof_enable(int on);
 int singa_prof_hint_edges(int E);
 int singa_prof_collect(float* ms, int* edges, int* nodes, int cap); /* after synchronising; returns #records */
+/* kernel tags of the profiled dispatches (bench.py's roofline block) */
+#define SINGA_PROF_K10_FWD 1     /* rotate_back_scatter forward ("scatter-TP") */
+#define SINGA_PROF_K10_BWD 2
+#define SINGA_PROF_K4_FWD 3      /* gather_rotate forward */
+#define SINGA_PROF_K4_BWD_RAD 4  /* gather_rotate backward w.r.t. the radial weights (edge-parallel) */
+#define SINGA_PROF_K4_BWD_DST 5  /* ... w.r.t. the destination node rows */
+#define SINGA_PROF_K4_BWD_SRC 6  /* ... w.r.t. the source node rows */
+int singa_prof_collect_tagged(float* ms, int* tags, int* edges, int* nodes, int cap);
 int singa_calib_copy(const float* src, float* dst, long long n, void* stream);
 
 #ifdef __cplusplus

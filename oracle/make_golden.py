@@ -11,8 +11,9 @@ outputs) are written. What is recorded, per SURVEY.md §8c:
                           final embeddings, and parameter-gradient norms of sum-of-squares loss
   wigner_L6.npz           RotationToWignerDMatrix output for 16 edges (reference model/EF_layers.py:508-528)
   singa_L<L>_B3.npz       full SINGA forward + CrossEntropy + backward (reference model/GAN.py:25-81,
-                          train.py:119-124) on the 3-graph batch, eval-mode dropout, with the kNN graphs
-                          and Laplacian PEs that were used recorded as inputs
+                          train.py:119-124) on the 3-graph batch for L = 2, 4, 6, eval-mode dropout, with the kNN
+                          graphs and Laplacian PEs that were used recorded as inputs; logits, loss, per-parameter
+                          gradient norms and up to 512 gradient elements of every parameter
   param_spec_L<L>.npz     (name, shape, mean, std) of every reference parameter -> oracle/weights.py
 """
 import os
@@ -205,6 +206,11 @@ def run_singa(L, rec):
     d["grad_total"] = np.array(tot)
     d["grad_names"] = np.array(list(gn.keys()))
     d["grad_norms"] = np.array(list(gn.values()))
+    # element-wise gradient samples of EVERY parameter (a norm cannot see a permuted or sign-flipped block): up to 512
+    # evenly spaced elements of each flattened gradient (W.sample_index), concatenated in parameter order
+    samples = [p.grad.reshape(-1)[torch.as_tensor(W.sample_index(p.numel()))].numpy()
+               for _, p in model.named_parameters() if p.grad is not None]
+    d["grad_samples"] = np.concatenate(samples).astype(np.float32)
     np.savez_compressed(os.path.join(OUT, f"singa_L{L}_B3.npz"), **d)
     print(f"singa L={L}: loss {float(loss):.6f} grad {tot:.4f}")
 
@@ -216,5 +222,5 @@ if __name__ == "__main__":
     rec = Recorder().install()
     for L in (2, 4, 6):
         run_embedding(L, rec)
-    for L in (2, 6):
+    for L in (2, 4, 6):
         run_singa(L, rec)

@@ -400,7 +400,10 @@ def decoder_forward(sd, pre, tokens, prop, enc, pad, pad_id=110):
     dc = pre + "decoder"
     B, Tn = tokens.shape
     n_layers = 1 + max(int(k[len(dc) + 8:].split(".")[0]) for k in sd if k.startswith(dc + ".layers."))
-    x = sd[dc + ".mol_emb.weight"][tokens] + sd[dc + ".pos_emb.pe"][:Tn, 0].unsqueeze(0) + sd[dc + ".type_emb.weight"][1]
+    # nn.Embedding(len(smiVoc), hidden, 0) at CP:377: padding_idx = 0 (Q9: that is token '#', not the pad token), so row 0
+    # is looked up like any other but never receives a gradient
+    x = (F.embedding(tokens, sd[dc + ".mol_emb.weight"], padding_idx=0) + sd[dc + ".pos_emb.pe"][:Tn, 0].unsqueeze(0)
+         + sd[dc + ".type_emb.weight"][1])
     ptok = lin(sd, dc + ".prop_nn", prop.unsqueeze(1)) + sd[dc + ".type_emb.weight"][0]
     x = torch.cat([ptok, x], 1)
     ids = torch.cat([torch.ones(B, 1), tokens.to(torch.float32)], 1)
@@ -513,3 +516,30 @@ def train_step_loss(sd, g, rots, L, lap_p, lap_l, knn_p=None, knn_l=None):
         knn_l = knn_graph(g["pos_l"], 30, bl)
     logits = singa_forward(sd, g, rots, L, knn_p, knn_l, lap_p, lap_l)
     return F.cross_entropy(logits, g["tok_tgt"].reshape(-1))
+
+
+def batch_from_graphs(graphs):
+    """Oracle inputs for a list of product-side graph containers (singa_amd.graph.HeteroGraph as made by the synthetic
+    generator: field names of the reference's HeteroData, GAN:26-49; `extras['rot_rand']` = the uniform draws of EF:2301;
+    `lap_pe` on the node stores).  Returns (collated dict, edge frames per pass, lap_p, lap_l).  Only reads tensors: the
+    product module is not imported here."""
+    E_PP, E_LL = (PA, "linked_to", PA), (LA, "linked_to", LA)
+    E_LP, E_PL = (LA, "interact_with", PA), (PA, "interact_with", LA)
+    og = []
+    for g in graphs:
+        ld = g["ligand_data"]
+        og.append({"x_p": g[PA]["x"], "pos_p": g[PA]["pos"], "z_p": g["atomicnum"][PA],
+                   "x_l": g[LA]["x"], "pos_l": g[LA]["pos"], "z_l": g["atomicnum"][LA],
+                   "ei_pp": g[E_PP]["edge_index"], "ei_ll": g[E_LL]["edge_index"],
+                   "ei_lp": g[E_LP]["edge_index"], "ei_pl": g[E_PL]["edge_index"],
+                   "tok_in": ld["smiIndices_input"], "tok_tgt": ld["smiIndices_tgt"],
+                   "props": torch.tensor([ld[k] for k in ("vina_score", "qed", "sas")], dtype=torch.float64)})
+    b = collate(og)
+    rand = {k: torch.cat([g.extras["rot_rand"][k] for g in graphs], 0) for k in ("pp", "ll", "lp")}
+    vec = {"pp": b["pos_p"][b["ei_pp"][0]] - b["pos_p"][b["ei_pp"][1]],
+           "ll": b["pos_l"][b["ei_ll"][0]] - b["pos_l"][b["ei_ll"][1]],
+           "lp": b["pos_l"][b["ei_lp"][0]] - b["pos_p"][b["ei_lp"][1]]}
+    rots = {k: edge_rot_mat(vec[k], rand[k]) for k in vec}
+    lap_p = torch.cat([g[PA]["lap_pe"] for g in graphs], 0)
+    lap_l = torch.cat([g[LA]["lap_pe"] for g in graphs], 0)
+    return b, rots, lap_p, lap_l

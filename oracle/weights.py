@@ -27,3 +27,10 @@ def spec_from_module(module):
     for n, p in module.named_parameters():
         out.append((n, tuple(p.shape), float(p.detach().mean()), float(p.detach().std()) if p.numel() > 1 else 0.0))
     return out
+
+
+def sample_index(n, cap=512):
+    """Indices of the gradient elements recorded per parameter in the golden files: up to `cap` evenly spaced positions
+    of the flattened tensor (deterministic; the tests recompute the same positions)."""
+    import numpy as np
+    return np.unique(np.linspace(0, n - 1, min(n, cap)).round().astype(np.int64))

@@ -67,6 +67,7 @@ _SIGS = {
     "singa_prof_enable": ([I32], I32),
     "singa_prof_hint_edges": ([I32], I32),
     "singa_prof_collect": ([P, P, P, I32], I32),
+    "singa_prof_collect_tagged": ([P, P, P, P, I32], I32),
     "singa_calib_copy": ([P, P, C.c_longlong, P], I32),
 }
 

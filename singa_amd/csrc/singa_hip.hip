@@ -44,13 +44,29 @@ int check_launch(const char* what) {
 // on the caller's stream.  singa_prof_collect() reads them back after the caller has synchronised.
 struct ProfRec {
     hipEvent_t a, b;
-    int E, N;
+    int E, N, tag;
 };
 constexpr int PROF_CAP = 8192;
 ProfRec g_prof[PROF_CAP];
 int g_prof_n = 0;
 bool g_prof_on = false;
 int g_prof_edges_hint = 0;  // E of the next profiled launch (the kernel itself only needs row_ptr)
+
+// SINGA_LAUNCH(tag, E, N, kernel, grid, block, stream, args...): a plain launch, or - while profiling is enabled - the same
+// launch with a start/stop event pair attached to the dispatch and a (tag, E, N) record for singa_prof_collect_tagged.
+#define SINGA_LAUNCH(tag_, E_, N_, kern, grid, block, st, ...)                                                   \
+    do {                                                                                                          \
+        if (g_prof_on && g_prof_n < PROF_CAP) {                                                                   \
+            ProfRec& r_ = g_prof[g_prof_n++];                                                                     \
+            (void)hipEventCreate(&r_.a);                                                                          \
+            (void)hipEventCreate(&r_.b);                                                                          \
+            r_.E = (E_);                                                                                          \
+            r_.N = (N_);                                                                                          \
+            r_.tag = (tag_);                                                                                      \
+            hipExtLaunchKernelGGL(kern, grid, block, 0, (st), r_.a, r_.b, 0, __VA_ARGS__);                        \
+        } else                                                                                                    \
+            hipLaunchKernelGGL(kern, grid, block, 0, (st), __VA_ARGS__);                                          \
+    } while (0)
 
 constexpr int MAX_J = 2300;  // sum_{l<=11} (2l+1)^2
 __device__ float g_J[MAX_J];
@@ -2436,6 +2452,25 @@ int singa_prof_collect(float* ms, int* edges, int* nodes, int cap) {
     return n;
 }
 
+int singa_prof_collect_tagged(float* ms, int* tags, int* edges, int* nodes, int cap) {
+    int n = 0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        float t = 0.f;
+        hipError_t e = hipEventElapsedTime(&t, g_prof[i].a, g_prof[i].b);
+        if (e == hipSuccess && n < cap) {
+            ms[n] = t;
+            tags[n] = g_prof[i].tag;
+            edges[n] = g_prof[i].E;
+            nodes[n] = g_prof[i].N;
+            ++n;
+        }
+        (void)hipEventDestroy(g_prof[i].a);
+        (void)hipEventDestroy(g_prof[i].b);
+    }
+    g_prof_n = 0;
+    return n;
+}
+
 int singa_calib_copy(const float* src, float* dst, long long n, void* stream) {
     if (!src || !dst) return fail(SINGA_E_NULL, "calib_copy: null pointer");
     hipLaunchKernelGGL(calib_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, src, dst, n);
@@ -2491,8 +2526,8 @@ int singa_gather_rotate_fwd(const float* x_src, const float* x_dst, const int32_
     if (C != 16) return fail(SINGA_E_SHAPE, "gather_rotate: built for C = 16 sphere channels");
     if (E <= 0) return SINGA_OK;
     SINGA_DISPATCH_L(lmax, mmax, {
-        hipLaunchKernelGGL((gather_rotate_kernel<L_, 2, 16, 0>), dim3(grid_for(E)), dim3(64), 0, (hipStream_t)stream,
-                           x_src, x_dst, src, dst, wr, rad, (const float*)nullptr, out, E);
+        SINGA_LAUNCH(SINGA_PROF_K4_FWD, E, 0, (gather_rotate_kernel<L_, 2, 16, 0>), dim3(grid_for(E)), dim3(64),
+                     (hipStream_t)stream, x_src, x_dst, src, dst, wr, rad, (const float*)nullptr, out, E);
     });
     return check_launch("gather_rotate_fwd");
 }
@@ -2508,14 +2543,14 @@ int singa_gather_rotate_bwd(const float* g_out, const float* x_src, const float*
     SINGA_DISPATCH_L(lmax, mmax, {
         hipStream_t st = (hipStream_t)stream;
         if (g_rad && E > 0)
-            hipLaunchKernelGGL((gather_rotate_kernel<L_, 2, 16, 1>), dim3(grid_for(E)), dim3(64), 0, st, x_src, x_dst,
-                               src, dst, wr, rad, g_out, g_rad, E);
+            SINGA_LAUNCH(SINGA_PROF_K4_BWD_RAD, E, 0, (gather_rotate_kernel<L_, 2, 16, 1>), dim3(grid_for(E)), dim3(64), st,
+                         x_src, x_dst, src, dst, wr, rad, g_out, g_rad, E);
         if (Nd > 0)
-            hipLaunchKernelGGL((gather_rotate_bwd_node_kernel<L_, 2, 16, 0>), dim3(grid_for(Nd)), dim3(64), 0, st,
-                               g_out, wr, rad, row_ptr, (const int*)nullptr, gx_dst, Nd);
+            SINGA_LAUNCH(SINGA_PROF_K4_BWD_DST, E, Nd, (gather_rotate_bwd_node_kernel<L_, 2, 16, 0>), dim3(grid_for(Nd)),
+                         dim3(64), st, g_out, wr, rad, row_ptr, (const int*)nullptr, gx_dst, Nd);
         if (Ns > 0)
-            hipLaunchKernelGGL((gather_rotate_bwd_node_kernel<L_, 2, 16, 1>), dim3(grid_for(Ns)), dim3(64), 0, st,
-                               g_out, wr, rad, col_ptr, eperm, gx_src, Ns);
+            SINGA_LAUNCH(SINGA_PROF_K4_BWD_SRC, E, Ns, (gather_rotate_bwd_node_kernel<L_, 2, 16, 1>), dim3(grid_for(Ns)),
+                         dim3(64), st, g_out, wr, rad, col_ptr, eperm, gx_src, Ns);
     });
     return check_launch("gather_rotate_bwd");
 }
@@ -2538,19 +2573,10 @@ int singa_rotate_back_scatter_fwd(const singa_seg_t* msg, int nseg, const float*
         if (m0_only)
             hipLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, true, 4, 16, 16>), dim3(grid_for(Nd, 1 << 20)), dim3(bs),
                                0, (hipStream_t)stream, s, alpha, wr, row_ptr, out, Nd, out_scale);
-        else if (g_prof_on && g_prof_n < PROF_CAP) {
-            ProfRec& r = g_prof[g_prof_n++];
-            (void)hipEventCreate(&r.a);
-            (void)hipEventCreate(&r.b);
-            r.E = n_edges_hint;
-            r.N = Nd;
-            hipExtLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, false, (L_ == 2 ? 4 : 0), 112, 16>),
-                                  dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0, (hipStream_t)stream, r.a, r.b, 0, s, alpha, wr,
-                                  row_ptr, out, Nd, out_scale);
-        } else
-            hipLaunchKernelGGL((rotate_back_scatter_kernel<L_, 2, false, (L_ == 2 ? 4 : 0), 112, 16>),
-                               dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0, (hipStream_t)stream, s, alpha, wr, row_ptr, out,
-                               Nd, out_scale);
+        else
+            SINGA_LAUNCH(SINGA_PROF_K10_FWD, n_edges_hint, Nd,
+                         (rotate_back_scatter_kernel<L_, 2, false, (L_ == 2 ? 4 : 0), 112, 16>), dim3(grid_for(Nd, 1 << 20)),
+                         dim3(bs), (hipStream_t)stream, s, alpha, wr, row_ptr, out, Nd, out_scale);
     });
     return check_launch("rotate_back_scatter_fwd");
 }
@@ -2577,8 +2603,9 @@ int singa_rotate_back_scatter_bwd(const float* g_out, const singa_seg_t* msg, co
             hipLaunchKernelGGL((rotate_back_scatter_bwd_kernel<L_, 2, true, 16, 16>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
                                (hipStream_t)stream, g_out, s, gm, alpha, wr, row_ptr, g_alpha_part, Nd, out_scale);
         else
-            hipLaunchKernelGGL((rotate_back_scatter_bwd_kernel<L_, 2, false, 112, 16>), dim3(grid_for(Nd, 1 << 20)), dim3(bs), 0,
-                               (hipStream_t)stream, g_out, s, gm, alpha, wr, row_ptr, g_alpha_part, Nd, out_scale);
+            SINGA_LAUNCH(SINGA_PROF_K10_BWD, g_prof_edges_hint, Nd, (rotate_back_scatter_bwd_kernel<L_, 2, false, 112, 16>),
+                         dim3(grid_for(Nd, 1 << 20)), dim3(bs), (hipStream_t)stream, g_out, s, gm, alpha, wr, row_ptr,
+                         g_alpha_part, Nd, out_scale);
     });
     return check_launch("rotate_back_scatter_bwd");
 }

@@ -41,19 +41,29 @@ class GradAllReducer:
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
         assert float(hi - lo) == 0.0, "ranks were not initialised with identical parameters"
 
+    def set_shard_weight(self, n_local, n_global):
+        """Shards of different sizes (batch % world != 0, or `shard_ranges_by_cost`): every rank's CrossEntropy is a mean
+        over ITS tokens, so the global-batch gradient is sum_r (tokens_r / tokens) grad_r, not the plain average.  All
+        graphs carry the same number of target tokens (tgt_len), hence the weight n_local / n_global."""
+        self.weight = float(n_local) / float(n_global)
+
+    weight = None
+
     def reduce(self):
-        """Average .grad over ranks in place. Call after backward(), before the optimizer step."""
+        """Combine .grad over ranks in place: the mean over ranks, or - after `set_shard_weight` - the token-weighted sum.
+        Call after backward(), before the optimizer step."""
         if self.world == 1:
             return
         if self.buckets is None:
             self._build()
+        pre = self.weight if self.weight is not None else 1.0 / self.world
         works = []
         for flat, bucket in zip(self.flat, self.buckets):
             torch._foreach_copy_(list(flat.split([p.numel() for p in bucket])), [p.grad.reshape(-1) for p in bucket])
+            flat.mul_(pre)
             works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w, flat, bucket in zip(works, self.flat, self.buckets):
             w.wait()
-            flat.div_(self.world)
             torch._foreach_copy_([p.grad.reshape(-1) for p in bucket], list(flat.split([p.numel() for p in bucket])))
 
     @property

@@ -197,17 +197,42 @@ def synthetic_graph(graph_id, n_protein=200, n_ligand=30, e_pp=1700, e_ll=64, e_
     return g
 
 
+def ragged_sizes(graph_id, n_protein=(230, 470), n_ligand=(25, 35), e_pp_per_node=2.0, e_ll_per_node=2.2, e_x=80):
+    """Sizes of synthetic graph `graph_id` of a CrossDocked-shaped (ragged) workload, SURVEY.md §8d config 3: Np ~ U[230,470],
+    Nl ~ U[25,35] (integers, inclusive), Epp = 2 Np, Ell ~ 2.2 Nl (even: both directions of each bond), Ex = 80 - the
+    statistics of the bundled example graphs.  Drawn from their own stream so that the graph's content stream
+    (default_rng(1000 + graph_id)) is the same as for a fixed-size graph."""
+    rng = np.random.default_rng(77_000_000 + graph_id)
+    n_p = int(rng.integers(n_protein[0], n_protein[1] + 1))
+    n_l = int(rng.integers(n_ligand[0], n_ligand[1] + 1))
+    e_ll = 2 * int(round(e_ll_per_node * n_l / 2))
+    return dict(n_protein=n_p, n_ligand=n_l, e_pp=2 * int(round(e_pp_per_node * n_p / 2)), e_ll=e_ll, e_x=int(e_x))
+
+
 WORKLOADS = {
-    # SURVEY.md §8d configs 2, 3 (fixed-size variant), 5
+    # SURVEY.md §8d configs 2, 3 (ragged, as the survey defines it; config 4 = the same batch sharded over the ranks), 5
     "cfg2_b32_l2": dict(n_graphs=32, lmax=2, n_protein=200, n_ligand=30, e_pp=1700, e_ll=64, e_x=118),
-    "cfg3_b128_l4": dict(n_graphs=128, lmax=4, n_protein=350, n_ligand=30, e_pp=700, e_ll=66, e_x=80),
+    "cfg3_b128_l4": dict(n_graphs=128, lmax=4, ragged=dict(n_protein=(230, 470), n_ligand=(25, 35), e_pp_per_node=2.0,
+                                                            e_ll_per_node=2.2, e_x=80)),
+    "cfg3_fixed_b128_l4": dict(n_graphs=128, lmax=4, n_protein=350, n_ligand=30, e_pp=700, e_ll=66, e_x=80),
     "cfg5_l6": dict(n_graphs=64, lmax=6, n_protein=800, n_ligand=40, e_pp=7600, e_ll=88, e_x=156),
     "cfg5_l6_b8": dict(n_graphs=8, lmax=6, n_protein=800, n_ligand=40, e_pp=7600, e_ll=88, e_x=156),
 }
 
 
-def synthetic_batch(n_graphs, first_id=0, **kw):
-    return collate([synthetic_graph(first_id + i, **kw) for i in range(n_graphs)])
+def graph_sizes(graph_id, ragged=None, **kw):
+    """Generator arguments of synthetic graph `graph_id` of a workload (fixed sizes, or drawn per graph when `ragged`)."""
+    return ragged_sizes(graph_id, **ragged) if ragged else dict(kw)
+
+
+def graph_cost(sizes):
+    """Edge count E_pp + E_ll + 2 E_x of a graph: the cost driver by which shards are balanced."""
+    return sizes["e_pp"] + sizes["e_ll"] + 2 * sizes["e_x"]
+
+
+def synthetic_batch(n_graphs, first_id=0, ragged=None, ids=None, **kw):
+    ids = range(first_id, first_id + n_graphs) if ids is None else ids
+    return collate([synthetic_graph(i, **graph_sizes(i, ragged, **kw)) for i in ids])
 
 
 # ----------------------------------------------------------------------------------------------- reference .pt graphs

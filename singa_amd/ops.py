@@ -26,16 +26,20 @@ def profile_start():
     _chk(_lib.lib().singa_prof_enable(1), "singa_prof_enable")
 
 
+PROF_TAGS = {1: "k10_fwd", 2: "k10_bwd", 3: "k4_fwd", 4: "k4_bwd_rad", 5: "k4_bwd_dst", 6: "k4_bwd_src"}   # include/singa_hip.h
+
+
 def profile_collect():
-    """Call after torch.cuda.synchronize().  Returns [(ms, n_edges, n_dst_nodes)] for every profiled dispatch."""
+    """Call after torch.cuda.synchronize().  Returns [(kernel tag name, ms, n_edges, n_nodes)] for every profiled
+    dispatch (tags: SINGA_PROF_* of include/singa_hip.h)."""
     global PROFILE_ON
     PROFILE_ON = False
     lib = _lib.lib()
     _chk(lib.singa_prof_enable(0), "singa_prof_enable")
     cap = 8192
-    ms, ne, nn = (ctypes.c_float * cap)(), (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
-    n = lib.singa_prof_collect(ms, ne, nn, cap)
-    return [(ms[i], ne[i], nn[i]) for i in range(n)]
+    ms, tg, ne, nn = (ctypes.c_float * cap)(), (ctypes.c_int * cap)(), (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
+    n = lib.singa_prof_collect_tagged(ms, tg, ne, nn, cap)
+    return [(PROF_TAGS.get(tg[i], str(tg[i])), ms[i], ne[i], nn[i]) for i in range(n)]
 
 
 def _stream():
@@ -167,6 +171,8 @@ class _RotateBackScatter(torch.autograd.Function):
         gap = torch.empty(es.E, CH, device=g.device, dtype=torch.float32)
         seg, n = _segs3((y0, y1, y2), lay.seg_rows, CH)
         gseg, _ = _segs3(gy, lay.seg_rows, CH)
+        if PROFILE_ON:
+            _lib.lib().singa_prof_hint_edges(es.E)
         _chk(_lib.lib().singa_rotate_back_scatter_bwd(_p(g), seg, gseg, n, _p(alpha), _p(wr), _p(es.row_ptr), _p(gap),
                                                       es.n_dst, CH, heads, L, M, 0, 1.0, _stream()),
              "singa_rotate_back_scatter_bwd")

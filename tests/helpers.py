@@ -58,3 +58,24 @@ def apply_beam_gains(weight, z):
     with torch.no_grad():
         weight.mul_(float(z["proj_gain"]))
         weight[smi_voc().index("$")] *= float(z["eos_gain"])
+
+
+def grad_sample_errors(named_grads, z, tol):
+    """Compare the element-wise gradient samples of a singa_L*_B3 golden (up to 512 evenly spaced elements of every
+    parameter's gradient, oracle/make_golden.py) with `named_grads` = {name: grad or None}.  Returns the list of
+    parameters whose samples differ by more than `tol` relative (L2 over the parameter's samples)."""
+    bad, off = [], 0
+    flat = z["grad_samples"]
+    for n, ref in zip(z["grad_names"], z["grad_norms"]):
+        if ref < 0:
+            continue
+        gr = named_grads[str(n)]
+        idx = W.sample_index(gr.numel())
+        want = torch.as_tensor(flat[off:off + len(idx)], dtype=torch.float64)
+        off += len(idx)
+        got = gr.detach().reshape(-1).cpu()[torch.as_tensor(idx)].double()
+        err = float((got - want).norm() / (want.norm() + 1e-12))
+        if err > tol and float((got - want).abs().max()) > 1e-7:
+            bad.append((str(n), err))
+    assert off == len(flat), (off, len(flat))
+    return bad

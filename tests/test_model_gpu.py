@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import singa_oracle as O
-from tests.helpers import NAMES, golden, product_batch, rel_err, state_from_spec
+from tests.helpers import NAMES, golden, grad_sample_errors, product_batch, rel_err, state_from_spec
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -79,7 +79,7 @@ def test_block0_intermediates_match_reference(L):
     assert rel_err(out.embedding[::st].detach().cpu(), z["b0_out_pp"]) < 1e-4
 
 
-@pytest.mark.parametrize("L", [2, 6])
+@pytest.mark.parametrize("L", [2, 4, 6])
 def test_singa_step_matches_reference(L):
     from singa_amd.config import load_config
     from singa_amd.model.GAN import SINGA
@@ -106,6 +106,9 @@ def test_singa_step_matches_reference(L):
                 bad.append((str(n), "unexpected gradient"))
         elif gr is None or abs(float(gr.norm()) - ref) > 3e-3 * ref + 1e-7:
             bad.append((str(n), None if gr is None else float(gr.norm()), float(ref)))
+    assert not bad, bad[:8]
+    # element-wise samples of every parameter's gradient against the reference's
+    bad = grad_sample_errors({n: p.grad for n, p in params.items()}, z, 3e-3)
     assert not bad, bad[:8]
 
 

@@ -4,7 +4,8 @@ import pytest
 import torch
 
 from oracle import singa_oracle as O
-from tests.helpers import BEAM_CASES, NAMES, apply_beam_gains, golden, rel_err, smi_voc, state_from_spec
+from tests.helpers import (BEAM_CASES, NAMES, apply_beam_gains, golden, grad_sample_errors, rel_err, smi_voc,
+                           state_from_spec)
 
 TOL = 2e-5  # fp32 op-order noise between the reference's einsum/bmm chains and the restatement
 
@@ -72,7 +73,7 @@ def test_block0_intermediates(L):
     assert rel_err((f + y)[::st], z["b0_out_pp"]) < TOL
 
 
-@pytest.mark.parametrize("L", [2, 6])
+@pytest.mark.parametrize("L", [2, 4, 6])
 def test_singa_step(L):
     """Full SINGA forward + CE + backward on the 3-graph batch vs the reference (GAN:25-81, train.py:119-124)."""
     sd = {k: v.requires_grad_(True) for k, v in state_from_spec(f"singa_L{L}").items()}
@@ -95,6 +96,9 @@ def test_singa_step(L):
                 bad.append((str(n), "unexpected grad"))
         elif abs(float(gr.norm()) - ref) > 2e-3 * ref + 1e-7:
             bad.append((str(n), float(gr.norm()), float(ref)))
+    assert not bad, bad[:10]
+    # element-wise: up to 512 gradient elements of EVERY parameter (a norm cannot see a permuted or sign-flipped block)
+    bad = grad_sample_errors({k: v.grad for k, v in sd.items()}, z, 3e-3)
     assert not bad, bad[:10]
 
 

@@ -6,6 +6,7 @@ import os
 import sys
 
 raw, out = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else None
 
 
 def short(name):
@@ -63,3 +64,42 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         w.writerow(["kernel", "grid", "counter", "dispatches", "avg_value", "min", "max"])
         for k, v in sorted(agg.items()):
             w.writerow(list(k) + [len(v), sum(v) / len(v), min(v), max(v)])
+
+# ---- MFMA counters (one pass: SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32, SQ_BUSY_CU_CYCLES, GRBM_GUI_ACTIVE)
+mfma = {}
+f = first("pmc_MFMA/**/*counter_collection.csv")
+if f:
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    calls = collections.Counter()
+    for r in csv.DictReader(open(f)):
+        name = short(r.get("Kernel_Name", ""))
+        per[name][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            calls[name] += 1
+    rows = []
+    for name, c in per.items():
+        busy, gui = c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0), c.get("GRBM_GUI_ACTIVE", 0.0)
+        if busy <= 0 or gui <= 0:
+            continue
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; the chip has 1024 SIMDs: utilisation = MFMA-busy cycles summed over
+        # SIMDs / (elapsed cycles x 1024)
+        util = busy / ((gui / 8.0) * 1024.0)
+        rows.append((name, calls[name], busy, c.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0), gui, util))
+    rows.sort(key=lambda r: -r[2])
+    with open(os.path.join(out, "pmc_MFMA.csv"), "w", newline="") as o:
+        w = csv.writer(o)
+        w.writerow(["kernel", "dispatches", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "GRBM_GUI_ACTIVE", "mfma_util"])
+        w.writerows([(r[0], r[1], int(r[2]), int(r[3]), int(r[4]), round(r[5], 4)) for r in rows[:60]])
+    for r in rows[:12]:
+        mfma[r[0][:70]] = {"dispatches": r[1], "mfma_util": round(r[5], 4), "mops_f32": int(r[3])}
+
+import hashlib
+import json
+h = hashlib.sha1()
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for src in ("singa_amd/csrc/singa_hip.hip", "singa_amd/csrc/so3_index.h"):
+    with open(os.path.join(root, src), "rb") as fh:
+        h.update(fh.read())
+json.dump({"workload": workload, "lib_sha": h.hexdigest()[:12],
+           "mfma": {"counters": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), eager pass", "kernels": mfma}
+                   if mfma else None}, open(os.path.join(out, "meta.json"), "w"), indent=1)
