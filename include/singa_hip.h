@@ -257,6 +257,11 @@ int singa_adam_step(float* const* p, const float* const* g, float* const* m, flo
                     const int32_t* chunk_tensor, const long long* chunk_off, int nchunks, int chunk, float* step,
                     const float* lr, float beta1, float beta2, float eps, void* stream);
 
+/* Total 2-norm of all gradients over the same (tensor, chunk) table as singa_adam_step: torch.nn.utils.clip_grad_norm_'s
+ * norm (reference train.py:126), deterministic and HIP-graph replayable.  partial: nchunks floats of scratch; out: 1 float. */
+int singa_grad_norm(const float* const* g, const long long* sizes, const int32_t* chunk_tensor, const long long* chunk_off,
+                    int nchunks, int chunk, float* partial, float* out, void* stream);
+
 /* Measurement helpers (bench.py): exact per-dispatch timing of the scatter-TP forward kernel with start/stop events
  * attached to the dispatch (hipExtLaunchKernelGGL) on the caller's stream, and a copy kernel with the segment kernels'
  * access shape for calibrating the PMC byte counters. */

@@ -9,6 +9,8 @@ outputs) are written. What is recorded, per SURVEY.md §8c:
   embed_L<L>_<name>.npz   EquivariantEmbedding forward (reference model/Embedding.py:205-480): the three
                           edge_rot_mat draws (Q6), edge-degree output, block-0 intermediates of the protein pass,
                           final embeddings, and parameter-gradient norms of sum-of-squares loss
+  rot_rand_<name>.npz     the three torch.rand_like draws the reference's init_edge_rot_mat took (EF:2301) for the
+                          frames recorded in embed_L2_<name>.npz (rot_pp / rot_ll / rot_lp)
   wigner_L6.npz           RotationToWignerDMatrix output for 16 edges (reference model/EF_layers.py:508-528)
   singa_L<L>_B3.npz       full SINGA forward + CrossEntropy + backward (reference model/GAN.py:25-81,
                           train.py:119-124) on the 3-graph batch for L = 2, 4, 6, eval-mode dropout, with the kNN
@@ -153,9 +155,24 @@ def run_embedding(L, rec):
         hooks.append(b0.ffn.register_forward_hook(save("b0_ffn_pp")))
         hooks.append(b0.register_forward_hook(save("b0_out_pp")))
         emb.zero_grad()
-        out = emb(g)
+        draws = []
+        orig_rand_like = torch.rand_like
+
+        def rec_rand_like(*a, **k):       # the reference's own draws inside init_edge_rot_mat (EF:2301, Q6)
+            r = orig_rand_like(*a, **k)
+            draws.append(r.clone())
+            return r
+        torch.rand_like = rec_rand_like
+        try:
+            out = emb(g)
+        finally:
+            torch.rand_like = orig_rand_like
         for h in hooks:
             h.remove()
+        assert len(draws) == 3
+        if L == 2:      # inputs of the edge-frame pin (tests/test_oracle_conventions.py): draw -> frame, per pass
+            np.savez_compressed(os.path.join(OUT, f"rot_rand_{name}.npz"),
+                                **{k: draws[i].numpy() for i, k in enumerate(["pp", "ll", "lp"])})
         loss = (out[PA].embedding ** 2).sum() + (out[LA].embedding ** 2).sum()
         loss.backward()
         gn = {n: (float(p.grad.norm()) if p.grad is not None else -1.0) for n, p in emb.named_parameters()}

@@ -543,3 +543,18 @@ def batch_from_graphs(graphs):
     lap_p = torch.cat([g[PA]["lap_pe"] for g in graphs], 0)
     lap_l = torch.cat([g[LA]["lap_pe"] for g in graphs], 0)
     return b, rots, lap_p, lap_l
+
+
+def laplacian_spectrum(edge_index, n):
+    """Dense normalised Laplacian of ONE graph as dgl.lap_pe defines it (reference model/CProMG.py:562-571 -> dgl 1.1.2
+    `lap_pe`: L = I - D^-1/2 A D^-1/2 with in-degrees clipped at 1) and its ascending eigenvalues, float64 numpy.  The
+    eigenvectors themselves are basis- and sign-dependent (dgl draws random signs, Q11), so tests compare the product's
+    encoding through basis-free properties: orthonormal columns spanning an invariant subspace of L whose Ritz values
+    are eigenvalues 1..k."""
+    ei = np.asarray(edge_index)
+    a = np.zeros((n, n))
+    a[ei[0], ei[1]] = 1.0
+    dinv = np.clip(a.sum(0), 1, None) ** -0.5
+    lap = np.eye(n) - dinv[:, None] * a * dinv[None, :]
+    lap = 0.5 * (lap + lap.T)
+    return lap, np.linalg.eigvalsh(lap)

@@ -2032,6 +2032,44 @@ __global__ void adam_advance_kernel(float* step) {
     if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1.0f;
 }
 
+// Total gradient norm over the same (tensor, chunk) table (clip_grad_norm_ of train.py:126): block b writes the sum of
+// squares of its chunk, a one-block second pass adds the partials in a fixed order (double accumulators) and takes the
+// root.  No cross-launch state, fixed summation order: the value is the same eager and replayed (torch's multi-block
+// reductions were not, on this build - see singa_colsum).
+__global__ void __launch_bounds__(256) grad_sumsq_kernel(const float* const* __restrict__ g, const long long* __restrict__ sizes,
+                                                         const int* __restrict__ chunk_tensor,
+                                                         const long long* __restrict__ chunk_off, int chunk,
+                                                         float* __restrict__ partial) {
+    __shared__ float red[256];
+    const int t = chunk_tensor[blockIdx.x];
+    const long long off = chunk_off[blockIdx.x];
+    const long long n = sizes[t];
+    const float* gg = g[t];
+    const long long end = off + chunk < n ? off + chunk : n;
+    float acc = 0.f;
+    for (long long i = off + threadIdx.x; i < end; i += blockDim.x) acc = fmaf(gg[i], gg[i], acc);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(256) grad_norm_finish_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += (double)partial[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)sqrt(red[0]);
+}
+
 // ------------------------------------------------------------------------------------------------ k8: S2 activation
 // thread = (edge-or-node e, channel c).  x rows in registers; loop over the G grid points with the two grid-matrix
 // rows as wave-uniform scalars: u = to[g,:].x, s = SiLU(u), y += from[g,:] * s.  Row 0 of the result is SiLU(gate).
@@ -2839,6 +2877,16 @@ int singa_adam_step(float* const* p, const float* const* g, float* const* m, flo
                        chunk_off, chunk, step, lr, beta1, beta2, eps);
     hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step);
     return check_launch("adam_step");
+}
+
+int singa_grad_norm(const float* const* g, const long long* sizes, const int32_t* chunk_tensor, const long long* chunk_off,
+                    int nchunks, int chunk, float* partial, float* out, void* stream) {
+    if (!g || !sizes || !chunk_tensor || !chunk_off || !partial || !out) return fail(SINGA_E_NULL, "grad_norm: null pointer");
+    if (nchunks <= 0) return SINGA_OK;
+    hipLaunchKernelGGL(grad_sumsq_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, g, sizes, chunk_tensor,
+                       chunk_off, chunk, partial);
+    hipLaunchKernelGGL(grad_norm_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nchunks, out);
+    return check_launch("grad_norm");
 }
 
 int singa_alpha_logits_nslots(int E) {

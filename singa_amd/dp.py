@@ -41,6 +41,19 @@ class GradAllReducer:
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
         assert float(hi - lo) == 0.0, "ranks were not initialised with identical parameters"
 
+    def any_rank(self, flag):
+        """True on every rank if `flag` is true on any (host-side decision that all ranks must take together, e.g.
+        re-capturing the step: its warm-up issues collectives).  Exchanged over a gloo group so that no device
+        synchronisation is involved."""
+        if self.world == 1:
+            return bool(flag)
+        if getattr(self, "_cpu_group", None) is None:
+            self._cpu_group = (self.group if dist.get_backend(self.group) == "gloo"
+                               else dist.new_group(backend="gloo"))
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._cpu_group)
+        return bool(int(t))
+
     def set_shard_weight(self, n_local, n_global):
         """Shards of different sizes (batch % world != 0, or `shard_ranges_by_cost`): every rank's CrossEntropy is a mean
         over ITS tokens, so the global-batch gradient is sum_r (tokens_r / tokens) grad_r, not the plain average.  All

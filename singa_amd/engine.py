@@ -96,13 +96,20 @@ class TrainStep:
         return loss
 
     def _update(self):
-        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
-        # clip_grad_norm_(parameters, max_norm) of train.py:126.  The reference passes max_norm = inf, i.e. it only
-        # wants the total norm for logging; torch's implementation still multiplies every gradient by
-        # clamp(inf / (norm + 1e-6), max=1), which turned into NaN under HIP-graph replay on this build, so the
-        # (mathematically void) scaling is skipped when max_norm is infinite and done with a finite coefficient otherwise.
-        self.grad_norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
+        # clip_grad_norm_(parameters, max_norm) of train.py:126.  The norm comes from the library's own chunked
+        # sum-of-squares (singa_grad_norm: fixed summation order, no cross-launch state).  torch's norm goes through its
+        # multi-block reduction kernels, which return garbage for a few outputs under HIP-graph replay on this build (the
+        # same defect that singa_colsum replaces for bias gradients): that garbage, not the gradients, was what made
+        # clamp(inf / (norm + 1e-6), max=1) NaN in replayed steps (tests/test_engine_gpu.py checks the replayed norm
+        # against the eager one).  The reference passes max_norm = inf - the coefficient is then exactly 1, so the
+        # multiplication is skipped; a finite max_norm scales the gradients as torch does.
+        if hasattr(self.opt, "grad_norm"):
+            self.grad_norm = self.opt.grad_norm()
+        else:
+            grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+            self.grad_norm = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
         if self.max_grad_norm != float("inf"):
+            grads = [p.grad for p in self.model.parameters() if p.grad is not None]
             coef = (self.max_grad_norm / (self.grad_norm + 1e-6)).clamp(max=1.0)
             torch._foreach_mul_(grads, coef)
         if hasattr(self.opt, "sync_hyper") and not torch.cuda.is_current_stream_capturing():
@@ -123,18 +130,31 @@ class TrainStep:
             EF_layers._edge_cache.clear()      # a new batch: sort its edges again
             batch.extras.pop("prepared", None)
             self.model.prepare(batch)
+            batch.extras["prepared_by_prefetch"] = True
             batch.extras["prefetched"] = torch.cuda.Event()
             batch.extras["prefetched"].record(self._aux)
         return batch
 
+    @staticmethod
+    def _join_prefetch(batch):
+        """If `prefetch` prepared this batch on the second stream: make the current stream wait for it and tell the
+        allocator that the batch's and the preparation's tensors are used here too.  Called before ANYTHING reads the
+        batch (clones for the static buffers, prepare, warm-up)."""
+        ev = batch.extras.pop("prefetched", None)
+        if ev is None:
+            return False
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        if "prepared" in batch.extras:
+            _record_tree(_prep_tensors(batch.extras["prepared"]), cur)
+        _record_tree([batch.nodes, batch.edges, batch.globals], cur)
+        return True
+
     def _prepared(self, batch):
         """The batch's graph structure: taken from `prefetch` if it ran, else built now."""
-        ev = batch.extras.pop("prefetched", None)
-        if ev is not None and "prepared" in batch.extras:
-            cur = torch.cuda.current_stream()
-            cur.wait_event(ev)
-            _record_tree(_prep_tensors(batch.extras["prepared"]), cur)
-            _record_tree([batch.nodes, batch.edges, batch.globals], cur)
+        self._join_prefetch(batch)
+        if "prepared" in batch.extras and batch.extras.get("prepared_by_prefetch"):
+            batch.extras.pop("prepared_by_prefetch")
             return batch.extras["prepared"]
         EF_layers._edge_cache.clear()          # a new batch: sort its edges again
         batch.extras.pop("prepared", None)
@@ -157,7 +177,7 @@ class TrainStep:
         st.edges = _clone_tree(batch.edges)
         st.globals = _clone_tree(batch.globals)
         st.extras = type(batch.extras)((k, _clone_tree(v)) for k, v in batch.extras.items()
-                                       if k not in ("prepared", "prefetched"))
+                                       if k not in ("prepared", "prefetched", "prepared_by_prefetch"))
         EF_layers._edge_cache.clear()
         prep = self.model.prepare(st)
         n_p, n_l = st[PA]["x"].shape[0], st[LA]["x"].shape[0]
@@ -179,17 +199,23 @@ class TrainStep:
         pairs = []
         ok = (_copy_tree(st.nodes, batch.nodes, pairs) and _copy_tree(st.edges, batch.edges, pairs)
               and _copy_tree(st.globals, batch.globals, pairs))
-        ok = ok and _copy_tree({k: v for k, v in st.extras.items() if k != "prefetched"},
-                               {k: batch.extras[k] for k in st.extras if k != "prefetched"}, pairs)
+        ok = ok and all(k in batch.extras for k in st.extras)
+        ok = ok and _copy_tree(dict(st.extras), {k: batch.extras[k] for k in st.extras}, pairs)
         ok = ok and _copy_tree(_prep_tensors(self.static_prep), _prep_tensors(prep), pairs)
         if ok:
             _flush_copies(pairs)
         return ok
 
     def _capture(self, batch):
+        """Capture the compute part for batches shaped like `batch`.  Side-effect free: the two warm-up steps graph
+        capture needs (allocator, library handles, autograd buffers) run on real data, but parameters, both Adam moments
+        and the step count are put back afterwards, so a (re-)capture never changes the training trajectory - the
+        batch gets exactly one update, from the replay that follows."""
+        self._join_prefetch(batch)
         EF_layers._edge_pinned.clear()
         self._make_static(batch)
         st = self.static
+        snap = self.opt.snapshot() if hasattr(self.opt, "snapshot") else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                      # warm-up on a side stream, as graph capture requires
@@ -199,6 +225,8 @@ class TrainStep:
                 if self.reducer is not None:
                     self.reducer.reduce()
                 self._update()
+            if snap is not None:
+                self.opt.restore(snap)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.opt.zero_grad(set_to_none=True)
@@ -224,12 +252,22 @@ class TrainStep:
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
 
+    def check(self):
+        """The reference's edge-frame guards for frames built inside replayed graphs (one read-back; call it where the
+        loss is read back anyway)."""
+        EF_layers.check_edge_frames()
+
     def step(self, batch):
         if not self.use_graph:
             return self.eager_step(batch)
-        if self.static is None or not self._load(batch):
+        need = self.static is None or not self._load(batch)
+        if self.reducer is not None:
+            # a re-capture runs two warm-up steps with their own all-reduces: every rank has to take that path together
+            need = self.reducer.any_rank(need)
+        if need:
             self._capture(batch)
-            self._load(batch)
+            ok = self._load(batch)
+            assert ok, "the batch does not fit the buffers captured from it"
         self.g_fb.replay()
         if self.reducer is not None:
             self.reducer.reduce()

@@ -488,10 +488,50 @@ class TransBlockV2(nn.Module):
         return out
 
 
+_frame_flags: Dict[str, Tensor] = {}      # device -> [min edge length, max |cos(edge, helper)|] seen under graph capture
+
+
+def _frame_flag_tensor(device) -> Tensor:
+    key = str(device)
+    if key not in _frame_flags:
+        _frame_flags[key] = torch.tensor([float("inf"), 0.0], device=device)
+    return _frame_flags[key]
+
+
+def _judge_frames(dmin: float, dotmax: float) -> None:
+    """The reference's two guards: edges shorter than 1e-4 are only reported (EF:2292-2297, a print there - a warning
+    here); a helper vector still aligned with the edge after both swaps aborts (EF:2329, an assert there - RuntimeError
+    here; `not <` so that the NaN of a zero-length edge fails like it fails the reference's assert)."""
+    import warnings
+    if dmin < 0.0001:
+        warnings.warn("Error edge_vec_0_distance: {}".format(dmin), RuntimeWarning, stacklevel=3)
+    if not dotmax < 0.99:
+        raise RuntimeError(f"init_edge_rot_mat: helper vector aligned with an edge (max |cos| = {dotmax}); "
+                           "zero-length edge or degenerate random draw (reference EF_layers.py:2329)")
+
+
+def check_edge_frames(device=None, reset: bool = True) -> None:
+    """Evaluate the guards for the frames built inside captured HIP graphs (where a host read-back is impossible, the
+    statistics are accumulated on the device instead): one read-back, then the same warning / RuntimeError.  Called by
+    the training loop whenever it reads the loss back (TrainStep.check)."""
+    for key, t in list(_frame_flags.items()):
+        if device is not None and key != str(device):
+            continue
+        dmin, dotmax = t.tolist()
+        if reset:
+            t.copy_(torch.tensor([float("inf"), 0.0]))
+        if dmin != float("inf"):
+            _judge_frames(dmin, dotmax)
+
+
 def init_edge_rot_mat(edge_distance_vec: Tensor, device: str = "cuda", rand: Optional[Tensor] = None) -> Tensor:
     """Edge frames (EF:2286-2351).  `rand` is the uniform [0,1) draw the reference takes from torch.rand_like (Q6);
-    pass it explicitly for reproducible parity, otherwise it is drawn on the tensor's device."""
+    pass it explicitly for reproducible parity, otherwise it is drawn on the tensor's device.  Both guards of the
+    reference are kept (`_judge_frames`): evaluated at once in eager mode, accumulated on the device under graph capture
+    (`check_edge_frames`)."""
     v = edge_distance_vec
+    if v.shape[0] == 0:
+        return v.new_zeros(0, 3, 3)
     d = v.norm(dim=1, keepdim=True)
     nx = v / d
     r = (torch.rand_like(v) if rand is None else rand) - 0.5
@@ -501,6 +541,13 @@ def init_edge_rot_mat(edge_distance_vec: Tensor, device: str = "cuda", rand: Opt
     dot = lambda a: (a * nx).sum(1, keepdim=True).abs()
     r = torch.where(dot(r) > dot(rb), rb, r)
     r = torch.where(dot(r) > dot(rc), rc, r)
+    # max over |cos| with NaN propagated (torch.max propagates NaN: a zero-length edge must trip the guard)
+    stats = torch.stack([d.min(), dot(r).max()])
+    if v.is_cuda and torch.cuda.is_current_stream_capturing():
+        fl = _frame_flag_tensor(v.device)
+        fl.copy_(torch.stack([torch.minimum(fl[0], stats[0]), torch.maximum(fl[1], stats[1])]))
+    else:
+        _judge_frames(*stats.tolist())
     nz = torch.linalg.cross(nx, r, dim=1)
     nz = nz / nz.norm(dim=1, keepdim=True)
     ny = torch.linalg.cross(nx, nz, dim=1)

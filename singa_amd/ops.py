@@ -78,14 +78,11 @@ class EdgeSet:
         self.order = order
         self.src64, self.dst64 = ei[0][order].contiguous(), ei[1][order].contiguous()
         self.src, self.dst = self.src64.to(torch.int32), self.dst64.to(torch.int32)
-        ones = torch.ones_like(self.dst64)
-        self.row_ptr = torch.zeros(self.n_dst + 1, dtype=torch.int64, device=dev)
-        self.row_ptr[1:] = torch.zeros(self.n_dst, dtype=torch.int64, device=dev).index_add_(0, self.dst64, ones).cumsum(0)
-        self.row_ptr = self.row_ptr.to(torch.int32)
-        self.eperm = torch.argsort(self.src64, stable=True).to(torch.int32)
-        self.col_ptr = torch.zeros(self.n_src + 1, dtype=torch.int64, device=dev)
-        self.col_ptr[1:] = torch.zeros(self.n_src, dtype=torch.int64, device=dev).index_add_(0, self.src64, ones).cumsum(0)
-        self.col_ptr = self.col_ptr.to(torch.int32)
+        # CSR / CSC pointers by binary search in the sorted index lists (no atomics)
+        self.row_ptr = torch.searchsorted(self.dst64, torch.arange(self.n_dst + 1, device=dev)).to(torch.int32)
+        eperm = torch.argsort(self.src64, stable=True)
+        self.eperm = eperm.to(torch.int32)
+        self.col_ptr = torch.searchsorted(self.src64[eperm], torch.arange(self.n_src + 1, device=dev)).to(torch.int32)
 
     def tensors(self):
         return [self.order, self.src64, self.dst64, self.src, self.dst, self.row_ptr, self.eperm, self.col_ptr]

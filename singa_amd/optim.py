@@ -77,25 +77,97 @@ class Adam(torch.optim.Optimizer):
                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         _capi.check(_lib.lib(), code, "singa_adam_step")
 
+    def grad_norm(self):
+        """Total 2-norm of the gradients the step will consume (torch.nn.utils.clip_grad_norm_'s return value,
+        train.py:126) as a device scalar: one chunked sum-of-squares launch + a fixed-order finish, HIP-graph replayable
+        and identical eager / replayed."""
+        if not self._built:
+            self._build()
+        g_ptr = self._grad_table()
+        if getattr(self, "_norm_partial", None) is None:
+            self._norm_partial = torch.empty(self.chunk_tensor.numel(), device=self.p_ptr.device, dtype=torch.float32)
+            self._norm_out = torch.zeros(1, device=self.p_ptr.device, dtype=torch.float32)
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())
+        code = _lib.lib().singa_grad_norm(vp(g_ptr), vp(self.sizes), vp(self.chunk_tensor), vp(self.chunk_off),
+                                          self.chunk_tensor.numel(), CHUNK, vp(self._norm_partial), vp(self._norm_out),
+                                          ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        _capi.check(_lib.lib(), code, "singa_grad_norm")
+        return self._norm_out[0]
+
+    # ------------------------------------------------------------------------------------------------ snapshots
+    def snapshot(self):
+        """Copies of everything a step changes (parameters, both moments, the step count), for TrainStep's warm-up."""
+        snap = {"params": [p.detach().clone() for p in self.params], "built": self._built}
+        if self._built:
+            snap.update(step=self.step_t.clone(), exp_avg=[t.clone() for t in self.exp_avg],
+                        exp_avg_sq=[t.clone() for t in self.exp_avg_sq])
+        return snap
+
+    @torch.no_grad()
+    def restore(self, snap):
+        for p, q in zip(self.params, snap["params"]):
+            p.copy_(q)
+        if not self._built:
+            return
+        if snap["built"]:
+            self.step_t.copy_(snap["step"])
+            torch._foreach_copy_(self.exp_avg, snap["exp_avg"])
+            torch._foreach_copy_(self.exp_avg_sq, snap["exp_avg_sq"])
+        else:                       # the optimizer was built by the warm-up itself: back to its initial state
+            self.step_t.zero_()
+            torch._foreach_zero_(self.exp_avg)
+            torch._foreach_zero_(self.exp_avg_sq)
+
     # ------------------------------------------------------------------------------------------------ checkpoints
     def state_dict(self):
-        if not self._built:
-            return {"built": False, "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
-        idx = {id(p): i for i, p in enumerate(self.params)}
-        return {"built": True, "step": float(self.step_t), "active": [idx[id(p)] for p in self.active],
-                "exp_avg": [t.clone() for t in self.exp_avg], "exp_avg_sq": [t.clone() for t in self.exp_avg_sq],
-                "param_groups": [{k: v for k, v in self.param_groups[0].items() if k != "params"}]}
+        """torch.optim.Adam's own layout (what the reference's checkpoints hold, train.py:244-252 / gen.py:106-110):
+        {'state': {param index: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [{..., 'params': [0..n-1]}]}; only
+        parameters that have taken a step have a state entry (torch skips `grad is None` the same way)."""
+        g = self.param_groups[0]
+        group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": 0, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(self.params)))}
+        state = {}
+        if self._built:
+            idx = {id(p): i for i, p in enumerate(self.params)}
+            step = self.step_t.detach().cpu().reshape(()).clone()
+            if float(step) > 0:
+                for p, m, v in zip(self.active, self.exp_avg, self.exp_avg_sq):
+                    state[idx[id(p)]] = {"step": step.clone(), "exp_avg": m.clone(), "exp_avg_sq": v.clone()}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.param_groups[0].update(sd["param_groups"][0])
-        if not sd.get("built"):
+        if not (isinstance(sd, dict) and "param_groups" in sd and "state" in sd and len(sd["param_groups"]) == 1):
+            raise ValueError("Adam.load_state_dict: expected torch.optim.Adam's state_dict layout "
+                             "{'state': {...}, 'param_groups': [one group]}")
+        g = sd["param_groups"][0]
+        if len(g.get("params", [])) != len(self.params):
+            raise ValueError(f"Adam.load_state_dict: the checkpoint's group has {len(g.get('params', []))} parameters, "
+                             f"this optimizer has {len(self.params)}")
+        if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
+            raise ValueError("Adam.load_state_dict: weight_decay / amsgrad / maximize are not supported (the reference uses none)")
+        for k in ("lr", "betas", "eps"):                       # hyper-parameters only; never the 'params' index list
+            if k in g:
+                self.param_groups[0][k] = tuple(g[k]) if k == "betas" else g[k]
+        state = {int(i): st for i, st in sd["state"].items()}
+        if not state:
+            self._built = False
             return
-        for i in sd["active"]:
+        steps = {float(st["step"]) for st in state.values()}
+        if len(steps) != 1:
+            raise ValueError("Adam.load_state_dict: parameters with different step counts are not supported")
+        for i in state:                                        # these parameters take part from now on
             if self.params[i].grad is None:
                 self.params[i].grad = torch.zeros_like(self.params[i])
+        for i, p in enumerate(self.params):
+            if i not in state and p.grad is not None:
+                p.grad = None
         self._build()
-        self.step_t.fill_(sd["step"])
-        for a, b in zip(self.exp_avg, sd["exp_avg"]):
-            a.copy_(b)
-        for a, b in zip(self.exp_avg_sq, sd["exp_avg_sq"]):
-            a.copy_(b)
+        self.step_t.fill_(steps.pop())
+        idx = {id(p): i for i, p in enumerate(self.params)}
+        with torch.no_grad():
+            for p, m, v in zip(self.active, self.exp_avg, self.exp_avg_sq):
+                st = state[idx[id(p)]]
+                m.copy_(st["exp_avg"])
+                v.copy_(st["exp_avg_sq"])
+        self.sync_hyper()

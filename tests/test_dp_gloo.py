@@ -72,6 +72,126 @@ def test_two_rank_gradient_average(tmp_path):
             assert torch.allclose(got["grads"][n], p.grad, atol=1e-6), n
 
 
+def _worker_unequal(rank, world, port, out):
+    """Unequal shards (7 + 3 rows): token-weighted combination = the global-batch mean gradient; and the collective
+    host-side decision helper."""
+    sys.path.insert(0, ROOT)
+    from singa_amd import dp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(7)
+    model = Toy()
+    red = dp.GradAllReducer(model)
+    data = torch.randn(10, 8, generator=torch.Generator().manual_seed(1))
+    tgt = torch.randn(10, 3, generator=torch.Generator().manual_seed(2))
+    lo, hi = (0, 7) if rank == 0 else (7, 10)
+    red.set_shard_weight(hi - lo, 10)
+    loss = ((model(data[lo:hi]) - tgt[lo:hi]) ** 2).mean()
+    loss.backward()
+    red.reduce()
+    flags = [red.any_rank(rank == 1), red.any_rank(False), red.any_rank(True)]
+    if rank == 0:
+        torch.save({"grads": {n: p.grad for n, p in model.named_parameters()}, "flags": flags}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unequal_shards_are_token_weighted(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker_unequal, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    torch.manual_seed(7)
+    model = Toy()
+    data = torch.randn(10, 8, generator=torch.Generator().manual_seed(1))
+    tgt = torch.randn(10, 3, generator=torch.Generator().manual_seed(2))
+    ((model(data) - tgt) ** 2).mean().backward()            # the global-batch mean loss
+    for n, p in model.named_parameters():
+        if "unused" not in n:
+            assert torch.allclose(got["grads"][n], p.grad, atol=1e-6), n
+    assert got["flags"] == [True, False, True]
+
+
+def singa_grad_free_names(model):
+    """the 90 parameter tensors of SINGA that never receive a gradient."""
+    out = set()
+    for n, _ in model.named_parameters():
+        parts = n.split(".")
+        if n.startswith("embedding.sphere_embedding"):
+            out.add(n)
+        elif parts[:2] in (["model", "encoder"], ["model", "encoder2"]) and parts[2] in ("out", "layer_norm"):
+            out.add(n)
+        elif "pos_ffn.batch_norm" in n:
+            out.add(n)
+        elif parts[:3] == ["model", "encoder2", "layers"] and parts[3] not in ("2", "5") and parts[4] in (
+                "proj", "cross_attn", "layer_norm"):
+            out.add(n)
+    return out
+
+
+def _worker_singa(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    from singa_amd import dp
+    from singa_amd.config import load_config
+    from singa_amd.model.GAN import SINGA
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(2022)
+    model = SINGA(load_config(lmax=6), device="cpu")         # parameter container: the forward is not run here
+    red = dp.GradAllReducer(model)
+    red.check_same_init()
+    free = singa_grad_free_names(model)
+    gen = torch.Generator().manual_seed(100 + rank)
+    for n, p in model.named_parameters():
+        p.grad = None if n in free else torch.randn(p.shape, generator=gen)
+    mine = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    red.reduce()
+    if rank == 0:
+        order = [id(p) for b in red.buckets for p in b]
+        names = {id(p): n for n, p in model.named_parameters()}
+        torch.save({"n_tensors": len(order), "payload": red.payload_bytes, "nb": len(red.buckets),
+                    "first": names[order[0]], "last": names[order[-1]], "bucket_order": [names[i] for i in order],
+                    "sample": {n: (model.get_parameter(n).grad.clone(), mine[n]) for n in
+                               ("model.projection.weight", "embedding.blocks.0.ga.alpha_dot")}}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_singa_parameter_set_buckets(tmp_path):
+    """The real SINGA parameter list at L = 6 through the reducer: 634 gradient tensors = 25,164,960 floats =
+    100.66 MB per step, the 90 gradient-free tensors excluded statically, buckets in reverse
+    execution order (vocabulary projection / decoder first, equivariant blocks last), averaged values exact."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker_singa, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["n_tensors"] == 634 and got["payload"] == 25_164_960 * 4
+    assert got["nb"] >= 3
+    assert got["first"] == "model.projection.weight" and got["last"].startswith("embedding.")
+    sys.path.insert(0, ROOT)
+    from singa_amd.config import load_config
+    from singa_amd.model.GAN import SINGA
+    model = SINGA(load_config(lmax=6), device="cpu")
+    decl = [n for n, _ in model.named_parameters()]
+    assert len(decl) == 724 and len(singa_grad_free_names(model)) == 90
+    assert got["bucket_order"] == [n for n in reversed(decl) if n not in singa_grad_free_names(model)]
+    # rank 1's gradients are reproducible here: the reduced value is the mean of the two ranks'
+    gen = torch.Generator().manual_seed(101)
+    other = {}
+    free = singa_grad_free_names(model)
+    for n, p in model.named_parameters():
+        if n not in free:
+            other[n] = torch.randn(p.shape, generator=gen)
+    for n, (red, mine) in got["sample"].items():
+        assert torch.allclose(red, 0.5 * (mine + other[n]), atol=1e-6), n
+
+
 def test_shard_range_covers_everything():
     from singa_amd import dp
     for n in (1, 7, 32, 129):

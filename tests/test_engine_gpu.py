@@ -23,20 +23,93 @@ def _run(use_graph, steps=3, torch_adam=False):
     eng = TrainStep(model, opt, None, use_graph=use_graph)
     z = golden(f"singa_L{L}_B3.npz")
     batch = product_batch(NAMES, z)
-    losses = []
-    for _ in range(steps + (2 if use_graph else 0)):        # graph capture spends 2 real warm-up steps first
+    losses, norms = [], []
+    for _ in range(steps):
         losses.append(float(eng.step(batch).detach()))
+        norms.append(float(eng.grad_norm))
+    eng.norms = norms
     return losses, eng
 
 
 def test_graph_replay_matches_eager():
-    eager, _ = _run(False, steps=5)
-    graph, eng = _run(True, steps=3)
+    """Step i of the replayed engine = step i of the eager engine, from the very first step: the capture's warm-up
+    steps leave parameters, Adam moments and the step count untouched (one update per batch)."""
+    eager, e_eng = _run(False, steps=5)
+    graph, eng = _run(True, steps=5)
     assert eng.captures == 1
-    # the graph engine's first call performs 2 un-recorded warm-up steps, so its i-th loss is eager's (i+2)-th
-    for a, b in zip(graph[:3], eager[2:5]):
+    for a, b in zip(graph, eager):
         assert abs(a - b) < 2e-4 * abs(b), (graph, eager)
     assert eager[4] < eager[0]                              # and the step does train
+    assert float(eng.opt.step_t) == 5.0 and float(e_eng.opt.step_t) == 5.0
+    # the total gradient norm (clip_grad_norm_'s return value, train.py:126) is finite and the same replayed and eager;
+    # first step: the golden's own total norm
+    z = golden("singa_L2_B3.npz")
+    assert abs(eng.norms[0] - float(z["grad_total"])) < 1e-3 * float(z["grad_total"]), eng.norms
+    for a, b in zip(eng.norms, e_eng.norms):
+        assert a == a and abs(a - b) < 2e-3 * abs(b), (eng.norms, e_eng.norms)
+
+
+def test_recapture_does_not_change_the_trajectory():
+    """A batch with other shapes triggers a re-capture; the loss sequence still equals the eager engine's."""
+    from singa_amd import graph as G
+    from singa_amd.config import load_config
+    from singa_amd.engine import TrainStep
+    from singa_amd.model.GAN import SINGA
+    from singa_amd.optim import Adam
+    bs = [G.synthetic_batch(2, first_id=50 + 2 * i, n_protein=40 + 6 * i, n_ligand=12, e_pp=200 + 20 * i, e_ll=24, e_x=30).to("cuda")
+          for i in range(3)]
+
+    def run(use_graph):
+        torch.manual_seed(3)
+        model = SINGA(load_config(lmax=2), device="cuda").eval()
+        eng = TrainStep(model, Adam(model.parameters(), lr=1e-4), None, use_graph=use_graph)
+        return [float(eng.step(bs[i % 3]).detach()) for i in range(6)], eng
+
+    eager, _ = run(False)
+    graph, eng = run(True)
+    assert eng.captures == 6                                # every step saw a new shape
+    assert all(abs(a - b) < 2e-4 * abs(b) for a, b in zip(graph, eager)), (graph, eager)
+
+
+def test_adam_state_dict_is_torch_adam_layout():
+    """Checkpoints interoperate with torch.optim.Adam in both directions (reference train.py:244-252, gen.py:106-110)."""
+    from singa_amd.optim import Adam
+    torch.manual_seed(0)
+    ws = [torch.nn.Parameter(torch.randn(33, 7, device="cuda")), torch.nn.Parameter(torch.randn(5000, device="cuda")),
+          torch.nn.Parameter(torch.randn(4, device="cuda"))]                    # the last one never gets a gradient
+    wt = [torch.nn.Parameter(w.detach().clone()) for w in ws]
+    ours, ref = Adam(ws, lr=1e-3, betas=(0.99, 0.999)), torch.optim.Adam(wt, lr=1e-3, betas=(0.99, 0.999))
+    for k in range(3):
+        for a, b in zip(ws[:2], wt[:2]):
+            g = torch.randn_like(a)
+            a.grad, b.grad = g.clone(), g.clone()
+        ours.step()
+        ref.step()
+    sd, sr = ours.state_dict(), ref.state_dict()
+    assert set(sd) == set(sr) and set(sd["state"]) == set(sr["state"]) == {0, 1}
+    assert sd["param_groups"][0]["params"] == sr["param_groups"][0]["params"] == [0, 1, 2]
+    assert set(sr["param_groups"][0]) <= set(sd["param_groups"][0]) | {"decoupled_weight_decay"}
+    for i in (0, 1):
+        assert float(sd["state"][i]["step"]) == float(sr["state"][i]["step"]) == 3.0
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.allclose(sd["state"][i][k], sr["state"][i][k], rtol=1e-5, atol=1e-8)
+        assert torch.allclose(ws[i], wt[i], rtol=1e-5, atol=1e-7)
+    # torch -> ours and ours -> torch, then one more step on each side
+    ws2 = [torch.nn.Parameter(w.detach().clone()) for w in wt]
+    ours2 = Adam(ws2, lr=5e-4)
+    ours2.load_state_dict(sr)
+    assert ours2.param_groups[0]["lr"] == 1e-3 and ours2.param_groups[0]["params"][0] is ws2[0]
+    ref2 = torch.optim.Adam([torch.nn.Parameter(w.detach().clone()) for w in ws], lr=5e-4)
+    ref2.load_state_dict(sd)
+    for a, b in zip(ws2[:2], ref2.param_groups[0]["params"][:2]):
+        g = torch.randn_like(a)
+        a.grad, b.grad = g.clone(), g.clone()
+    ours2.step()
+    ref2.step()
+    for a, b in zip(ws2[:2], ref2.param_groups[0]["params"][:2]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    with pytest.raises(ValueError):
+        ours2.load_state_dict({"built": True, "param_groups": [{}]})
 
 
 def test_graph_replay_gradients_match_eager_per_parameter():

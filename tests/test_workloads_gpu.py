@@ -1,0 +1,86 @@
+"""-m gpu: BASELINE.json's configurations as parity cases.  Two-graph batches drawn from the SAME generators bench.py
+uses (singa_amd.graph.WORKLOADS: config 2 = L 2, config 3 = ragged CrossDocked-shaped graphs at L 4, config 5 = 840
+atoms / 8 k edges per graph at L 6) go through the product (HIP kernels, one full training step's forward + CrossEntropy
++ backward) and through the CPU oracle (pinned to the reference by tests/golden): logits within 1e-4 relative
+(north_star), and the gradient of EVERY parameter element-wise.  Plus the basis-free check of the on-GPU Laplacian
+positional encoding (reference model/CProMG.py:562-571)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import singa_oracle as O
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("workload", ["cfg2_b32_l2", "cfg3_b128_l4", "cfg5_l6"])
+def test_workload_step_matches_oracle(workload):
+    from singa_amd import graph as G
+    from singa_amd.config import load_config
+    from singa_amd.model.GAN import SINGA
+    wl = dict(G.WORKLOADS[workload])
+    L = wl["lmax"]
+    kw = {k: v for k, v in wl.items() if k not in ("n_graphs", "lmax")}
+    ids = [3, 4]
+    graphs = [G.synthetic_graph(i, **G.graph_sizes(i, **kw)) for i in ids]
+    cfg = load_config(lmax=L)
+    torch.manual_seed(7)
+    model = SINGA(cfg, device=DEV)
+    model.eval()                                   # dropout off on both sides (Q9)
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    # oracle (CPU): its own kNN graphs, frames from the same draws, the same Laplacian encodings
+    b, rots, lap_p, lap_l = O.batch_from_graphs(graphs)
+    loss_o = O.train_step_loss(sd, b, rots, L, lap_p, lap_l)
+    loss_o.backward()
+    # product (GPU)
+    batch = G.collate(graphs).to(DEV)
+    logits = model(batch)
+    loss = torch.nn.functional.cross_entropy(logits, batch["ligand_data"]["smiIndices_tgt"].reshape(-1))
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(loss_o)) < 1e-4 * abs(float(loss_o)), (float(loss), float(loss_o))
+    with torch.no_grad():
+        bp = torch.repeat_interleave(torch.arange(2), b["ptr_p"][1:] - b["ptr_p"][:-1])
+        bl = torch.repeat_interleave(torch.arange(2), b["ptr_l"][1:] - b["ptr_l"][:-1])
+        ref = O.singa_forward(sd, b, rots, L, O.knn_graph(b["pos_p"], 48, bp), O.knn_graph(b["pos_l"], 30, bl), lap_p, lap_l)
+    assert rel_err(logits.detach().cpu(), ref) < 1e-4
+    total = float(torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sd.values() if v.grad is not None)))
+    bad, n_checked = [], 0
+    for name, p in model.named_parameters():
+        go = sd[name].grad
+        if go is None or float(go.norm()) == 0.0:
+            assert p.grad is None or float(p.grad.norm()) == 0.0, name       # Q1 / Q10: no gradient on either side
+            continue
+        assert p.grad is not None, name
+        n_checked += 1
+        diff = (p.grad.detach().cpu().double() - go.double())
+        err = float(diff.norm() / go.double().norm())
+        if err > 2e-3 and float(diff.norm()) > 1e-6 * total:
+            bad.append((name, err, float(go.norm())))
+    assert n_checked == 634, n_checked                    # 634 of the 724 tensors carry gradients
+    assert not bad, bad[:8]
+
+
+def test_laplacian_pe_batched_on_gpu_against_oracle_spectrum():
+    """graph.laplacian_pe_batched (batched symmetric eigensolve on the GPU, what SINGA.prepare uses when a batch carries
+    no encoding) per graph: orthonormal columns, an invariant subspace of the oracle's Laplacian, Ritz values =
+    eigenvalues 1..8, fixed sign convention.  Ragged batch (config-3 generator) so that the padding path is exercised."""
+    from singa_amd import graph as G
+    kw = {k: v for k, v in G.WORKLOADS["cfg3_b128_l4"].items() if k not in ("n_graphs", "lmax")}
+    graphs = [G.synthetic_graph(i, **G.graph_sizes(i, **kw)) for i in (11, 12, 13)]
+    b = G.collate(graphs).to(DEV)
+    for nt, et in ((G.PA, G.E_PP), (G.LA, G.E_LL)):
+        pe = G.laplacian_pe_batched(b[et]["edge_index"], b[nt]["batch"], 3).cpu().double().numpy()
+        ptr = b[nt]["ptr"].cpu().numpy()
+        for i, g in enumerate(graphs):
+            v = pe[ptr[i]:ptr[i + 1]]
+            n = v.shape[0]
+            lap, w = O.laplacian_spectrum(g[et]["edge_index"].numpy(), n)
+            assert np.abs(v.T @ v - np.eye(8)).max() < 1e-5
+            ritz = v.T @ lap @ v
+            assert np.abs(lap @ v - v @ ritz).max() < 1e-5
+            assert np.abs(np.linalg.eigvalsh(ritz) - w[1:9]).max() < 1e-5
+            top = v[np.abs(v).argmax(0), np.arange(8)]
+            assert (top > 0).all()
