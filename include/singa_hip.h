@@ -257,6 +257,33 @@ int singa_adam_step(float* const* p, const float* const* g, float* const* m, flo
                     const int32_t* chunk_tensor, const long long* chunk_off, int nchunks, int chunk, float* step,
                     const float* lr, float beta1, float beta2, float eps, void* stream);
 
+/* k7 / k11 - f32 GEMM on the matrix cores (v_mfma_f32_32x32x2_f32: exact f32) for the per-edge contractions of the SO(2)
+ * convolutions (reference model/EF_layers.py:715-729, 782, 807-875: fc_m0 and the so2_m_conv[m].fc Linears applied to
+ * m-primary edge rows) and the per-degree SO3_LinearV2 (EF:655-671).  Up to SINGA_GEMM_MAX independent problems per
+ * launch:  c[i, j] = sum_r A(i, r) * B(r, j) (+ bias[j]).
+ *   a_r_contig != 0: A is stored [I rows][R] with row pitch lda; else A is stored [R rows][I].
+ *   b_r_contig != 0: B is stored [J][R] (an nn.Linear weight [out, in]); else [R rows][J].
+ *   Rows of A, of an [R][J] B and of C may be grouped: row i lives at (i / group) * group_ld + (i % group) * ld (the
+ *   2l+1 coefficient rows of degree l inside [N, K, C] node tensors); group = 0: plain rows.
+ *   Built combinations: (1,1) y = x W^T; (1,0) dx = dy W; (0,0) dW = dy^T x.
+ *   splits > 1: the reduction range is cut into `splits` chunks; chunk s writes a dense [I, J] slab (ldc = J, no bias, no
+ *   grouping) at c + s * c_split_stride, which the caller adds up (singa_colsum).
+ *   All problems of a launch use 128 x 128 output tiles, or 256 x 32 when every J <= 32.
+ * Contiguous axes must be multiples of 4 floats and 16-byte aligned.  Enqueue-only on `stream`. */
+#define SINGA_GEMM_MAX 8
+typedef struct {
+    const float* a;
+    const float* b;
+    float* c;
+    const float* bias;        /* [J] or NULL */
+    int64_t lda, ldb, ldc;
+    int32_t I, J, R;
+    int32_t a_group, b_group, c_group;           /* rows per group (0 = plain rows) */
+    int64_t a_group_ld, b_group_ld, c_group_ld;
+    int64_t c_split_stride;                       /* floats between the partial slabs of consecutive splits */
+} singa_gemm_t;
+int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_contig, int splits, void* stream);
+
 /* Total 2-norm of all gradients over the same (tensor, chunk) table as singa_adam_step: torch.nn.utils.clip_grad_norm_'s
  * norm (reference train.py:126), deterministic and HIP-graph replayable.  partial: nchunks floats of scratch; out: 1 float. */
 int singa_grad_norm(const float* const* g, const long long* sizes, const int32_t* chunk_tensor, const long long* chunk_off,
@@ -275,6 +302,9 @@ int singa_prof_collect(float* ms, int* edges, int* nodes, int cap); /* after syn
 #define SINGA_PROF_K4_BWD_RAD 4  /* gather_rotate backward w.r.t. the radial weights (edge-parallel) */
 #define SINGA_PROF_K4_BWD_DST 5  /* ... w.r.t. the destination node rows */
 #define SINGA_PROF_K4_BWD_SRC 6  /* ... w.r.t. the source node rows */
+#define SINGA_PROF_GEMM_NT 7     /* singa_gemm_f32 (1,1): nodes field = number of 128 x 128 tiles */
+#define SINGA_PROF_GEMM_NN 8
+#define SINGA_PROF_GEMM_TN 9
 int singa_prof_collect_tagged(float* ms, int* tags, int* edges, int* nodes, int cap);
 int singa_calib_copy(const float* src, float* dst, long long n, void* stream);
 

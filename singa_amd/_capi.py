@@ -14,6 +14,22 @@ class Seg(C.Structure):
 
 SegArr = Seg * 3
 
+
+class Gemm(C.Structure):
+    """singa_gemm_t of include/singa_hip.h"""
+    _fields_ = [("a", P), ("b", P), ("c", P), ("bias", P), ("lda", I64), ("ldb", I64), ("ldc", I64), ("I", C.c_int32),
+                ("J", C.c_int32), ("R", C.c_int32), ("a_group", C.c_int32), ("b_group", C.c_int32), ("c_group", C.c_int32),
+                ("a_group_ld", I64), ("b_group_ld", I64), ("c_group_ld", I64), ("c_split_stride", I64)]
+
+
+def gemm_probs(items):
+    """items: list of dicts with the fields of singa_gemm_t (pointers as ints, missing fields 0) -> (ctypes array, n)"""
+    arr = (Gemm * len(items))()
+    for g, it in zip(arr, items):
+        for k, v in it.items():
+            setattr(g, k, v)
+    return arr, len(items)
+
 _SIGS = {
     "singa_version": ([], I32),
     "singa_last_error_string": ([], C.c_char_p),
@@ -65,6 +81,7 @@ _SIGS = {
     "singa_colsum": ([P, C.c_longlong, C.c_longlong, I32, P, P, P], I32),
     "singa_adam_step": ([P, P, P, P, P, P, P, I32, I32, P, P, F32, F32, F32, P], I32),
     "singa_grad_norm": ([P, P, P, P, I32, I32, P, P, P], I32),
+    "singa_gemm_f32": ([C.POINTER(Gemm), I32, I32, I32, I32, P], I32),
     "singa_prof_enable": ([I32], I32),
     "singa_prof_hint_edges": ([I32], I32),
     "singa_prof_collect": ([P, P, P, I32], I32),

@@ -2409,6 +2409,189 @@ __global__ void __launch_bounds__(64) rmsnorm_bwd_kernel(const float* __restrict
     if (lane < C) gb_part[(long long)blockIdx.x * C + lane] = gbp;
 }
 
+
+// ------------------------------------------------------------------------------------------------ k7 / k11: f32 MFMA GEMM
+// C[i, j] (+= bias[j]) = sum_r Aop[i, r] * Bop[r, j] on v_mfma_f32_32x32x2_f32 (exact f32: a k-ordered fmaf chain), for up to
+// SINGA_GEMM_MAX independent problems per launch (the m = 0, 1, 2 blocks of an SO(2) convolution, EF:807-875; the
+// degrees l of an SO3_LinearV2, EF:655-671).  Each operand is stored either "reduction-contiguous" ([i][r], e.g. an
+// activation matrix X[E, K] or an nn.Linear weight W[out, in]) or "output-contiguous" ([r][i]):
+//     forward   Y = X W^T     A = X  (RC)   B = W   (RC)
+//     d input   dX = dY W     A = dY (RC)   B = W   (output-contiguous)
+//     d weight  dW = dY^T X   A = dY (OC)   B = X   (OC), reduction over the edges, split over workgroups (partials)
+// Workgroup = 256 threads = 2 x 2 wavefronts, macro tile 128 x 128, wavefront tile 64 x 64 = 2 x 2 MFMA tiles (64
+// accumulator registers); K step 32 staged through LDS in [r][i] order for both operands, so that the fragment of k-pair
+// (r, r+1) is one ds_read_b32 per 32-row block (lane l reads [r + l/32][i0 + l%32]: conflict-free).  Reduction-contiguous
+// operands are transposed on the LDS write (row pitch 129 floats: the 32 lanes of a write group hit 32 banks);
+// output-contiguous ones are copied as float4 (pitch 132).  Global loads of step t+1 are issued before the 64 MFMAs of
+// step t and written to the other LDS buffer after them: one barrier per step.  Tiles are numbered so that the
+// workgroups of one XCD (blockIdx % 8) walk consecutive column tiles of the same row tile: its A rows stay in that L2.
+// Rows of A and C may be grouped (row i -> (i / group) * ld_group + (i % group) * ld): the (2l+1) coefficient rows of a
+// degree inside [N, K, C] node tensors.
+struct GemmProb {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    long long lda, ldb, ldc, a_gld, b_gld, c_gld, c_split;
+    int I, J, R, a_group, b_group, c_group, tiles_j, tile_begin;
+};
+struct GemmBatch {
+    GemmProb p[SINGA_GEMM_MAX];
+    int n, tiles_total, splits;
+    long long r_chunk;
+};
+
+// NT = 2: macro tile 128 x 128 (2 x 2 wavefronts of 64 x 64); NT = 1: 256 x 32 (4 x 1 wavefronts of 64 x 32) for outputs with
+// few columns (the 16-channel results of SO3_LinearV2).
+template <bool A_RC, bool B_RC, int NT>
+__global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
+    constexpr int BM = NT == 2 ? 128 : 256, BN = NT == 2 ? 128 : 32, BK = 32;
+    constexpr int NA = BM / 32, NB = BN / 32;                      // float4 loads per thread and K step
+    constexpr int LDA = A_RC ? BM + 1 : BM + 4, LDB = B_RC ? BN + 1 : BN + 4;
+    __shared__ float As[2][BK * LDA];
+    __shared__ float Bs[2][BK * LDB];
+    // XCD-aware numbering: block b runs on XCD b % 8; give every XCD a contiguous range of tile ids
+    const int nblk = gb.tiles_total * gb.splits;
+    const int per = (nblk + 7) >> 3;
+    const int id = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (id >= nblk) return;
+    const int split = id / gb.tiles_total;
+    const int tile = id - split * gb.tiles_total;
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < SINGA_GEMM_MAX; ++q)
+        if (q < gb.n && tile >= gb.p[q].tile_begin) pi = q;
+    const GemmProb& P = gb.p[pi];
+    const int local = tile - P.tile_begin;
+    const int i0 = (local / P.tiles_j) * BM, j0 = (local % P.tiles_j) * BN;
+    const long long r_begin = (long long)split * gb.r_chunk;
+    const long long r_end = (r_begin + gb.r_chunk < P.R) ? r_begin + gb.r_chunk : P.R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = NT == 2 ? wave >> 1 : wave, wn = NT == 2 ? wave & 1 : 0, l31 = lane & 31, half = lane >> 5;
+
+    float4 ra[NA], rb[NB];
+    // ---- global -> registers for the K step starting at r0.  Reduction-contiguous operand ([i][r]): 8 lanes cover 128
+    // contiguous bytes of one row; output-contiguous ([r][i]): consecutive lanes cover consecutive float4 of one r row.
+    auto load_rc = [&](float4* reg, const float* base, long long ld, int grp, long long gld, int o0, int lim, int n, long long r0) {
+        const int kq = tid & 7, rr = tid >> 3;
+        const long long r = r0 + 4 * kq;
+        for (int j = 0; j < n; ++j) {
+            const int i = o0 + rr + 32 * j;
+            reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < lim && r < r_end) {
+                const long long row = (long long)(i / grp) * gld + (long long)(i % grp) * ld;
+                reg[j] = *reinterpret_cast<const float4*>(base + row + r);
+            }
+        }
+    };
+    auto load_oc = [&](float4* reg, const float* base, long long ld, int grp, long long gld, int o0, int lim, int n, int width4,
+                       long long r0) {
+        const int c4 = tid % width4, rr = tid / width4, rows = 256 / width4;
+        const int i = o0 + 4 * c4;
+        for (int j = 0; j < n; ++j) {
+            const long long r = r0 + rr + rows * j;
+            reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < r_end && i < lim) {
+                const long long row = (r / grp) * gld + (r % grp) * ld;
+                reg[j] = *reinterpret_cast<const float4*>(base + row + i);
+            }
+        }
+    };
+    // ---- registers -> LDS image [r][i]
+    auto store_rc = [&](float* S, const float4* reg, int pitch, int n) {
+        const int kq = tid & 7, rr = tid >> 3;
+        for (int j = 0; j < n; ++j) {
+            S[(4 * kq + 0) * pitch + rr + 32 * j] = reg[j].x;
+            S[(4 * kq + 1) * pitch + rr + 32 * j] = reg[j].y;
+            S[(4 * kq + 2) * pitch + rr + 32 * j] = reg[j].z;
+            S[(4 * kq + 3) * pitch + rr + 32 * j] = reg[j].w;
+        }
+    };
+    auto store_oc = [&](float* S, const float4* reg, int pitch, int n, int width4) {
+        const int c4 = tid % width4, rr = tid / width4, rows = 256 / width4;
+        for (int j = 0; j < n; ++j) *reinterpret_cast<float4*>(S + (rr + rows * j) * pitch + 4 * c4) = reg[j];
+    };
+    auto load_a = [&](long long r0) {
+        if (A_RC) load_rc(ra, P.A, P.lda, P.a_group, P.a_gld, i0, P.I, NA, r0);
+        else load_oc(ra, P.A, P.lda, P.a_group, P.a_gld, i0, P.I, NA, BM / 4, r0);
+    };
+    auto load_b = [&](long long r0) {
+        if (B_RC) load_rc(rb, P.B, P.ldb, 1 << 30, 0, j0, P.J, NB, r0);
+        else load_oc(rb, P.B, P.ldb, P.b_group, P.b_gld, j0, P.J, NB, BN / 4, r0);
+    };
+    auto store_a = [&](int buf) {
+        if (A_RC) store_rc(As[buf], ra, LDA, NA);
+        else store_oc(As[buf], ra, LDA, NA, BM / 4);
+    };
+    auto store_b = [&](int buf) {
+        if (B_RC) store_rc(Bs[buf], rb, LDB, NB);
+        else store_oc(Bs[buf], rb, LDB, NB, BN / 4);
+    };
+
+    floatx16 acc[2][NT];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const long long nsteps = r_end > r_begin ? (r_end - r_begin + BK - 1) / BK : 0;
+    if (nsteps > 0) {
+        load_a(r_begin);
+        load_b(r_begin);
+        store_a(0);
+        store_b(0);
+    }
+    __syncthreads();
+    for (long long t = 0; t < nsteps; ++t) {
+        const int buf = (int)(t & 1);
+        const bool more = t + 1 < nsteps;
+        if (more) {
+            load_a(r_begin + (t + 1) * BK);
+            load_b(r_begin + (t + 1) * BK);
+        }
+        const float* Sa = As[buf] + wm * 64 + l31;
+        const float* Sb = Bs[buf] + wn * 64 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = Sa[(kk + half) * LDA], a1 = Sa[(kk + half) * LDA + 32];
+            const float b0 = Sb[(kk + half) * LDB];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            if (NT == 2) {
+                const float b1 = Sb[(kk + half) * LDB + 32];
+                acc[0][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][NT - 1], 0, 0, 0);
+                acc[1][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][NT - 1], 0, 0, 0);
+            }
+        }
+        if (more) {
+            store_a(buf ^ 1);
+            store_b(buf ^ 1);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: accumulator register q of a 32 x 32 tile holds row (q & 3) + 8 (q >> 2) + 4 half, column lane & 31
+    float* Cb = P.C + (long long)split * P.c_split;
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int j = j0 + wn * 64 + 32 * b + l31;
+        if (j >= P.J) continue;
+        const float bj = P.bias ? P.bias[j] : 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int i = i0 + wm * 64 + 32 * a + (q & 3) + 8 * (q >> 2) + 4 * half;
+                if (i < P.I) {
+                    const long long row = (long long)(i / P.c_group) * P.c_gld + (long long)(i % P.c_group) * P.ldc;
+                    Cb[row + j] = acc[a][b][q] + bj;
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host helpers
 int grid_for(long long work, int cap = 256 * 32) {
     long long g = work < 1 ? 1 : work;
@@ -2887,6 +3070,68 @@ int singa_grad_norm(const float* const* g, const long long* sizes, const int32_t
                        chunk_off, chunk, partial);
     hipLaunchKernelGGL(grad_norm_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nchunks, out);
     return check_launch("grad_norm");
+}
+
+int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_contig, int splits, void* stream) {
+    if (!probs || n < 1 || n > SINGA_GEMM_MAX) return fail(SINGA_E_SHAPE, "gemm_f32: 1..SINGA_GEMM_MAX problems per launch");
+    if (splits < 1) return fail(SINGA_E_SHAPE, "gemm_f32: splits must be >= 1");
+    if (!a_r_contig && b_r_contig) return fail(SINGA_E_SHAPE, "gemm_f32: A output-contiguous with B reduction-contiguous is not built");
+    GemmBatch gb;
+    memset(&gb, 0, sizeof(gb));
+    gb.n = n;
+    gb.splits = splits;
+    long long rmax = 0;
+    int jmax = 0;
+    for (int k = 0; k < n; ++k) jmax = probs[k].J > jmax ? probs[k].J : jmax;
+    const bool narrow = jmax <= 32;                   // 256 x 32 tiles for outputs with at most 32 columns
+    const int BM = narrow ? 256 : 128, BN = narrow ? 32 : 128;
+    int tiles = 0;
+    for (int k = 0; k < n; ++k) {
+        const singa_gemm_t& q = probs[k];
+        GemmProb& P = gb.p[k];
+        if (!q.a || !q.b || !q.c) return fail(SINGA_E_NULL, "gemm_f32: null operand");
+        if (q.I < 0 || q.J < 0 || q.R < 0) return fail(SINGA_E_SHAPE, "gemm_f32: negative size");
+        // float4 accesses: the contiguous axis of each operand must be a multiple of 4 floats and 16-byte aligned
+        const bool a_ok = a_r_contig ? (q.R % 4 == 0) : (q.I % 4 == 0);
+        const bool b_ok = b_r_contig ? (q.R % 4 == 0) : (q.J % 4 == 0);
+        if (!a_ok || !b_ok || q.lda % 4 || q.ldb % 4 || q.a_group_ld % 4 || q.b_group_ld % 4 || ((uintptr_t)q.a & 15) ||
+            ((uintptr_t)q.b & 15))
+            return fail(SINGA_E_SHAPE, "gemm_f32: contiguous axes must be multiples of 4 floats and 16-byte aligned");
+        if (b_r_contig && q.b_group > 0) return fail(SINGA_E_SHAPE, "gemm_f32: a reduction-contiguous B has plain rows");
+        if (splits > 1 && (q.c_group > 0 || q.ldc != q.J || q.bias || q.c_split_stride < (long long)q.I * q.J))
+            return fail(SINGA_E_SHAPE, "gemm_f32: split reductions write dense [I, J] partial slabs (c_split_stride apart), no bias");
+        P.A = q.a; P.B = q.b; P.C = q.c; P.bias = q.bias;
+        P.lda = q.lda; P.ldb = q.ldb; P.ldc = q.ldc;
+        P.a_group = q.a_group > 0 ? q.a_group : (1 << 30);
+        P.b_group = q.b_group > 0 ? q.b_group : (1 << 30);
+        P.c_group = q.c_group > 0 ? q.c_group : (1 << 30);
+        P.a_gld = q.a_group > 0 ? q.a_group_ld : 0;
+        P.b_gld = q.b_group > 0 ? q.b_group_ld : 0;
+        P.c_gld = q.c_group > 0 ? q.c_group_ld : 0;
+        P.c_split = q.c_split_stride;
+        P.I = q.I; P.J = q.J; P.R = q.R;
+        P.tiles_j = (q.J + BN - 1) / BN;
+        P.tile_begin = tiles;
+        tiles += ((q.I + BM - 1) / BM) * P.tiles_j;
+        if (q.R > rmax) rmax = q.R;
+    }
+    if (tiles == 0) return SINGA_OK;
+    gb.tiles_total = tiles;
+    gb.r_chunk = splits > 1 ? ((rmax + splits - 1) / splits + 31) / 32 * 32 : (rmax > 0 ? rmax : 1);
+    const long long nblk = (long long)tiles * splits;
+    if (nblk > (1 << 30)) return fail(SINGA_E_SHAPE, "gemm_f32: too many tiles");
+    const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define SINGA_GEMM_GO(tag, ARC, BRC)                                                                     \
+    do {                                                                                                 \
+        if (narrow) SINGA_LAUNCH(tag, 0, tiles, (gemm_f32_kernel<ARC, BRC, 1>), grid, block, st, gb);    \
+        else SINGA_LAUNCH(tag, 0, tiles, (gemm_f32_kernel<ARC, BRC, 2>), grid, block, st, gb);           \
+    } while (0)
+    if (a_r_contig && b_r_contig) SINGA_GEMM_GO(SINGA_PROF_GEMM_NT, true, true);
+    else if (a_r_contig) SINGA_GEMM_GO(SINGA_PROF_GEMM_NN, true, false);
+    else SINGA_GEMM_GO(SINGA_PROF_GEMM_TN, false, false);
+#undef SINGA_GEMM_GO
+    return check_launch("gemm_f32");
 }
 
 int singa_alpha_logits_nslots(int E) {

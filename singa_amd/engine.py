@@ -215,6 +215,7 @@ class TrainStep:
         EF_layers._edge_pinned.clear()
         self._make_static(batch)
         st = self.static
+        EF_layers._frame_flag_tensor(st[PA]["pos"].device)     # the guards' device-side statistics must exist before capture
         snap = self.opt.snapshot() if hasattr(self.opt, "snapshot") else None
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())

@@ -142,7 +142,7 @@ def _segs3(ts, rows, CH):
 class _RotateBackScatter(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y0, y1, y2, alpha, wr, es, heads, L, M):
-        y0, y1, y2, alpha = y0.contiguous(), y1.contiguous(), y2.contiguous(), alpha.contiguous()
+        y0, y1, y2, alpha = _rows(y0), _rows(y1), _rows(y2), alpha.contiguous()      # column-block views are taken as they are
         _dev(y0, y1, y2, alpha, wr)
         lay = so3.layout(L, M)
         CH = y0.shape[1] // lay.seg_rows[0]
@@ -164,7 +164,9 @@ class _RotateBackScatter(torch.autograd.Function):
         es, heads, L, M, CH = ctx.es, ctx.heads, ctx.L, ctx.M, ctx.CH
         lay = so3.layout(L, M)
         g = g.contiguous()
-        gy = [torch.empty_like(y0), torch.empty_like(y1), torch.empty_like(y2)]
+        widths = [y0.shape[1], y1.shape[1], y2.shape[1]]
+        gY = torch.empty(es.E, sum(widths), device=g.device, dtype=torch.float32)   # the three gradients as column blocks
+        gy = list(gY.split(widths, dim=1))
         gap = torch.empty(es.E, CH, device=g.device, dtype=torch.float32)
         seg, n = _segs3((y0, y1, y2), lay.seg_rows, CH)
         gseg, _ = _segs3(gy, lay.seg_rows, CH)
@@ -293,7 +295,7 @@ class _S2ActEdge(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h0, h1, h2, gate_off, x_off, C, L, M):
-        h0, h1, h2 = h0.contiguous(), h1.contiguous(), h2.contiguous()
+        h0, h1, h2 = _rows(h0), _rows(h1), _rows(h2)
         _dev(h0, h1, h2)
         lay = so3.layout(L, M)
         P, Q, A = _grid_factors(L, M, True, h0.device)
@@ -343,7 +345,7 @@ class _EdgeHead(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h0, h1, h2, ln_w, ln_b, dot, heads, A, C, L, M, eps):
-        h0, h1, h2 = h0.contiguous(), h1.contiguous(), h2.contiguous()
+        h0, h1, h2 = _rows(h0), _rows(h1), _rows(h2)
         ln_w, ln_b, dot = ln_w.contiguous(), ln_b.contiguous(), dot.contiguous()
         _dev(h0, h1, h2, ln_w, ln_b, dot)
         lay = so3.layout(L, M)
@@ -945,11 +947,113 @@ class _Linear(torch.autograd.Function):
         return gx, gw, gb
 
 
+# ---------------------------------------------------------------------------------------- k7 / k11: own f32 MFMA GEMM
+USE_OWN_GEMM = _os.environ.get("SINGA_GEMM", "own") == "own"      # "lib": the library GEMMs (kept as the tests' cross-check)
+_GEMM_SPLIT_ROWS = int(_os.environ.get("SINGA_GEMM_SPLIT_ROWS", "2048"))
+
+
+def _rows(t):
+    """A 2-D operand with unit column stride and 16-byte aligned rows (column-block views qualify); a copy otherwise."""
+    if t.stride(-1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t
+
+
+def _gemm(items, a_rc, b_rc, splits=1):
+    arr, n = _capi.gemm_probs(items)
+    _chk(_lib.lib().singa_gemm_f32(arr, n, int(a_rc), int(b_rc), int(splits), _stream()), "singa_gemm_f32")
+
+
+def _splits_for(rows):
+    return max(1, min(64, -(-rows // _GEMM_SPLIT_ROWS)))
+
+
+def gemm_nt(x, w, bias=None, out=None):
+    """y = x w^T (+ bias) on the library's own MFMA kernel; x [M, K] (row-strided views allowed), w [N, K]."""
+    x, w = _rows(x), _rows(w)
+    _dev(x, w)
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    _gemm([dict(a=x.data_ptr(), lda=x.stride(0), b=w.data_ptr(), ldb=w.stride(0), c=out.data_ptr(), ldc=out.stride(0),
+                bias=bias.data_ptr() if bias is not None else None, I=M, J=N, R=K)], True, True)
+    return out
+
+
 class _SO2Linear3(torch.autograd.Function):
-    """The three GEMMs of one SO(2) convolution (m = 0 with bias, m = 1, m = 2) on column blocks of ONE m-primary edge
-    matrix X [E, n0+n1+n2].  As separate autograd nodes every block's input gradient came back as a slice gradient:
-    a zero-filled [E, n0+n1+n2] tensor, a copy into the slice and an accumulation per block (three full-size passes
-    each).  Here the three dX products are written straight into the column blocks of one uninitialised buffer."""
+    """The three contractions of one SO(2) convolution (m = 0 with bias, m = 1, m = 2; EF:807-875 with the +-m
+    recombination folded into the block weights) on column blocks of ONE m-primary edge matrix X [E, n0+n1+n2]: one launch
+    of the library's f32 MFMA GEMM (k7) forward, one for dX (written straight into the column blocks of one buffer), one
+    split-reduction launch + one column sum for the three weight gradients.  The results are column blocks of one
+    [E, o0+o1+o2] buffer; their consumers take (pointer, row pitch) pairs."""
+
+    @staticmethod
+    def forward(ctx, X, w0, b0, w1, w2, n0, n1):
+        X = _rows(X)
+        ws = [_rows(w0), _rows(w1), _rows(w2)]
+        b0 = b0.contiguous()
+        _dev(X, *ws, b0)
+        E, nin = X.shape
+        ins = (n0, n1, nin - n0 - n1)
+        outs = tuple(w.shape[0] for w in ws)
+        assert all(w.shape[1] == k for w, k in zip(ws, ins))
+        H = torch.empty(E, sum(outs), device=X.device, dtype=torch.float32)
+        items, ai, ci = [], 0, 0
+        for w, k, o, b in zip(ws, ins, outs, (b0, None, None)):
+            items.append(dict(a=X.data_ptr() + 4 * ai, lda=X.stride(0), b=w.data_ptr(), ldb=w.stride(0),
+                              c=H.data_ptr() + 4 * ci, ldc=H.stride(0), bias=b.data_ptr() if b is not None else None,
+                              I=E, J=o, R=k))
+            ai, ci = ai + k, ci + o
+        if E > 0:
+            _gemm(items, True, True)
+        ctx.save_for_backward(X, *ws)
+        ctx.ins, ctx.outs = ins, outs
+        o0, o1 = outs[0], outs[0] + outs[1]
+        return H[:, :o0], H[:, o0:o1], H[:, o1:]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        X, w0, w1, w2 = ctx.saved_tensors
+        ins, outs = ctx.ins, ctx.outs
+        E = X.shape[0]
+        gs = [_rows(g) for g in (g0, g1, g2)]
+        ws = (w0, w1, w2)
+        gX = None
+        if ctx.needs_input_grad[0]:
+            gX = torch.empty_like(X)
+            items, ai = [], 0
+            for g, w, k, o in zip(gs, ws, ins, outs):       # dX_blk = g_blk @ w_blk: A = g [E, o] (RC), B = w [o, k] ([R][J])
+                items.append(dict(a=g.data_ptr(), lda=g.stride(0), b=w.data_ptr(), ldb=w.stride(0),
+                                  c=gX.data_ptr() + 4 * ai, ldc=gX.stride(0), I=E, J=k, R=o))
+                ai += k
+            if E > 0:
+                _gemm(items, True, False)
+        # dW_blk = g_blk^T X_blk: reduction over the edges, split over workgroups into dense partial slabs
+        sizes = [o * k for o, k in zip(outs, ins)]
+        tot = sum(sizes)
+        S = _splits_for(E)
+        part = torch.empty(S, tot, device=X.device, dtype=torch.float32)
+        items, ai, off = [], 0, 0
+        for g, k, o, sz in zip(gs, ins, outs, sizes):
+            items.append(dict(a=g.data_ptr(), lda=g.stride(0), b=X.data_ptr() + 4 * ai, ldb=X.stride(0),
+                              c=part.data_ptr() + 4 * off, ldc=k, I=o, J=k, R=E, c_split_stride=tot))
+            ai, off = ai + k, off + sz
+        if E > 0:
+            _gemm(items, False, False, S)
+            gw = colsum(part) if S > 1 else part[0]
+        else:
+            gw = torch.zeros(tot, device=X.device, dtype=torch.float32)
+        gws, off = [], 0
+        for o, k, sz in zip(outs, ins, sizes):
+            gws.append(gw[off:off + sz].view(o, k))
+            off += sz
+        return gX, gws[0], colsum(gs[0]), gws[1], gws[2], None, None
+
+
+class _SO2Linear3Lib(torch.autograd.Function):
+    """The same three GEMMs through the BLAS libraries (hipBLASLt / rocBLAS via torch): the cross-check of k7 in the tests
+    (SINGA_GEMM=lib selects it)."""
 
     @staticmethod
     def forward(ctx, X, w0, b0, w1, w2, n0, n1):
@@ -980,15 +1084,74 @@ class _SO2Linear3(torch.autograd.Function):
 
 def so2_linear3(X, w0, b0, w1, w2, n0, n1):
     """(X[:, :n0] w0^T + b0, X[:, n0:n0+n1] w1^T, X[:, n0+n1:] w2^T) - see _SO2Linear3."""
-    return _SO2Linear3.apply(X, w0, b0, w1, w2, n0, n1)
+    return (_SO2Linear3 if USE_OWN_GEMM else _SO2Linear3Lib).apply(X, w0, b0, w1, w2, n0, n1)
 
 
 class _SO3Linear(torch.autograd.Function):
-    """SO3_LinearV2 (EF:624-674) on [N, K, C] coefficient rows: one batched GEMM over the K rows with the per-degree weight
-    expanded by row, written straight into the [N, K, out] result through a transposed view (the library takes the row
-    and batch strides as they are), bias on the l = 0 row only.  The backward does the same for dX; the per-degree
-    weight gradient is the per-row gradient summed by degree with a one-hot GEMM.  No transposed copies, no zero-filled
-    select / slice gradients."""
+    """SO3_LinearV2 (EF:624-674) on [N, K, C] coefficient rows with the library's f32 MFMA GEMM (k11): one launch with one
+    problem per degree l (its 2l+1 rows of every node form a grouped row set, so the [N, K, out] result is written in
+    place, bias on the l = 0 row), one launch for dX, one split-reduction launch + column sum for the per-degree weight
+    gradients.  No expanded [K, out, in] weight, no transposed copies."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, L):
+        x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
+        _dev(x, weight, bias)
+        N, K, cin = x.shape
+        cout = weight.shape[1]
+        out = torch.empty(N, K, cout, device=x.device, dtype=torch.float32)
+        items = []
+        for l in range(L + 1):
+            n = 2 * l + 1
+            items.append(dict(a=x.data_ptr() + 4 * l * l * cin, lda=cin, a_group=n, a_group_ld=K * cin,
+                              b=weight.data_ptr() + 4 * l * cout * cin, ldb=cin,
+                              c=out.data_ptr() + 4 * l * l * cout, ldc=cout, c_group=n, c_group_ld=K * cout,
+                              bias=bias.data_ptr() if l == 0 else None, I=N * n, J=cout, R=cin))
+        if N > 0:
+            _gemm(items, True, True)
+        ctx.save_for_backward(x, weight)
+        ctx.L = L
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        L = ctx.L
+        g = g.contiguous()
+        N, K, cin = x.shape
+        cout = weight.shape[1]
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            items = []
+            for l in range(L + 1):
+                n = 2 * l + 1
+                items.append(dict(a=g.data_ptr() + 4 * l * l * cout, lda=cout, a_group=n, a_group_ld=K * cout,
+                                  b=weight.data_ptr() + 4 * l * cout * cin, ldb=cin,
+                                  c=gx.data_ptr() + 4 * l * l * cin, ldc=cin, c_group=n, c_group_ld=K * cin,
+                                  I=N * n, J=cin, R=cout))
+            if N > 0:
+                _gemm(items, True, False)
+        # dW_l = sum over the (node, row) pairs of degree l of g_row^T x_row
+        sz = cout * cin
+        S = _splits_for(N * (2 * L + 1))
+        part = torch.empty(S, (L + 1) * sz, device=x.device, dtype=torch.float32)
+        items = []
+        for l in range(L + 1):
+            n = 2 * l + 1
+            items.append(dict(a=g.data_ptr() + 4 * l * l * cout, lda=cout, a_group=n, a_group_ld=K * cout,
+                              b=x.data_ptr() + 4 * l * l * cin, ldb=cin, b_group=n, b_group_ld=K * cin,
+                              c=part.data_ptr() + 4 * l * sz, ldc=cin, I=cout, J=cin, R=N * n, c_split_stride=(L + 1) * sz))
+        if N > 0:
+            _gemm(items, False, False, S)
+            gw = (colsum(part) if S > 1 else part[0]).view(L + 1, cout, cin)
+        else:
+            gw = torch.zeros(L + 1, cout, cin, device=x.device, dtype=torch.float32)
+        return gx, gw, colsum(g[:, 0, :]), None
+
+
+class _SO3LinearLib(torch.autograd.Function):
+    """SO3_LinearV2 as one batched library GEMM over the K rows (the cross-check of k11; SINGA_GEMM=lib selects it)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, L):
@@ -1016,7 +1179,7 @@ class _SO3Linear(torch.autograd.Function):
 
 
 def so3_linear(x, weight, bias, L):
-    return _SO3Linear.apply(x, weight, bias, L)
+    return (_SO3Linear if USE_OWN_GEMM else _SO3LinearLib).apply(x, weight, bias, L)
 
 
 class _GroupedLinear(torch.autograd.Function):

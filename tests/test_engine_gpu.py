@@ -92,7 +92,7 @@ def test_adam_state_dict_is_torch_adam_layout():
     for i in (0, 1):
         assert float(sd["state"][i]["step"]) == float(sr["state"][i]["step"]) == 3.0
         for k in ("exp_avg", "exp_avg_sq"):
-            assert torch.allclose(sd["state"][i][k], sr["state"][i][k], rtol=1e-5, atol=1e-8)
+            assert torch.allclose(sd["state"][i][k], sr["state"][i][k], rtol=1e-4, atol=1e-8)
         assert torch.allclose(ws[i], wt[i], rtol=1e-5, atol=1e-7)
     # torch -> ours and ours -> torch, then one more step on each side
     ws2 = [torch.nn.Parameter(w.detach().clone()) for w in wt]

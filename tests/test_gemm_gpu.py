@@ -1,0 +1,143 @@
+"""-m gpu: the library's f32 MFMA GEMM (k7 / k11, singa_gemm_f32) - raw products against float64 on the CPU, the SO(2)
+convolution against the oracle's restatement of the reference (EF:807-875, 715-729: per-m Linear with the (r0 - i1,
+r1 + i0) recombination) and SO3_LinearV2 against EF:655-671, forward and every gradient, plus the BLAS-library path as a
+second opinion."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import singa_oracle as O
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _f64(t):
+    return t.detach().cpu().double()
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 16, 16), (130, 40, 36), (129, 992, 160), (1000, 560, 640), (257, 16, 112), (300, 32, 512),
+                                   (64, 1024, 256), (5000, 128, 8)])
+def test_gemm_nt_nn_tn_against_float64(M, N, K):
+    """y = x W^T + b, dx = dy W, dW = dy^T x (split reduction) for sizes with ragged tiles in every dimension; exact
+    integers first (any indexing slip shows as an O(1) error), then random floats."""
+    from singa_amd import ops
+    g = torch.Generator().manual_seed(M * 7 + N)
+    for kind in ("int", "float"):
+        mk = (lambda *s: torch.randint(-3, 4, s, generator=g).float()) if kind == "int" else (lambda *s: torch.randn(*s, generator=g))
+        x, w, b, dy = mk(M, K), mk(N, K), mk(N), mk(M, N)
+        xd, wd, bd, dyd = x.to(DEV), w.to(DEV), b.to(DEV), dy.to(DEV)
+        tol = 0 if kind == "int" else 2e-6
+        y = ops.gemm_nt(xd, wd, bd)
+        ref = _f64(x) @ _f64(w).t() + _f64(b)
+        assert float((_f64(y) - ref).abs().max()) <= tol * float(ref.abs().max()) + (0 if kind == "int" else 1e-6)
+        # dx through the (1, 0) form, dW through the split (0, 0) form
+        dx = torch.empty(M, K, device=DEV)
+        ops._gemm([dict(a=dyd.data_ptr(), lda=N, b=wd.data_ptr(), ldb=K, c=dx.data_ptr(), ldc=K, I=M, J=K, R=N)], True, False)
+        ref = _f64(dy) @ _f64(w)
+        assert float((_f64(dx) - ref).abs().max()) <= tol * float(ref.abs().max()) + (0 if kind == "int" else 1e-6)
+        for S in (1, 3):
+            part = torch.full((S, N * K), float("nan"), device=DEV)
+            ops._gemm([dict(a=dyd.data_ptr(), lda=N, b=xd.data_ptr(), ldb=K, c=part.data_ptr(), ldc=K, I=N, J=K, R=M,
+                            c_split_stride=N * K)], False, False, S)
+            ref = _f64(dy).t() @ _f64(x)
+            got = _f64(part).sum(0).view(N, K)
+            assert float((got - ref).abs().max()) <= tol * float(ref.abs().max()) + (0 if kind == "int" else 2e-6 * M ** 0.5)
+
+
+def test_gemm_argument_errors():
+    from singa_amd import ops
+    x, w = torch.zeros(8, 6, device=DEV), torch.zeros(4, 6, device=DEV)
+    with pytest.raises(RuntimeError, match="multiples of 4"):
+        ops.gemm_nt(x, w)                                   # K = 6 is not a multiple of 4 floats
+    with pytest.raises(RuntimeError):
+        ops._gemm([dict(a=0, b=0, c=0, I=1, J=1, R=4)], True, True)
+
+
+def _so2_case(L, E, cin, cout, extra, seed):
+    """Random m-primary edge rows + weights in the reference's parameter layout."""
+    from singa_amd import so3
+    lay = so3.layout(L, 2)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(E, lay.KR, cin, generator=g)                      # reduced l-primary, as the oracle takes it
+    sd = {"c.fc_m0.weight": torch.randn((L + 1) * cout + extra, (L + 1) * cin, generator=g) / ((L + 1) * cin) ** 0.5,
+          "c.fc_m0.bias": torch.randn((L + 1) * cout + extra, generator=g)}
+    for m in (1, 2):
+        n = L - m + 1
+        sd[f"c.so2_m_conv.{m - 1}.fc.weight"] = torch.randn(2 * cout * n, cin * n, generator=g) / (cin * n) ** 0.5
+    return lay, x, sd
+
+
+@pytest.mark.parametrize("L,cin,cout,extra", [(2, 32, 128, 352), (4, 32, 128, 352), (4, 128, 112, 0), (6, 128, 112, 0)])
+def test_so2_convolution_matches_oracle(L, cin, cout, extra):
+    """ops.so2_linear3 on the own MFMA kernel (and on the BLAS libraries) vs oracle.so2_conv: outputs per m, d input,
+    d weights, d bias.  E = 777 edges: ragged row tiles; the weight-gradient reduction is forced into several splits."""
+    from singa_amd import ops
+    from singa_amd.model.EF_layers import SO2_m_Convolution
+    E = 777
+    lay, x, sd = _so2_case(L, E, cin, cout, extra, seed=L * 10 + cin)
+    fr = O.Frame(torch.eye(3).repeat(E, 1, 1), L, 2)
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    want, ex = O.so2_conv(sdo, "c", xo, None, fr, cout, extra)       # [E, KR, cout] reduced l-primary (+ extra)
+    gy = torch.randn(want.shape, generator=torch.Generator().manual_seed(1))
+    gex = torch.randn(E, extra, generator=torch.Generator().manual_seed(2)) if extra else None
+    ((want * gy).sum() + ((ex * gex).sum() if extra else 0.0)).backward()
+    to_m = torch.as_tensor(lay.to_m)
+    st = lay.seg_start
+    for own in (True, False):
+        ops.USE_OWN_GEMM, ops._GEMM_SPLIT_ROWS = own, 200
+        try:
+            X = x[:, to_m].reshape(E, -1).to(DEV).requires_grad_(True)       # m-primary rows, what k4 hands over
+            w0 = sd["c.fc_m0.weight"].to(DEV).requires_grad_(True)
+            b0 = sd["c.fc_m0.bias"].to(DEV).requires_grad_(True)
+            fcs = []
+            for m in (1, 2):
+                mod = SO2_m_Convolution(m, cin, cout, [L], [2], device=DEV)
+                with torch.no_grad():
+                    mod.fc.weight.copy_(sd[f"c.so2_m_conv.{m - 1}.fc.weight"])
+                fcs.append(mod)
+            h0, h1, h2 = ops.so2_linear3(X, w0, b0, fcs[0].block_weight(), fcs[1].block_weight(), st[1] * cin, (st[2] - st[1]) * cin)
+            got = torch.cat([h0[:, extra:], h1, h2], 1).reshape(E, lay.KR, cout)        # m-primary rows
+            assert rel_err(got.detach().cpu(), want[:, to_m]) < 2e-6
+            if extra:
+                assert rel_err(h0[:, :extra].detach().cpu(), ex) < 2e-6
+            loss = (got * gy[:, to_m].to(DEV)).sum() + ((h0[:, :extra] * gex.to(DEV)).sum() if extra else 0.0)
+            loss.backward()
+            assert rel_err(X.grad.cpu().reshape(E, lay.KR, cin), xo.grad[:, to_m]) < 5e-6
+            assert rel_err(w0.grad.cpu(), sdo["c.fc_m0.weight"].grad) < 1e-5
+            assert rel_err(b0.grad.cpu(), sdo["c.fc_m0.bias"].grad) < 1e-5
+            for m in (1, 2):
+                assert rel_err(fcs[m - 1].fc.weight.grad.cpu(), sdo[f"c.so2_m_conv.{m - 1}.fc.weight"].grad) < 1e-5, (own, m)
+        finally:
+            ops.USE_OWN_GEMM, ops._GEMM_SPLIT_ROWS = True, 2048
+
+
+@pytest.mark.parametrize("L,cin,cout", [(2, 16, 512), (4, 512, 16), (4, 112, 16), (6, 16, 512), (6, 512, 16)])
+def test_so3_linear_matches_oracle(L, cin, cout):
+    """ops.so3_linear (k11: one grouped-row problem per degree) vs oracle.so3_linear (EF:655-671): output, d input,
+    d weight per degree, d bias; N = 333 nodes (ragged tiles, several reduction splits)."""
+    from singa_amd import ops
+    N, K = 333, (L + 1) ** 2
+    g = torch.Generator().manual_seed(L + cin)
+    x = torch.randn(N, K, cin, generator=g)
+    sd = {"p.weight": torch.randn(L + 1, cout, cin, generator=g) / cin ** 0.5, "p.bias": torch.randn(cout, generator=g)}
+    sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xo = x.clone().requires_grad_(True)
+    want = O.so3_linear(sdo, "p", xo, L)
+    gy = torch.randn(want.shape, generator=g)
+    (want * gy).sum().backward()
+    for own in (True, False):
+        ops.USE_OWN_GEMM, ops._GEMM_SPLIT_ROWS = own, 500
+        try:
+            xd = x.to(DEV).requires_grad_(True)
+            w, b = sd["p.weight"].to(DEV).requires_grad_(True), sd["p.bias"].to(DEV).requires_grad_(True)
+            got = ops.so3_linear(xd, w, b, L)
+            assert rel_err(got.detach().cpu(), want) < 2e-6
+            (got * gy.to(DEV)).sum().backward()
+            assert rel_err(xd.grad.cpu(), xo.grad) < 5e-6
+            assert rel_err(w.grad.cpu(), sdo["p.weight"].grad) < 1e-5
+            assert rel_err(b.grad.cpu(), sdo["p.bias"].grad) < 1e-5
+        finally:
+            ops.USE_OWN_GEMM, ops._GEMM_SPLIT_ROWS = True, 2048
