@@ -2168,21 +2168,127 @@ struct S2Sep {
     static constexpr int NM = 2 * MM + 1;
     static constexpr int RB = 2 * (L + 1);
     static constexpr int RA = EDGE ? (L == 2 ? 7 : 5) : 2 * L + 3;
+    static constexpr int HA = (RA - 1) / 2;          // RA is odd: alpha_a and alpha_{RA-a} are mirror images
     static constexpr int mc(int i) {
         if (EDGE) return i < L + 1 ? 2 : (i < 2 * L + 1 ? 3 : (i < 3 * L + 1 ? 1 : (i < 4 * L ? 4 : 0)));
         int l = 0;
         while ((l + 1) * (l + 1) <= i) ++l;
         return i - l * l - l + L;
     }
+    // parity of l + |m| of row i: P~_l^|m|(-z) = (-1)^(l+|m|) P~_l^|m|(z), i.e. ring RB-1-b carries the table row of
+    // ring b with this sign (beta_{RB-1-b} = pi - beta_b; the quadrature weights are symmetric too)
+    static constexpr int par(int i) {
+        if (EDGE) {
+            int l = i < L + 1 ? i : (i < 2 * L + 1 ? 1 + i - (L + 1) : (i < 3 * L + 1 ? 1 + i - (2 * L + 1) : (i < 4 * L ? 2 + i - (3 * L + 1) : 2 + i - 4 * L)));
+            int m = i < L + 1 ? 0 : (i < 3 * L + 1 ? 1 : 2);
+            return (l + m) & 1;
+        }
+        int l = 0;
+        while ((l + 1) * (l + 1) <= i) ++l;
+        int m = i - l * l - l;
+        return (l + (m < 0 ? -m : m)) & 1;
+    }
 };
 
+// sqrt(2) cos / sin (2 pi k a / RA) as compile-time constants (the alpha-harmonics of the grid, EF:562-587 via e3nn's
+// `sha`): a local constexpr table, indexed by unrolled loop counters, folds into instruction literals - no table loads,
+// no scalar-register pressure (the run-time [RA, 2M+1] table of the first version cost 440 SGPR spill moves per ring).
+constexpr double cx_sin_cos(int j, int n, bool want_cos) {      // sin or cos of 2 pi j / n, |j| reduced to (-n/2, n/2]
+    j %= n;
+    if (j < 0) j += n;
+    if (2 * j > n) j -= n;
+    const double x = 6.283185307179586476925286766559 * (double)j / (double)n;
+    double term = want_cos ? 1.0 : x, sum = term;
+    for (int t = 1; t < 30; ++t) {
+        const int d = want_cos ? (2 * t - 1) * (2 * t) : (2 * t) * (2 * t + 1);
+        term = -term * x * x / (double)d;
+        sum += term;
+    }
+    return sum;
+}
+template <int RA, int MM>
+struct FourTab {
+    float c[MM + 1][(RA - 1) / 2 + 1];
+    float s[MM + 1][(RA - 1) / 2 + 1];
+};
+template <int RA, int MM>
+constexpr FourTab<RA, MM> make_four_tab() {
+    FourTab<RA, MM> t{};
+    for (int k = 0; k <= MM; ++k)
+        for (int a = 0; a <= (RA - 1) / 2; ++a) {
+            t.c[k][a] = (float)(1.4142135623730950488016887242097 * cx_sin_cos(k * a, RA, true));
+            t.s[k][a] = (float)(1.4142135623730950488016887242097 * cx_sin_cos(k * a, RA, false));
+        }
+    return t;
+}
+__device__ __forceinline__ float silu_fast(float u) { return u * __frcp_rn(1.0f + __expf(-u)); }
+__device__ __forceinline__ float silu_grad_fast(float u) {
+    const float sg = __frcp_rn(1.0f + __expf(-u));
+    return sg * (1.0f + u * (1.0f - sg));
+}
+
+// u[a] = sum_m A[a, m] v[m] over the RA points of one ring (A[a, +k] = sqrt2 cos(k alpha_a), A[a, -k] = sqrt2 sin(k alpha_a),
+// A[a, 0] = 1; v[MM + m]) through the even / odd split: u[a] = E[a] + O[a], u[RA - a] = E[a] - O[a].
+template <int RA, int MM>
+__device__ __forceinline__ void ring_to_grid(const float (&v)[2 * MM + 1], float (&u)[RA]) {
+    constexpr auto T = make_four_tab<RA, MM>();
+    constexpr int HA = (RA - 1) / 2;
+    float e0 = v[MM];
+#pragma unroll
+    for (int k = 1; k <= MM; ++k) e0 = fmaf(T.c[k][0], v[MM + k], e0);
+    u[0] = e0;
+#pragma unroll
+    for (int a = 1; a <= HA; ++a) {
+        float ev = v[MM], od = 0.f;
+#pragma unroll
+        for (int k = 1; k <= MM; ++k) {
+            ev = fmaf(T.c[k][a], v[MM + k], ev);
+            od = fmaf(T.s[k][a], v[MM - k], od);
+        }
+        u[a] = ev + od;
+        u[RA - a] = ev - od;
+    }
+}
+// w[m] += sum_a A[a, m] s[a] (the transpose of ring_to_grid)
+template <int RA, int MM>
+__device__ __forceinline__ void ring_from_grid(const float (&sv)[RA], float (&w)[2 * MM + 1]) {
+    constexpr auto T = make_four_tab<RA, MM>();
+    constexpr int HA = (RA - 1) / 2;
+    float sp[HA + 1], sm[HA + 1];
+    float tot = sv[0];
+#pragma unroll
+    for (int a = 1; a <= HA; ++a) {
+        sp[a] = sv[a] + sv[RA - a];
+        sm[a] = sv[a] - sv[RA - a];
+        tot += sp[a];
+    }
+    w[MM] = tot;
+#pragma unroll
+    for (int k = 1; k <= MM; ++k) {
+        float wc = T.c[k][0] * sv[0], ws = 0.f;
+#pragma unroll
+        for (int a = 1; a <= HA; ++a) {
+            wc = fmaf(T.c[k][a], sp[a], wc);
+            ws = fmaf(T.s[k][a], sm[a], ws);
+        }
+        w[MM + k] = wc;
+        w[MM - k] = ws;
+    }
+}
+
+// thread = (row e, channel c), the KIN coefficient rows in registers.  Rings are handled in mirror pairs (b, RB-1-b): one
+// Legendre pass with the table row of ring b gives both rings' Fourier coefficients (even / odd parts), and both rings'
+// results are folded back with one pass.  Per ring the Fourier transform over alpha and its transpose use the even / odd
+// split above.  SiLU fused; row 0 of the result := SiLU(gate).  P, Q: [RB, KIN] Legendre tables (to-grid / from-grid) in
+// the row order of x, read as wave-uniform scalars.
 template <int L, bool EDGE, int C>
 __global__ void __launch_bounds__(256) s2act_sep_fwd_kernel(Segs x, const float* __restrict__ gate, long long ldg,
                                                             const float* __restrict__ P, const float* __restrict__ Q,
                                                             const float* __restrict__ A, float* __restrict__ out,
                                                             long long EC) {
     using S = S2Sep<L, EDGE>;
-    constexpr int KIN = S::KIN, NM = S::NM;
+    constexpr int KIN = S::KIN, NM = S::NM, RA = S::RA, MM = S::MM;
+    (void)A;
     long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= EC) return;
     long long e = tid / C;
@@ -2197,34 +2303,41 @@ __global__ void __launch_bounds__(256) s2act_sep_fwd_kernel(Segs x, const float*
         xv[i] = i < r0 ? b0[i * C] : (i < r01 ? b1[(i - r0) * C] : b2[(i - r01) * C]);
         yv[i] = 0.f;
     }
-    for (int b = 0; b < S::RB; ++b) {
+    for (int b = 0; b < S::RB / 2; ++b) {
         const float* Pb = P + b * KIN;
         const float* Qb = Q + b * KIN;
-        float v[NM], w[NM];
+        float ve[NM], vo[NM];
 #pragma unroll
-        for (int m = 0; m < NM; ++m) { v[m] = 0.f; w[m] = 0.f; }
+        for (int m = 0; m < NM; ++m) { ve[m] = 0.f; vo[m] = 0.f; }
 #pragma unroll
-        for (int i = 0; i < KIN; ++i) v[S::mc(i)] = fmaf(Pb[i], xv[i], v[S::mc(i)]);
-#pragma unroll
-        for (int a = 0; a < S::RA; ++a) {
-            float u = 0.f;
-#pragma unroll
-            for (int m = 0; m < NM; ++m) u = fmaf(A[a * NM + m], v[m], u);
-            const float sv = silu(u);
-#pragma unroll
-            for (int m = 0; m < NM; ++m) w[m] = fmaf(A[a * NM + m], sv, w[m]);
+        for (int i = 0; i < KIN; ++i) {
+            if (S::par(i)) vo[S::mc(i)] = fmaf(Pb[i], xv[i], vo[S::mc(i)]);
+            else ve[S::mc(i)] = fmaf(Pb[i], xv[i], ve[S::mc(i)]);
         }
+        float v1[NM], v2[NM], w1[NM], w2[NM], u[RA];
 #pragma unroll
-        for (int i = 1; i < KIN; ++i) yv[i] = fmaf(Qb[i], w[S::mc(i)], yv[i]);
+        for (int m = 0; m < NM; ++m) { v1[m] = ve[m] + vo[m]; v2[m] = ve[m] - vo[m]; }
+        ring_to_grid<RA, MM>(v1, u);
+#pragma unroll
+        for (int a = 0; a < RA; ++a) u[a] = silu_fast(u[a]);
+        ring_from_grid<RA, MM>(u, w1);
+        ring_to_grid<RA, MM>(v2, u);
+#pragma unroll
+        for (int a = 0; a < RA; ++a) u[a] = silu_fast(u[a]);
+        ring_from_grid<RA, MM>(u, w2);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) { ve[m] = w1[m] + w2[m]; vo[m] = w1[m] - w2[m]; }
+#pragma unroll
+        for (int i = 1; i < KIN; ++i) yv[i] = fmaf(Qb[i], S::par(i) ? vo[S::mc(i)] : ve[S::mc(i)], yv[i]);
     }
     float* o = out + e * KIN * C + c;
-    o[0] = silu(gate[e * ldg + c]);
+    o[0] = silu_fast(gate[e * ldg + c]);
 #pragma unroll
     for (int i = 1; i < KIN; ++i) o[i * C] = yv[i];
 }
 
-// Backward (recompute): per ring v = P x, gq[m] = sum_l Q[b,(l,m)] gy_(l,m) (rows i >= 1); per alpha u = A v,
-// t = SiLU'(u) * (A gq); acc[m] += A[a,m] t; gx_(l,m) += P[b,(l,m)] acc[m].  g_gate = gy_0 * SiLU'(gate).
+// Backward (recompute), same pairing: per ring v = P x and gq = Q^T gy (rows i >= 1); per alpha u = A v,
+// t = SiLU'(u) * (A gq); acc = A^T t; gx_i += P[b, i] acc[m(i)].  g_gate = gy_0 * SiLU'(gate).
 template <int L, bool EDGE, int C>
 __global__ void __launch_bounds__(256) s2act_sep_bwd_kernel(Segs x, const float* __restrict__ gate, long long ldg,
                                                             const float* __restrict__ P, const float* __restrict__ Q,
@@ -2232,7 +2345,8 @@ __global__ void __launch_bounds__(256) s2act_sep_bwd_kernel(Segs x, const float*
                                                             float* __restrict__ gx, float* __restrict__ g_gate,
                                                             long long EC) {
     using S = S2Sep<L, EDGE>;
-    constexpr int KIN = S::KIN, NM = S::NM;
+    constexpr int KIN = S::KIN, NM = S::NM, RA = S::RA, MM = S::MM;
+    (void)A;
     long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= EC) return;
     long long e = tid / C;
@@ -2249,35 +2363,49 @@ __global__ void __launch_bounds__(256) s2act_sep_bwd_kernel(Segs x, const float*
         gy[i] = gi[i * C];
         ga[i] = 0.f;
     }
-    for (int b = 0; b < S::RB; ++b) {
+    for (int b = 0; b < S::RB / 2; ++b) {
         const float* Pb = P + b * KIN;
         const float* Qb = Q + b * KIN;
-        float v[NM], gq[NM], acc[NM];
+        float ve[NM], vo[NM], ge[NM], go[NM];
 #pragma unroll
-        for (int m = 0; m < NM; ++m) { v[m] = 0.f; gq[m] = 0.f; acc[m] = 0.f; }
+        for (int m = 0; m < NM; ++m) { ve[m] = 0.f; vo[m] = 0.f; ge[m] = 0.f; go[m] = 0.f; }
 #pragma unroll
-        for (int i = 0; i < KIN; ++i) v[S::mc(i)] = fmaf(Pb[i], xv[i], v[S::mc(i)]);
-#pragma unroll
-        for (int i = 1; i < KIN; ++i) gq[S::mc(i)] = fmaf(Qb[i], gy[i], gq[S::mc(i)]);
-#pragma unroll
-        for (int a = 0; a < S::RA; ++a) {
-            float u = 0.f, vb = 0.f;
-#pragma unroll
-            for (int m = 0; m < NM; ++m) {
-                u = fmaf(A[a * NM + m], v[m], u);
-                vb = fmaf(A[a * NM + m], gq[m], vb);
-            }
-            const float t = vb * silu_grad(u);
-#pragma unroll
-            for (int m = 0; m < NM; ++m) acc[m] = fmaf(A[a * NM + m], t, acc[m]);
+        for (int i = 0; i < KIN; ++i) {
+            if (S::par(i)) vo[S::mc(i)] = fmaf(Pb[i], xv[i], vo[S::mc(i)]);
+            else ve[S::mc(i)] = fmaf(Pb[i], xv[i], ve[S::mc(i)]);
         }
 #pragma unroll
-        for (int i = 0; i < KIN; ++i) ga[i] = fmaf(Pb[i], acc[S::mc(i)], ga[i]);
+        for (int i = 1; i < KIN; ++i) {
+            if (S::par(i)) go[S::mc(i)] = fmaf(Qb[i], gy[i], go[S::mc(i)]);
+            else ge[S::mc(i)] = fmaf(Qb[i], gy[i], ge[S::mc(i)]);
+        }
+        float acc1[NM], acc2[NM];
+        {
+            float v[NM], q[NM], u[RA], t[RA];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) { v[m] = ve[m] + vo[m]; q[m] = ge[m] + go[m]; }
+            ring_to_grid<RA, MM>(v, u);
+            ring_to_grid<RA, MM>(q, t);
+#pragma unroll
+            for (int a = 0; a < RA; ++a) t[a] *= silu_grad_fast(u[a]);
+            ring_from_grid<RA, MM>(t, acc1);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) { v[m] = ve[m] - vo[m]; q[m] = ge[m] - go[m]; }
+            ring_to_grid<RA, MM>(v, u);
+            ring_to_grid<RA, MM>(q, t);
+#pragma unroll
+            for (int a = 0; a < RA; ++a) t[a] *= silu_grad_fast(u[a]);
+            ring_from_grid<RA, MM>(t, acc2);
+        }
+#pragma unroll
+        for (int m = 0; m < NM; ++m) { ve[m] = acc1[m] + acc2[m]; vo[m] = acc1[m] - acc2[m]; }
+#pragma unroll
+        for (int i = 0; i < KIN; ++i) ga[i] = fmaf(Pb[i], S::par(i) ? vo[S::mc(i)] : ve[S::mc(i)], ga[i]);
     }
     float* o = gx + e * KIN * C + c;
 #pragma unroll
     for (int i = 0; i < KIN; ++i) o[i * C] = ga[i];
-    g_gate[e * C + c] = gy[0] * silu_grad(gate[e * ldg + c]);
+    g_gate[e * C + c] = gy[0] * silu_grad_fast(gate[e * ldg + c]);
 }
 
 // ------------------------------------------------------------------------------------------------ k12: equivariant RMS norm

@@ -41,6 +41,7 @@ static inline hipError_t hipMemcpyToSymbol(T& sym, const void* src, size_t n, si
     return hipSuccess;
 }
 #define __expf(x) expf(x)
+static inline float __frcp_rn(float x) { return 1.0f / x; }
 #define __logf(x) logf(x)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline float __shfl_xor(float, int, int) {
