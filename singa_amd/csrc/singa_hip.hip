@@ -2569,15 +2569,24 @@ struct GemmBatch {
     long long r_chunk;
 };
 
-// NT = 2: macro tile 128 x 128 (2 x 2 wavefronts of 64 x 64); NT = 1: 256 x 32 (4 x 1 wavefronts of 64 x 32) for outputs with
+// NT = 2: macro tile 128 x 128 (2 x 2 wavefronts of 64 x 64); NT = 1: 128 x 32 (4 x 1 wavefronts of 32 x 32) for outputs with
 // few columns (the 16-channel results of SO3_LinearV2).
+//
+// LDS images, K step 32.  A reduction-contiguous operand keeps its global layout, [row][r] with a pitch of 36 floats: global
+// float4 -> ds_write_b128 with no transposition, and a lane's fragment for FOUR k-steps is ONE ds_read_b128 (row = lane % 32,
+// r = 8 t + 4 (lane / 32) .. + 3; 9 sixteen-byte slots per row: the 16 lanes of a read group land in 16 different slots).
+// The MFMA takes k from lanes 0-31 and k' from lanes 32-63 of its operand registers; WHICH reduction indices those are is
+// free as long as both operands agree: MFMA (t, s) pairs r = 8 t + s with r = 8 t + 4 + s.  An output-contiguous operand is
+// stored [r][col] (pitch + 4) and read with one ds_read_b32 per k-step at row 8 t + s + 4 (lane / 32) - the same pairing.
 template <bool A_RC, bool B_RC, int NT>
 __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
-    constexpr int BM = NT == 2 ? 128 : 256, BN = NT == 2 ? 128 : 32, BK = 32;
+    constexpr int BM = 128, BN = NT == 2 ? 128 : 32, BK = 32, PR = BK + 4;
+    constexpr int MT = NT == 2 ? 2 : 1;                            // 32-row MFMA tiles per wavefront
     constexpr int NA = BM / 32, NB = BN / 32;                      // float4 loads per thread and K step
-    constexpr int LDA = A_RC ? BM + 1 : BM + 4, LDB = B_RC ? BN + 1 : BN + 4;
-    __shared__ float As[2][BK * LDA];
-    __shared__ float Bs[2][BK * LDB];
+    constexpr int LDA = BM + 4, LDB = BN + 4;                      // pitches of the [r][col] images
+    constexpr int SZA = A_RC ? BM * PR : BK * LDA, SZB = B_RC ? BN * PR : BK * LDB;
+    __shared__ __attribute__((aligned(16))) float As[2][SZA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][SZB];
     // XCD-aware numbering: block b runs on XCD b % 8; give every XCD a contiguous range of tile ids
     const int nblk = gb.tiles_total * gb.splits;
     const int per = (nblk + 7) >> 3;
@@ -2596,69 +2605,88 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
     const long long r_end = (r_begin + gb.r_chunk < P.R) ? r_begin + gb.r_chunk : P.R;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = NT == 2 ? wave >> 1 : wave, wn = NT == 2 ? wave & 1 : 0, l31 = lane & 31, half = lane >> 5;
+    const int kq = tid & 7, rr = tid >> 3;                          // reduction-contiguous staging: float4 kq of row rr + 32 j
 
+    // ---- per-thread global row pointers (loop invariant for reduction-contiguous operands; nullptr = outside the matrix)
+    const float* arow[NA];
+    const float* brow[NB];
+    if (A_RC) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int i = i0 + rr + 32 * j;
+            arow[j] = i < P.I ? P.A + (long long)(i / P.a_group) * P.a_gld + (long long)(i % P.a_group) * P.lda + 4 * kq : nullptr;
+        }
+    }
+    if (B_RC) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int jj = j0 + rr + 32 * j;
+            brow[j] = jj < P.J ? P.B + (long long)jj * P.ldb + 4 * kq : nullptr;
+        }
+    }
     float4 ra[NA], rb[NB];
-    // ---- global -> registers for the K step starting at r0.  Reduction-contiguous operand ([i][r]): 8 lanes cover 128
-    // contiguous bytes of one row; output-contiguous ([r][i]): consecutive lanes cover consecutive float4 of one r row.
-    auto load_rc = [&](float4* reg, const float* base, long long ld, int grp, long long gld, int o0, int lim, int n, long long r0) {
-        const int kq = tid & 7, rr = tid >> 3;
-        const long long r = r0 + 4 * kq;
+    auto load_rc = [&](float4* reg, const float* const* rows, int n, long long r0) {
+        const bool in = r0 + 4 * kq < r_end;
+#pragma unroll
         for (int j = 0; j < n; ++j) {
-            const int i = o0 + rr + 32 * j;
             reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < lim && r < r_end) {
-                const long long row = (long long)(i / grp) * gld + (long long)(i % grp) * ld;
-                reg[j] = *reinterpret_cast<const float4*>(base + row + r);
-            }
+            if (in && rows[j]) reg[j] = *reinterpret_cast<const float4*>(rows[j] + r0);
         }
     };
     auto load_oc = [&](float4* reg, const float* base, long long ld, int grp, long long gld, int o0, int lim, int n, int width4,
                        long long r0) {
-        const int c4 = tid % width4, rr = tid / width4, rows = 256 / width4;
+        const int c4 = tid % width4, rq = tid / width4, rows = 256 / width4;
         const int i = o0 + 4 * c4;
+#pragma unroll
         for (int j = 0; j < n; ++j) {
-            const long long r = r0 + rr + rows * j;
+            const long long r = r0 + rq + rows * j;
             reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < r_end && i < lim) {
-                const long long row = (r / grp) * gld + (r % grp) * ld;
+                const long long row = grp == (1 << 30) ? r * ld : (r / grp) * gld + (r % grp) * ld;
                 reg[j] = *reinterpret_cast<const float4*>(base + row + i);
             }
         }
     };
-    // ---- registers -> LDS image [r][i]
-    auto store_rc = [&](float* S, const float4* reg, int pitch, int n) {
-        const int kq = tid & 7, rr = tid >> 3;
-        for (int j = 0; j < n; ++j) {
-            S[(4 * kq + 0) * pitch + rr + 32 * j] = reg[j].x;
-            S[(4 * kq + 1) * pitch + rr + 32 * j] = reg[j].y;
-            S[(4 * kq + 2) * pitch + rr + 32 * j] = reg[j].z;
-            S[(4 * kq + 3) * pitch + rr + 32 * j] = reg[j].w;
-        }
+    auto store_rc = [&](float* S, const float4* reg, int n) {
+#pragma unroll
+        for (int j = 0; j < n; ++j) *reinterpret_cast<float4*>(S + (rr + 32 * j) * PR + 4 * kq) = reg[j];
     };
     auto store_oc = [&](float* S, const float4* reg, int pitch, int n, int width4) {
-        const int c4 = tid % width4, rr = tid / width4, rows = 256 / width4;
-        for (int j = 0; j < n; ++j) *reinterpret_cast<float4*>(S + (rr + rows * j) * pitch + 4 * c4) = reg[j];
+        const int c4 = tid % width4, rq = tid / width4, rows = 256 / width4;
+#pragma unroll
+        for (int j = 0; j < n; ++j) *reinterpret_cast<float4*>(S + (rq + rows * j) * pitch + 4 * c4) = reg[j];
     };
     auto load_a = [&](long long r0) {
-        if (A_RC) load_rc(ra, P.A, P.lda, P.a_group, P.a_gld, i0, P.I, NA, r0);
+        if (A_RC) load_rc(ra, arow, NA, r0);
         else load_oc(ra, P.A, P.lda, P.a_group, P.a_gld, i0, P.I, NA, BM / 4, r0);
     };
     auto load_b = [&](long long r0) {
-        if (B_RC) load_rc(rb, P.B, P.ldb, 1 << 30, 0, j0, P.J, NB, r0);
+        if (B_RC) load_rc(rb, brow, NB, r0);
         else load_oc(rb, P.B, P.ldb, P.b_group, P.b_gld, j0, P.J, NB, BN / 4, r0);
     };
     auto store_a = [&](int buf) {
-        if (A_RC) store_rc(As[buf], ra, LDA, NA);
+        if (A_RC) store_rc(As[buf], ra, NA);
         else store_oc(As[buf], ra, LDA, NA, BM / 4);
     };
     auto store_b = [&](int buf) {
-        if (B_RC) store_rc(Bs[buf], rb, LDB, NB);
+        if (B_RC) store_rc(Bs[buf], rb, NB);
         else store_oc(Bs[buf], rb, LDB, NB, BN / 4);
     };
-
-    floatx16 acc[2][NT];
+    // fragments of k-group t (8 reduction indices = 4 MFMA k-steps) for the wavefront's MT / NT 32-wide blocks
+    const int ia = (NT == 2 ? wm * 64 : wm * 32) + l31, jb = wn * 64 + l31;
+    auto frag = [&](const float* S, bool rc, int pitch, int col, int t, float (&f)[4]) {
+        if (rc) {
+            const float4 v = *reinterpret_cast<const float4*>(S + col * PR + 8 * t + 4 * half);
+            f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+        } else {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+            for (int q = 0; q < 4; ++q) f[q] = S[(8 * t + q + 4 * half) * pitch + col];
+        }
+    };
+
+    floatx16 acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b)
 #pragma unroll
@@ -2672,26 +2700,36 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
         store_b(0);
     }
     __syncthreads();
-    for (long long t = 0; t < nsteps; ++t) {
-        const int buf = (int)(t & 1);
-        const bool more = t + 1 < nsteps;
+    for (long long st = 0; st < nsteps; ++st) {
+        const int buf = (int)(st & 1);
+        const bool more = st + 1 < nsteps;
         if (more) {
-            load_a(r_begin + (t + 1) * BK);
-            load_b(r_begin + (t + 1) * BK);
+            load_a(r_begin + (st + 1) * BK);
+            load_b(r_begin + (st + 1) * BK);
         }
-        const float* Sa = As[buf] + wm * 64 + l31;
-        const float* Sb = Bs[buf] + wn * 64 + l31;
+        const float* Sa = As[buf];
+        const float* Sb = Bs[buf];
+        float fa[2][MT][4], fb[2][NT][4];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = Sa[(kk + half) * LDA], a1 = Sa[(kk + half) * LDA + 32];
-            const float b0 = Sb[(kk + half) * LDB];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            if (NT == 2) {
-                const float b1 = Sb[(kk + half) * LDB + 32];
-                acc[0][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][NT - 1], 0, 0, 0);
-                acc[1][NT - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][NT - 1], 0, 0, 0);
+        for (int a = 0; a < MT; ++a) frag(Sa, A_RC, LDA, ia + 32 * a, 0, fa[0][a]);
+#pragma unroll
+        for (int b = 0; b < NT; ++b) frag(Sb, B_RC, LDB, jb + 32 * b, 0, fb[0][b]);
+#pragma unroll
+        for (int t = 0; t < BK / 8; ++t) {
+            const int cur = t & 1;
+            if (t + 1 < BK / 8) {            // the next group's fragments travel behind this group's MFMAs
+#pragma unroll
+                for (int a = 0; a < MT; ++a) frag(Sa, A_RC, LDA, ia + 32 * a, t + 1, fa[cur ^ 1][a]);
+#pragma unroll
+                for (int b = 0; b < NT; ++b) frag(Sb, B_RC, LDB, jb + 32 * b, t + 1, fb[cur ^ 1][b]);
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int b = 0; b < NT; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][a][q], fb[cur][b][q], acc[a][b], 0, 0, 0);
         }
         if (more) {
             store_a(buf ^ 1);
@@ -2707,10 +2745,10 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
         if (j >= P.J) continue;
         const float bj = P.bias ? P.bias[j] : 0.f;
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < MT; ++a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-                const int i = i0 + wm * 64 + 32 * a + (q & 3) + 8 * (q >> 2) + 4 * half;
+                const int i = i0 + (NT == 2 ? wm * 64 : wm * 32) + 32 * a + (q & 3) + 8 * (q >> 2) + 4 * half;
                 if (i < P.I) {
                     const long long row = (long long)(i / P.c_group) * P.c_gld + (long long)(i % P.c_group) * P.ldc;
                     Cb[row + j] = acc[a][b][q] + bj;
@@ -3211,8 +3249,8 @@ int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_con
     long long rmax = 0;
     int jmax = 0;
     for (int k = 0; k < n; ++k) jmax = probs[k].J > jmax ? probs[k].J : jmax;
-    const bool narrow = jmax <= 32;                   // 256 x 32 tiles for outputs with at most 32 columns
-    const int BM = narrow ? 256 : 128, BN = narrow ? 32 : 128;
+    const bool narrow = jmax <= 32;                   // 128 x 32 tiles for outputs with at most 32 columns
+    const int BM = 128, BN = narrow ? 32 : 128;
     int tiles = 0;
     for (int k = 0; k < n; ++k) {
         const singa_gemm_t& q = probs[k];
