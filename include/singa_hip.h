@@ -268,8 +268,9 @@ int singa_adam_step(float* const* p, const float* const* g, float* const* m, flo
  *   Built combinations: (1,1) y = x W^T; (1,0) dx = dy W; (0,0) dW = dy^T x.
  *   splits > 1: the reduction range is cut into `splits` chunks; chunk s writes a dense [I, J] slab (ldc = J, no bias, no
  *   grouping) at c + s * c_split_stride, which the caller adds up (singa_colsum).
- *   All problems of a launch use 128 x 128 output tiles, or 128 x 32 when every J <= 32.
- * Contiguous axes must be multiples of 4 floats and 16-byte aligned.  Enqueue-only on `stream`. */
+ *   All problems of a launch use 128 x 128 output tiles, 128 x 32 when every J <= 32, or 32 x 128 when every I <= 32.
+ * Contiguous axes (of A, B and of the result: J, ldc) must be multiples of 4 floats and 16-byte aligned.  Enqueue-only
+ * on `stream`. */
 #define SINGA_GEMM_MAX 8
 typedef struct {
     const float* a;

@@ -2569,8 +2569,8 @@ struct GemmBatch {
     long long r_chunk;
 };
 
-// NT = 2: macro tile 128 x 128 (2 x 2 wavefronts of 64 x 64); NT = 1: 128 x 32 (4 x 1 wavefronts of 32 x 32) for outputs with
-// few columns (the 16-channel results of SO3_LinearV2).
+// CFG 0: macro tile 128 x 128 (2 x 2 wavefronts of 64 x 64); CFG 1: 128 x 32 (4 x 1 wavefronts of 32 x 32) for outputs with
+// few columns, CFG 2: 32 x 128 (1 x 4 wavefronts) for outputs with few rows (the 16-channel sides of SO3_LinearV2).
 //
 // LDS images, K step 32.  A reduction-contiguous operand keeps its global layout, [row][r] with a pitch of 36 floats: global
 // float4 -> ds_write_b128 with no transposition, and a lane's fragment for FOUR k-steps is ONE ds_read_b128 (row = lane % 32,
@@ -2578,15 +2578,21 @@ struct GemmBatch {
 // The MFMA takes k from lanes 0-31 and k' from lanes 32-63 of its operand registers; WHICH reduction indices those are is
 // free as long as both operands agree: MFMA (t, s) pairs r = 8 t + s with r = 8 t + 4 + s.  An output-contiguous operand is
 // stored [r][col] (pitch + 4) and read with one ds_read_b32 per k-step at row 8 t + s + 4 (lane / 32) - the same pairing.
-template <bool A_RC, bool B_RC, int NT>
+// Epilogue: an accumulator holds 4 consecutive ROWS of one column per register quad, so a direct store is 64 dword stores
+// per lane; instead each wavefront passes its 32-row blocks through LDS (the K-loop buffers are free by then) and writes
+// float4 rows - 4x fewer store instructions, full 256-byte row segments.
+template <bool A_RC, bool B_RC, int CFG>
 __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
-    constexpr int BM = 128, BN = NT == 2 ? 128 : 32, BK = 32, PR = BK + 4;
-    constexpr int MT = NT == 2 ? 2 : 1;                            // 32-row MFMA tiles per wavefront
+    constexpr int BM = CFG == 2 ? 32 : 128, BN = CFG == 0 ? 128 : (CFG == 1 ? 32 : 128), BK = 32, PR = BK + 4;
+    constexpr int MT = CFG == 0 ? 2 : 1, NT = CFG == 0 ? 2 : 1;   // 32 x 32 MFMA tiles per wavefront
     constexpr int NA = BM / 32, NB = BN / 32;                      // float4 loads per thread and K step
     constexpr int LDA = BM + 4, LDB = BN + 4;                      // pitches of the [r][col] images
     constexpr int SZA = A_RC ? BM * PR : BK * LDA, SZB = B_RC ? BN * PR : BK * LDB;
-    __shared__ __attribute__((aligned(16))) float As[2][SZA];
-    __shared__ __attribute__((aligned(16))) float Bs[2][SZB];
+    constexpr int PE = 32 * NT + 4;                                // epilogue staging pitch (floats)
+    constexpr int SMEM = 2 * SZA + 2 * SZB > 4 * 32 * PE ? 2 * SZA + 2 * SZB : 4 * 32 * PE;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* const As0 = smem;
+    float* const Bs0 = smem + 2 * SZA;
     // XCD-aware numbering: block b runs on XCD b % 8; give every XCD a contiguous range of tile ids
     const int nblk = gb.tiles_total * gb.splits;
     const int per = (nblk + 7) >> 3;
@@ -2604,7 +2610,9 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
     const long long r_begin = (long long)split * gb.r_chunk;
     const long long r_end = (r_begin + gb.r_chunk < P.R) ? r_begin + gb.r_chunk : P.R;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = NT == 2 ? wave >> 1 : wave, wn = NT == 2 ? wave & 1 : 0, l31 = lane & 31, half = lane >> 5;
+    const int wrow = CFG == 0 ? (wave >> 1) * 64 : (CFG == 1 ? wave * 32 : 0);     // the wavefront's block of the macro tile
+    const int wcol = CFG == 0 ? (wave & 1) * 64 : (CFG == 1 ? 0 : wave * 32);
+    const int l31 = lane & 31, half = lane >> 5;
     const int kq = tid & 7, rr = tid >> 3;                          // reduction-contiguous staging: float4 kq of row rr + 32 j
 
     // ---- per-thread global row pointers (loop invariant for reduction-contiguous operands; nullptr = outside the matrix)
@@ -2665,15 +2673,15 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
         else load_oc(rb, P.B, P.ldb, P.b_group, P.b_gld, j0, P.J, NB, BN / 4, r0);
     };
     auto store_a = [&](int buf) {
-        if (A_RC) store_rc(As[buf], ra, NA);
-        else store_oc(As[buf], ra, LDA, NA, BM / 4);
+        if (A_RC) store_rc(As0 + buf * SZA, ra, NA);
+        else store_oc(As0 + buf * SZA, ra, LDA, NA, BM / 4);
     };
     auto store_b = [&](int buf) {
-        if (B_RC) store_rc(Bs[buf], rb, NB);
-        else store_oc(Bs[buf], rb, LDB, NB, BN / 4);
+        if (B_RC) store_rc(Bs0 + buf * SZB, rb, NB);
+        else store_oc(Bs0 + buf * SZB, rb, LDB, NB, BN / 4);
     };
     // fragments of k-group t (8 reduction indices = 4 MFMA k-steps) for the wavefront's MT / NT 32-wide blocks
-    const int ia = (NT == 2 ? wm * 64 : wm * 32) + l31, jb = wn * 64 + l31;
+    const int ia = wrow + l31, jb = wcol + l31;
     auto frag = [&](const float* S, bool rc, int pitch, int col, int t, float (&f)[4]) {
         if (rc) {
             const float4 v = *reinterpret_cast<const float4*>(S + col * PR + 8 * t + 4 * half);
@@ -2707,8 +2715,8 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
             load_a(r_begin + (st + 1) * BK);
             load_b(r_begin + (st + 1) * BK);
         }
-        const float* Sa = As[buf];
-        const float* Sb = Bs[buf];
+        const float* Sa = As0 + buf * SZA;
+        const float* Sb = Bs0 + buf * SZB;
         float fa[2][MT][4], fb[2][NT][4];
 #pragma unroll
         for (int a = 0; a < MT; ++a) frag(Sa, A_RC, LDA, ia + 32 * a, 0, fa[0][a]);
@@ -2737,22 +2745,34 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
         }
         __syncthreads();
     }
-    // ---- epilogue: accumulator register q of a 32 x 32 tile holds row (q & 3) + 8 (q >> 2) + 4 half, column lane & 31
+    // ---- epilogue.  Accumulator register q of a 32 x 32 tile holds row (q & 3) + 8 (q >> 2) + 4 half, column lane & 31.
+    // Every wavefront owns 32 x PE floats of LDS (all K-loop reads are behind the barrier above); one 32-row block at a time:
+    // registers -> [row][col] image -> float4 rows -> global, bias added on the way.
     float* Cb = P.C + (long long)split * P.c_split;
+    float* stage = smem + wave * (32 * PE);
+    constexpr int C4 = 8 * NT;                                       // float4 per staged row
+    constexpr int ROWS_PER_PASS = 64 / C4, PASSES = 32 / ROWS_PER_PASS;
+    const int c4 = lane % C4, rsub = lane / C4;
+    const int jcol = j0 + wcol + 4 * c4;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (P.bias && jcol < P.J) bias4 = *reinterpret_cast<const float4*>(P.bias + jcol);
 #pragma unroll
-    for (int b = 0; b < NT; ++b) {
-        const int j = j0 + wn * 64 + 32 * b + l31;
-        if (j >= P.J) continue;
-        const float bj = P.bias ? P.bias[j] : 0.f;
+    for (int a = 0; a < MT; ++a) {
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int a = 0; a < MT; ++a) {
+        for (int b = 0; b < NT; ++b)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int i = i0 + (NT == 2 ? wm * 64 : wm * 32) + 32 * a + (q & 3) + 8 * (q >> 2) + 4 * half;
-                if (i < P.I) {
-                    const long long row = (long long)(i / P.c_group) * P.c_gld + (long long)(i % P.c_group) * P.ldc;
-                    Cb[row + j] = acc[a][b][q] + bj;
-                }
+            for (int q = 0; q < 16; ++q) stage[((q & 3) + 8 * (q >> 2) + 4 * half) * PE + 32 * b + l31] = acc[a][b][q];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int rloc = rsub + ROWS_PER_PASS * ps;
+            const int i = i0 + wrow + 32 * a + rloc;
+            float4 v = *reinterpret_cast<const float4*>(stage + rloc * PE + 4 * c4);
+            if (i < P.I && jcol < P.J) {
+                v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
+                const long long row = (long long)(i / P.c_group) * P.c_gld + (long long)(i % P.c_group) * P.ldc;
+                *reinterpret_cast<float4*>(Cb + row + jcol) = v;
             }
         }
     }
@@ -3249,8 +3269,11 @@ int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_con
     long long rmax = 0;
     int jmax = 0;
     for (int k = 0; k < n; ++k) jmax = probs[k].J > jmax ? probs[k].J : jmax;
-    const bool narrow = jmax <= 32;                   // 128 x 32 tiles for outputs with at most 32 columns
-    const int BM = 128, BN = narrow ? 32 : 128;
+    int imax = 0;
+    for (int k = 0; k < n; ++k) imax = probs[k].I > imax ? probs[k].I : imax;
+    // 128 x 32 tiles for outputs with at most 32 columns, 32 x 128 for outputs with at most 32 rows, else 128 x 128
+    const int cfg = jmax <= 32 ? 1 : (imax <= 32 ? 2 : 0);
+    const int BM = cfg == 2 ? 32 : 128, BN = cfg == 1 ? 32 : 128;
     int tiles = 0;
     for (int k = 0; k < n; ++k) {
         const singa_gemm_t& q = probs[k];
@@ -3264,6 +3287,10 @@ int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_con
             ((uintptr_t)q.b & 15))
             return fail(SINGA_E_SHAPE, "gemm_f32: contiguous axes must be multiples of 4 floats and 16-byte aligned");
         if (b_r_contig && q.b_group > 0) return fail(SINGA_E_SHAPE, "gemm_f32: a reduction-contiguous B has plain rows");
+        // float4 stores of the result: J, the row pitches and the base must be multiples of 4 floats / 16 bytes
+        if (q.J % 4 || q.ldc % 4 || q.c_group_ld % 4 || q.c_split_stride % 4 || ((uintptr_t)q.c & 15) ||
+            (q.bias && ((uintptr_t)q.bias & 15)))
+            return fail(SINGA_E_SHAPE, "gemm_f32: the result's columns, pitches and base must be multiples of 4 floats / 16 bytes");
         if (splits > 1 && (q.c_group > 0 || q.ldc != q.J || q.bias || q.c_split_stride < (long long)q.I * q.J))
             return fail(SINGA_E_SHAPE, "gemm_f32: split reductions write dense [I, J] partial slabs (c_split_stride apart), no bias");
         P.A = q.a; P.B = q.b; P.C = q.c; P.bias = q.bias;
@@ -3288,10 +3315,11 @@ int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_con
     if (nblk > (1 << 30)) return fail(SINGA_E_SHAPE, "gemm_f32: too many tiles");
     const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define SINGA_GEMM_GO(tag, ARC, BRC)                                                                     \
-    do {                                                                                                 \
-        if (narrow) SINGA_LAUNCH(tag, 0, tiles, (gemm_f32_kernel<ARC, BRC, 1>), grid, block, st, gb);    \
-        else SINGA_LAUNCH(tag, 0, tiles, (gemm_f32_kernel<ARC, BRC, 2>), grid, block, st, gb);           \
+#define SINGA_GEMM_GO(tag, ARC, BRC)                                                                        \
+    do {                                                                                                    \
+        if (cfg == 1) SINGA_LAUNCH(tag, 0, tiles, (gemm_f32_kernel<ARC, BRC, 1>), grid, block, st, gb);     \
+        else if (cfg == 2) SINGA_LAUNCH(tag, 0, tiles, (gemm_f32_kernel<ARC, BRC, 2>), grid, block, st, gb); \
+        else SINGA_LAUNCH(tag, 0, tiles, (gemm_f32_kernel<ARC, BRC, 0>), grid, block, st, gb);              \
     } while (0)
     if (a_r_contig && b_r_contig) SINGA_GEMM_GO(SINGA_PROF_GEMM_NT, true, true);
     else if (a_r_contig) SINGA_GEMM_GO(SINGA_PROF_GEMM_NN, true, false);
