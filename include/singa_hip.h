@@ -284,6 +284,8 @@ typedef struct {
     int64_t c_split_stride;                       /* floats between the partial slabs of consecutive splits */
 } singa_gemm_t;
 int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_contig, int splits, void* stream);
+/* resident workgroups per CU of one kernel variant (cfg 0: 128x128, 1: 128x32, 2: 32x128 tiles), for the lab probes */
+int singa_gemm_occupancy(int a_r_contig, int b_r_contig, int cfg);
 
 /* Total 2-norm of all gradients over the same (tensor, chunk) table as singa_adam_step: torch.nn.utils.clip_grad_norm_'s
  * norm (reference train.py:126), deterministic and HIP-graph replayable.  partial: nchunks floats of scratch; out: 1 float. */

@@ -2565,7 +2565,7 @@ struct GemmProb {
 };
 struct GemmBatch {
     GemmProb p[SINGA_GEMM_MAX];
-    int n, tiles_total, splits;
+    int n, tiles_total, splits, tj_total;      // tj_total > 0: interleaved order (tiles_total = row tiles x column tiles of all problems)
     long long r_chunk;
 };
 
@@ -2600,13 +2600,18 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
     if (id >= nblk) return;
     const int split = id / gb.tiles_total;
     const int tile = id - split * gb.tiles_total;
+    // tiles are ordered row tile by row tile, and inside a row tile problem by problem: every XCD's contiguous range then
+    // holds the same mix of problems (their reduction lengths differ: problem-by-problem ranges left some XCDs with only
+    // the long ones and the launch waited for them)
+    // (problems with equal row counts only; otherwise problem after problem: tj_total = 0)
+    const int ti = gb.tj_total ? tile / gb.tj_total : 0, trem = gb.tj_total ? tile - ti * gb.tj_total : tile;
     int pi = 0;
 #pragma unroll
     for (int q = 1; q < SINGA_GEMM_MAX; ++q)
-        if (q < gb.n && tile >= gb.p[q].tile_begin) pi = q;
+        if (q < gb.n && trem >= gb.p[q].tile_begin) pi = q;
     const GemmProb& P = gb.p[pi];
-    const int local = tile - P.tile_begin;
-    const int i0 = (local / P.tiles_j) * BM, j0 = (local % P.tiles_j) * BN;
+    const int local = trem - P.tile_begin;
+    const int i0 = (gb.tj_total ? ti : local / P.tiles_j) * BM, j0 = (gb.tj_total ? local : local % P.tiles_j) * BN;
     const long long r_begin = (long long)split * gb.r_chunk;
     const long long r_end = (r_begin + gb.r_chunk < P.R) ? r_begin + gb.r_chunk : P.R;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2632,7 +2637,9 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
             brow[j] = jj < P.J ? P.B + (long long)jj * P.ldb + 4 * kq : nullptr;
         }
     }
-    float4 ra[NA], rb[NB];
+    // two register sets: the loads of K step s+2 are issued at the start of step s and written to LDS at the end of step
+    // s+1, so every load has two steps (~8,000 MFMA cycles) to arrive - one step did not cover an HBM miss under load
+    float4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
     auto load_rc = [&](float4* reg, const float* const* rows, int n, long long r0) {
         const bool in = r0 + 4 * kq < r_end;
 #pragma unroll
@@ -2664,19 +2671,15 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
 #pragma unroll
         for (int j = 0; j < n; ++j) *reinterpret_cast<float4*>(S + (rq + rows * j) * pitch + 4 * c4) = reg[j];
     };
-    auto load_a = [&](long long r0) {
+    auto load_ab = [&](float4* ra, float4* rb, long long r0) {
         if (A_RC) load_rc(ra, arow, NA, r0);
         else load_oc(ra, P.A, P.lda, P.a_group, P.a_gld, i0, P.I, NA, BM / 4, r0);
-    };
-    auto load_b = [&](long long r0) {
         if (B_RC) load_rc(rb, brow, NB, r0);
         else load_oc(rb, P.B, P.ldb, P.b_group, P.b_gld, j0, P.J, NB, BN / 4, r0);
     };
-    auto store_a = [&](int buf) {
+    auto store_ab = [&](const float4* ra, const float4* rb, int buf) {
         if (A_RC) store_rc(As0 + buf * SZA, ra, NA);
         else store_oc(As0 + buf * SZA, ra, LDA, NA, BM / 4);
-    };
-    auto store_b = [&](int buf) {
         if (B_RC) store_rc(Bs0 + buf * SZB, rb, NB);
         else store_oc(Bs0 + buf * SZB, rb, LDB, NB, BN / 4);
     };
@@ -2700,21 +2703,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const long long nsteps = r_end > r_begin ? (r_end - r_begin + BK - 1) / BK : 0;
-    if (nsteps > 0) {
-        load_a(r_begin);
-        load_b(r_begin);
-        store_a(0);
-        store_b(0);
-    }
-    __syncthreads();
-    for (long long st = 0; st < nsteps; ++st) {
-        const int buf = (int)(st & 1);
-        const bool more = st + 1 < nsteps;
-        if (more) {
-            load_a(r_begin + (st + 1) * BK);
-            load_b(r_begin + (st + 1) * BK);
-        }
+    auto compute = [&](int buf) {
         const float* Sa = As0 + buf * SZA;
         const float* Sb = Bs0 + buf * SZB;
         float fa[2][MT][4], fb[2][NT][4];
@@ -2739,10 +2728,26 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
                     for (int b = 0; b < NT; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][a][q], fb[cur][b][q], acc[a][b], 0, 0, 0);
         }
-        if (more) {
-            store_a(buf ^ 1);
-            store_b(buf ^ 1);
-        }
+    };
+
+    const long long nsteps = r_end > r_begin ? (r_end - r_begin + BK - 1) / BK : 0;
+    if (nsteps > 0) {
+        load_ab(ra0, rb0, r_begin);
+        if (nsteps > 1) load_ab(ra1, rb1, r_begin + BK);
+        store_ab(ra0, rb0, 0);
+    }
+    __syncthreads();
+    // step st computes LDS buffer st & 1; register set (st + 1) & 1 holds step st + 1 (written at the end of this step), the
+    // other set is free for step st + 2
+    for (long long st = 0; st < nsteps; st += 2) {
+        if (st + 2 < nsteps) load_ab(ra0, rb0, r_begin + (st + 2) * BK);
+        compute(0);
+        if (st + 1 < nsteps) store_ab(ra1, rb1, 1);
+        __syncthreads();
+        if (st + 1 >= nsteps) break;
+        if (st + 3 < nsteps) load_ab(ra1, rb1, r_begin + (st + 3) * BK);
+        compute(1);
+        if (st + 2 < nsteps) store_ab(ra0, rb0, 0);
         __syncthreads();
     }
     // ---- epilogue.  Accumulator register q of a 32 x 32 tile holds row (q & 3) + 8 (q >> 2) + 4 half, column lane & 31.
@@ -3258,6 +3263,17 @@ int singa_grad_norm(const float* const* g, const long long* sizes, const int32_t
     return check_launch("grad_norm");
 }
 
+int singa_gemm_occupancy(int a_r_contig, int b_r_contig, int cfg) {
+    int n = -1;
+    hipError_t e = hipErrorInvalidValue;
+#define SINGA_OCC(ARC, BRC, CFG) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_f32_kernel<ARC, BRC, CFG>, 256, 0)
+    if (a_r_contig && b_r_contig) { if (cfg == 0) SINGA_OCC(true, true, 0); else if (cfg == 1) SINGA_OCC(true, true, 1); else SINGA_OCC(true, true, 2); }
+    else if (a_r_contig) { if (cfg == 0) SINGA_OCC(true, false, 0); else if (cfg == 1) SINGA_OCC(true, false, 1); else SINGA_OCC(true, false, 2); }
+    else { if (cfg == 0) SINGA_OCC(false, false, 0); else if (cfg == 1) SINGA_OCC(false, false, 1); else SINGA_OCC(false, false, 2); }
+#undef SINGA_OCC
+    return e == hipSuccess ? n : -(int)e;
+}
+
 int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_contig, int splits, void* stream) {
     if (!probs || n < 1 || n > SINGA_GEMM_MAX) return fail(SINGA_E_SHAPE, "gemm_f32: 1..SINGA_GEMM_MAX problems per launch");
     if (splits < 1) return fail(SINGA_E_SHAPE, "gemm_f32: splits must be >= 1");
@@ -3274,7 +3290,9 @@ int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_con
     // 128 x 32 tiles for outputs with at most 32 columns, 32 x 128 for outputs with at most 32 rows, else 128 x 128
     const int cfg = jmax <= 32 ? 1 : (imax <= 32 ? 2 : 0);
     const int BM = cfg == 2 ? 32 : 128, BN = cfg == 1 ? 32 : 128;
-    int tiles = 0;
+    int tj_total = 0, ti_max = 0, tiles_seq = 0;
+    bool same_rows = true;
+    for (int k = 1; k < n; ++k) same_rows = same_rows && probs[k].I == probs[0].I;
     for (int k = 0; k < n; ++k) {
         const singa_gemm_t& q = probs[k];
         GemmProb& P = gb.p[k];
@@ -3304,12 +3322,18 @@ int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_con
         P.c_split = q.c_split_stride;
         P.I = q.I; P.J = q.J; P.R = q.R;
         P.tiles_j = (q.J + BN - 1) / BN;
-        P.tile_begin = tiles;
-        tiles += ((q.I + BM - 1) / BM) * P.tiles_j;
+        // interleaved order: first column tile of this problem inside a row tile's group; else: first tile of the problem
+        P.tile_begin = same_rows ? tj_total : tiles_seq;
+        tj_total += P.tiles_j;
+        const int ti = (q.I + BM - 1) / BM;
+        tiles_seq += ti * P.tiles_j;
+        if (ti > ti_max) ti_max = ti;
         if (q.R > rmax) rmax = q.R;
     }
+    const int tiles = same_rows ? ti_max * tj_total : tiles_seq;
     if (tiles == 0) return SINGA_OK;
     gb.tiles_total = tiles;
+    gb.tj_total = same_rows ? tj_total : 0;
     gb.r_chunk = splits > 1 ? ((rmax + splits - 1) / splits + 31) / 32 * 32 : (rmax > 0 ? rmax : 1);
     const long long nblk = (long long)tiles * splits;
     if (nblk > (1 << 30)) return fail(SINGA_E_SHAPE, "gemm_f32: too many tiles");

@@ -949,6 +949,7 @@ class _Linear(torch.autograd.Function):
 
 # ---------------------------------------------------------------------------------------- k7 / k11: own f32 MFMA GEMM
 USE_OWN_GEMM = _os.environ.get("SINGA_GEMM", "own") == "own"      # "lib": the library GEMMs (kept as the tests' cross-check)
+USE_OWN_SO3 = _os.environ.get("SINGA_SO3_GEMM", "own") == "own"
 _GEMM_SPLIT_ROWS = int(_os.environ.get("SINGA_GEMM_SPLIT_ROWS", "2048"))
 
 
@@ -1179,7 +1180,7 @@ class _SO3LinearLib(torch.autograd.Function):
 
 
 def so3_linear(x, weight, bias, L):
-    return (_SO3Linear if USE_OWN_GEMM else _SO3LinearLib).apply(x, weight, bias, L)
+    return (_SO3Linear if (USE_OWN_GEMM and USE_OWN_SO3) else _SO3LinearLib).apply(x, weight, bias, L)
 
 
 class _GroupedLinear(torch.autograd.Function):
