@@ -230,43 +230,74 @@ __global__ void __launch_bounds__(64) gather_rotate_kernel(const float* __restri
     }
 }
 
-// Backward of gather+rotate w.r.t. the node tensors: one wavefront per node, lanes 0..C-1 = channel.
+// Backward of gather+rotate w.r.t. the node tensors.  A wavefront takes FOUR nodes: lane group q = lane / 16 walks the edge
+// segment of node 4 w + q, lane % 16 = channel, so all 64 lanes work (the first version gave a whole wavefront to one node
+// and kept 16 of its 64 lanes busy: 0.12 of the HBM roofline).  The four groups are on four different edges, so the Wigner
+// record is no longer wave-uniform: every lane reads its edge's record itself, 16 bytes at a time (the 16 lanes of a group
+// read the same addresses - one L1 transaction), instead of the readlane broadcasts of the edge-parallel kernels.
 // SIDE 0: destination nodes, edges row_ptr[n]..row_ptr[n+1] (already contiguous).  SIDE 1: source nodes, edge ids
 // eperm[col_ptr[n]..col_ptr[n+1]].  gx[n, l^2+j, c] = sum_e sum_r W_e[r][j] * g_out[e, r, side*C + c] * rad[e, r, ..].
+// The record of the last edge is read up to 3 floats past its end: the caller allocates the Wigner rows with 4 floats of
+// slack (ops.wigner_rows).
+struct __attribute__((aligned(4))) F4U {
+    float v[4];
+};
 template <int L, int M, int C, int SIDE>
-__global__ void __launch_bounds__(64) gather_rotate_bwd_node_kernel(const float* __restrict__ g_out, const float* __restrict__ wr,
+__global__ void __launch_bounds__(256) gather_rotate_bwd_node_kernel(const float* __restrict__ g_out, const float* __restrict__ wr,
                                               const float* __restrict__ rad, const int* __restrict__ ptr,
                                               const int* __restrict__ eperm, float* __restrict__ gx, int N) {
     using I = SO3Idx<L, M>;
-    const int lane = threadIdx.x;
-    const bool act = lane < C;
-    const int co = SIDE == 0 ? C + (lane & (C - 1)) : (lane & (C - 1));  // dst half of the 2C channels is [C, 2C)
-    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    static_assert(C == 16, "lane group = 16 channels");
+    const int lane = threadIdx.x & 63, grp = lane >> 4, c = lane & 15;
+    const int co = SIDE == 0 ? C + c : c;                             // dst half of the 2C channels is [C, 2C)
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = gridDim.x * (blockDim.x >> 6);
+    for (int n0 = wave * 4; n0 < N; n0 += nwaves * 4) {
+        const int n = n0 + grp;
         float acc[I::K];
 #pragma unroll
         for (int k = 0; k < I::K; ++k) acc[k] = 0.f;
-        const int beg = ptr[n], end = ptr[n + 1];
-        for (int i = beg; i < end; ++i) {
-            const int e = SIDE == 0 ? i : eperm[i];
-            WRows<I::WSZ> W;
-            W.load(wr + (long long)e * I::WSZ, lane);
+        const int beg = n < N ? ptr[n] : 0, end = n < N ? ptr[n + 1] : 0;
+        int len = 0;                                                   // longest of the wavefront's four segments
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int nq = n0 + q;
+            const int lq = nq < N ? ptr[nq + 1] - ptr[nq] : 0;
+            len = lq > len ? lq : len;
+        }
+        for (int i = 0; i < len; ++i) {
+            const bool on = beg + i < end;
+            const int slot = on ? beg + i : (end > beg ? end - 1 : 0);  // an idle group re-reads a valid edge with weight 0
+            const int e = (end > beg) ? (SIDE == 0 ? slot : eperm[slot]) : 0;
+            const float live = on ? 1.f : 0.f;
+            const float* wp = wr + (long long)e * I::WSZ;
             const long long eo = (long long)e * I::KR * 2 * C + co;
             const long long ro = (long long)e * I::RAD_ROWS * 2 * C + co;
 #pragma unroll
             for (int l = 0; l <= L; ++l) {
+                // this degree's block of the record, [w_off(l), w_off(l+1)), fetched as the float4 chunks that cover it
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int lo4 = I::w_off(l) / 4, hi4 = (I::w_off(l + 1) + 3) / 4;
+                float w[(2 * L + 1) * (2 * M + 1) + 6];
+#pragma unroll
+                for (int q = lo4; q < hi4; ++q) {
+                    const F4U t = *reinterpret_cast<const F4U*>(wp + 4 * q);
+                    w[4 * (q - lo4)] = t.v[0]; w[4 * (q - lo4) + 1] = t.v[1]; w[4 * (q - lo4) + 2] = t.v[2]; w[4 * (q - lo4) + 3] = t.v[3];
+                }
+                const int sh = I::w_off(l) - 4 * lo4;
 #pragma unroll
                 for (int mi = 0; mi < I::nr(l); ++mi) {
                     const int m = mi - I::mm(l);
-                    float g = g_out[eo + I::mpos(l, m) * 2 * C];
+                    float g = g_out[eo + I::mpos(l, m) * 2 * C] * live;
                     if (rad) g *= rad[ro + I::rad_row(l, m) * 2 * C];
 #pragma unroll
                     for (int j = 0; j < 2 * l + 1; ++j)
-                        acc[l * l + j] = fmaf(W_AT(W, I::w_off(l) + mi * (2 * l + 1) + j), g, acc[l * l + j]);
+                        acc[l * l + j] = fmaf(w[sh + mi * (2 * l + 1) + j], g, acc[l * l + j]);
                 }
             }
         }
-        if (act) {
-            float* o = gx + (long long)n * I::K * C + lane;
+        if (n < N) {
+            float* o = gx + (long long)n * I::K * C + c;
 #pragma unroll
             for (int k = 0; k < I::K; ++k) o[k * C] = acc[k];
         }
@@ -2958,11 +2989,11 @@ int singa_gather_rotate_bwd(const float* g_out, const float* x_src, const float*
             SINGA_LAUNCH(SINGA_PROF_K4_BWD_RAD, E, 0, (gather_rotate_kernel<L_, 2, 16, 1>), dim3(grid_for(E)), dim3(64), st,
                          x_src, x_dst, src, dst, wr, rad, g_out, g_rad, E);
         if (Nd > 0)
-            SINGA_LAUNCH(SINGA_PROF_K4_BWD_DST, E, Nd, (gather_rotate_bwd_node_kernel<L_, 2, 16, 0>), dim3(grid_for(Nd)),
-                         dim3(64), st, g_out, wr, rad, row_ptr, (const int*)nullptr, gx_dst, Nd);
+            SINGA_LAUNCH(SINGA_PROF_K4_BWD_DST, E, Nd, (gather_rotate_bwd_node_kernel<L_, 2, 16, 0>), dim3(grid_for((Nd + 15) / 16)),
+                         dim3(256), st, g_out, wr, rad, row_ptr, (const int*)nullptr, gx_dst, Nd);
         if (Ns > 0)
-            SINGA_LAUNCH(SINGA_PROF_K4_BWD_SRC, E, Ns, (gather_rotate_bwd_node_kernel<L_, 2, 16, 1>), dim3(grid_for(Ns)),
-                         dim3(64), st, g_out, wr, rad, col_ptr, eperm, gx_src, Ns);
+            SINGA_LAUNCH(SINGA_PROF_K4_BWD_SRC, E, Ns, (gather_rotate_bwd_node_kernel<L_, 2, 16, 1>), dim3(grid_for((Ns + 15) / 16)),
+                         dim3(256), st, g_out, wr, rad, col_ptr, eperm, gx_src, Ns);
     });
     return check_launch("gather_rotate_bwd");
 }

@@ -130,6 +130,17 @@ def load_npz(path, with_lap=True):
     return from_arrays({k: z[k] for k in z.files}, with_lap)
 
 
+EXAMPLE_NAMES = ("3wi2_4tpp", "4agq_5a7b", "5cp5_4nue")
+
+
+def example_graph(i, with_lap=True):
+    """The i-th (mod 3) of the three protein-ligand graphs the reference bundles (example/*.pt), shipped as plain arrays
+    under singa_amd/data/examples (what `train.py --data golden` trains on)."""
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    return load_npz(os.path.join(here, "data", "examples", f"graph_{EXAMPLE_NAMES[i % 3]}.npz"), with_lap)
+
+
 # ----------------------------------------------------------------------------------------------- synthetic graphs
 def _closest_pairs(pa, pb, count, same):
     d = np.linalg.norm(pa[:, None, :] - pb[None, :, :], axis=-1)

@@ -94,7 +94,8 @@ def wigner_rows(rot, L, M=2):
     _dev(rot)
     lay = so3.layout(L, M)
     E = rot.shape[0]
-    wr = torch.empty(E, lay.WSZ, device=rot.device, dtype=torch.float32)
+    # 4 floats of slack behind the last record: the node-gradient kernel of k4 reads records 16 bytes at a time
+    wr = torch.zeros(E * lay.WSZ + 4, device=rot.device, dtype=torch.float32)[:E * lay.WSZ].view(E, lay.WSZ)
     _chk(_lib.lib().singa_wigner_rows(_p(rot), _p(wr), E, L, M, _stream()), "singa_wigner_rows")
     return wr
 
@@ -270,6 +271,19 @@ class _SegmentWSum(torch.autograd.Function):
         _chk(_lib.lib().singa_segment_wsum_bwd(_p(g), _p(w), _p(v), _p(row_ptr), _p(gw), _p(gv), N, H, F, _stream()),
              "singa_segment_wsum_bwd")
         return gw, gv, None
+
+
+def segment_sum_rows(v, row_ptr):
+    """out[n, :] = sum of the rows v[row_ptr[n] : row_ptr[n+1], :] (no gradient; rows sorted by segment): the segmented
+    sum kernel with unit weights, no atomics."""
+    v = v.detach()
+    _dev(v, row_ptr)
+    E, F = v.shape
+    N = row_ptr.numel() - 1
+    out = torch.empty(N, 1, F, device=v.device, dtype=torch.float32)
+    w = torch.ones(max(E, 1), 1, device=v.device, dtype=torch.float32)
+    _chk(_lib.lib().singa_segment_wsum_fwd(_p(w), _p(v), _p(row_ptr), _p(out), N, 1, F, _stream()), "singa_segment_wsum_fwd")
+    return out.view(N, F)
 
 
 def segment_wsum(w, v, row_ptr):

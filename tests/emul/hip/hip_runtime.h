@@ -44,6 +44,16 @@ static inline hipError_t hipMemcpyToSymbol(T& sym, const void* src, size_t n, si
 static inline float __frcp_rn(float x) { return 1.0f / x; }
 #define __logf(x) logf(x)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+enum { hipErrorInvalidValue = 1 };
+template <class K>
+static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K, int, int) {
+    *n = 0;
+    return hipSuccess;
+}
+static inline int __shfl_xor(int, int, int) {
+    fprintf(stderr, "emul: cross-lane kernel cannot be emulated sequentially\n");
+    abort();
+}
 static inline float __shfl_xor(float, int, int) {
     fprintf(stderr, "emul: cross-lane kernel cannot be emulated sequentially\n");
     abort();

@@ -27,8 +27,8 @@ def test_train_eager_graph_and_resume(tmp_path):
     eager = _losses(_run(["--max-iters", "4"], str(tmp_path / "a")))
     assert len(eager) == 4 and eager[-1] < eager[0]
     graph = _losses(_run(["--max-iters", "2", "--graph"], str(tmp_path / "b")))
-    # graph capture spends two real warm-up steps first: its first logged loss is the eager run's third
-    assert abs(graph[0] - eager[2]) < 1e-3 * eager[2]
+    # the capture's warm-up steps leave the training state untouched: replayed step i = eager step i
+    assert all(abs(g - e) < 1e-3 * e for g, e in zip(graph, eager[:2])), (graph, eager)
     ck = glob.glob(str(tmp_path / "a" / "*" / "checkpoints" / "4.pt"))
     assert ck, "checkpoint of the last iteration missing"
     resumed = _losses(_run(["--max-iters", "5", "--resume", ck[0]], str(tmp_path / "c")))

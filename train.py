@@ -5,7 +5,7 @@ validation every `val_freq` iterations with early stopping, checkpoints {'config
 'iteration'}.  The step itself runs through singa_amd.engine.TrainStep (HIP kernels + HIP-graph replay).
 
 The CrossDocked dataset and the RDKit/ODDT featurisation of the reference are out of scope, so graphs
-come from `--data golden` (the three bundled example graphs, tests/golden/graph_*.npz) or `--data synthetic`
+come from `--data golden` (the three example graphs the reference bundles, shipped under singa_amd/data/examples) or `--data synthetic`
 (singa_amd.graph.synthetic_graph).  Under `torch.distributed.run` every rank trains on its own shard of each batch and
 gradients are averaged with RCCL (singa_amd.dp).
 
@@ -94,13 +94,13 @@ def main():
     log = (lambda m: logger.info(m)) if rank == 0 else (lambda m: None)
 
     batch_size = args.batch_size or cfg.train.batch_size
-    lo, hi = dp.shard_range(batch_size, rank, world)
+    lo, hi = dp.shard_range(batch_size, rank, world)     # equal-sized shards when world divides batch_size
 
     def make_batch(split, it):
         """One batch of `batch_size` graphs; this rank materialises only its shard [lo, hi)."""
         if args.data == "golden":
-            names = ["3wi2_4tpp", "4agq_5a7b", "5cp5_4nue"]
-            gs = [G.load_npz(os.path.join(ROOT, "tests", "golden", f"graph_{names[i % 3]}.npz")) for i in range(lo, hi)]
+            # the three example graphs the reference bundles (example/*.pt), shipped with the package as plain arrays
+            gs = [G.example_graph(i) for i in range(lo, hi)]
         else:
             base = {"train": 0, "val": 10_000_000, "test": 20_000_000}[split] + it * batch_size
             gs = [G.synthetic_graph(base + i) for i in range(lo, hi)]
@@ -123,6 +123,7 @@ def main():
     reducer = dp.GradAllReducer(model) if world > 1 else None
     if reducer:
         reducer.check_same_init()
+        reducer.set_shard_weight(hi - lo, batch_size)        # token-weighted combination: exact for unequal shards too
     engine = TrainStep(model, opt, reducer, use_graph=args.graph, max_grad_norm=float(cfg.train.max_grad_norm))
     early = EarlyStopping(patience=20, delta=0.00005)
 
@@ -154,6 +155,7 @@ def main():
         if it < max_iters:
             nxt = engine.prefetch(lambda: make_batch("train", it + 1))
         loss_v = float(loss.detach())
+        engine.check()                      # the reference's edge-frame guards for frames built inside replayed graphs
         log(f"[Train] Iter {it} | Loss {loss_v:.6f} | Grad {float(engine.grad_norm):.4f} | "
             f"LR {opt.param_groups[0]['lr']:.2e} | {time.perf_counter() - t0:.3f} s")
         if it % cfg.train.val_freq == 0 or it == max_iters:
