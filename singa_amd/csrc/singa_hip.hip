@@ -237,9 +237,8 @@ __global__ void __launch_bounds__(64) gather_rotate_kernel(const float* __restri
 // read the same addresses - one L1 transaction), instead of the readlane broadcasts of the edge-parallel kernels.
 // SIDE 0: destination nodes, edges row_ptr[n]..row_ptr[n+1] (already contiguous).  SIDE 1: source nodes, edge ids
 // eperm[col_ptr[n]..col_ptr[n+1]].  gx[n, l^2+j, c] = sum_e sum_r W_e[r][j] * g_out[e, r, side*C + c] * rad[e, r, ..].
-// The record of the last edge is read up to 3 floats past its end: the caller allocates the Wigner rows with 4 floats of
-// slack (ops.wigner_rows).
-struct __attribute__((aligned(4))) F4U {
+// Records are WSZ floats long, WSZ a multiple of 4 (so3_index.h): every float4 load is aligned and stays inside the record.
+struct __attribute__((aligned(16))) F4U {
     float v[4];
 };
 template <int L, int M, int C, int SIDE>
@@ -2770,6 +2769,21 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
     __syncthreads();
     // step st computes LDS buffer st & 1; register set (st + 1) & 1 holds step st + 1 (written at the end of this step), the
     // other set is free for step st + 2
+#if defined(SINGA_GEMM_LAB_NOLOAD) || defined(SINGA_GEMM_LAB_NOSYNC)   // tools/lab only: which part of a step costs what
+    for (long long st = 0; st < nsteps; st += 2) {
+        compute(0);
+#ifndef SINGA_GEMM_LAB_NOSYNC
+        if (st + 1 < nsteps) store_ab(ra1, rb1, 1);
+        __syncthreads();
+#endif
+        if (st + 1 >= nsteps) break;
+        compute(1);
+#ifndef SINGA_GEMM_LAB_NOSYNC
+        if (st + 2 < nsteps) store_ab(ra0, rb0, 0);
+        __syncthreads();
+#endif
+    }
+#else
     for (long long st = 0; st < nsteps; st += 2) {
         if (st + 2 < nsteps) load_ab(ra0, rb0, r_begin + (st + 2) * BK);
         compute(0);
@@ -2781,6 +2795,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
         if (st + 2 < nsteps) store_ab(ra0, rb0, 0);
         __syncthreads();
     }
+#endif
     // ---- epilogue.  Accumulator register q of a 32 x 32 tile holds row (q & 3) + 8 (q >> 2) + 4 half, column lane & 31.
     // Every wavefront owns 32 x PE floats of LDS (all K-loop reads are behind the barrier above); one 32-row block at a time:
     // registers -> [row][col] image -> float4 rows -> global, bias added on the way.

@@ -19,7 +19,10 @@ struct SO3Idx {
         for (int i = 0; i < l; ++i) s += nr(i) * (2 * i + 1);
         return s;
     }
-    static constexpr int WSZ = w_off(L + 1);
+    // record length in floats, rounded up to a multiple of 4 so that every edge's record starts 16-byte aligned (the
+    // node-gradient kernel of k4 reads records with float4 loads; unaligned dwordx4 loads were 1.5x slower than the
+    // scalar version they replaced)
+    static constexpr int WSZ = (w_off(L + 1) + 3) / 4 * 4;
     static constexpr int msize(int m) { return L - m + 1; }
     static constexpr int m_off(int m) {  // first m-primary row of order +m
         if (m == 0) return 0;

