@@ -183,7 +183,7 @@ __global__ void wigner_rows_kernel(const float* __restrict__ rot, float* __restr
 // ------------------------------------------------------------------------------------------------ k3-k6: gather+rotate
 // One wavefront per edge (grid-stride).  Lanes 0..2C-1: channel c of [x_src | x_dst].  MODE 0: forward (out = rotated *
 // rad).  MODE 1: backward w.r.t. rad (g_rad = sum over the +-m rows of g_out * rotated).
-template <int L, int M, int C, int MODE>
+template <int L, int M, int C, int MODE, bool RAD>
 __global__ void __launch_bounds__(64) gather_rotate_kernel(const float* __restrict__ x_src, const float* __restrict__ x_dst,
                                      const int* __restrict__ src, const int* __restrict__ dst,
                                      const float* __restrict__ wr, const float* __restrict__ rad,
@@ -199,33 +199,41 @@ __global__ void __launch_bounds__(64) gather_rotate_kernel(const float* __restri
         const float* xin = (ln < C ? x_src : x_dst) + (long long)node * I::K * C + (ln & (C - 1));
         const long long eo = (long long)e * I::KR * 2 * C + ln;
         const long long ro = (long long)e * I::RAD_ROWS * 2 * C + ln;
-        float gr[I::RAD_ROWS];
+        // every load of the edge is issued before the first use: the node rows (K of them), the radial weights (forward)
+        // or the incoming gradient rows (MODE 1).  RAD is a template flag - a run-time `rad ? .. : 1` per row made the
+        // compiler interleave load / wait / branch row by row (148 waits for 47 loads: 0.38 of the HBM roofline).
+        float xv[I::K], rv[I::RAD_ROWS], gv[MODE == 1 ? I::KR : 1];
+#pragma unroll
+        for (int k = 0; k < I::K; ++k) xv[k] = xin[k * C];
+        if (MODE == 0 && RAD) {
+#pragma unroll
+            for (int i = 0; i < I::RAD_ROWS; ++i) rv[i] = rad[ro + i * 2 * C];
+        }
         if (MODE == 1) {
 #pragma unroll
-            for (int i = 0; i < I::RAD_ROWS; ++i) gr[i] = 0.f;
+            for (int r = 0; r < I::KR; ++r) gv[r] = g_out[eo + r * 2 * C];
+#pragma unroll
+            for (int i = 0; i < I::RAD_ROWS; ++i) rv[i] = 0.f;
         }
 #pragma unroll
         for (int l = 0; l <= L; ++l) {
-            float xv[2 * L + 1];
-#pragma unroll
-            for (int j = 0; j < 2 * l + 1; ++j) xv[j] = xin[(l * l + j) * C];
 #pragma unroll
             for (int mi = 0; mi < I::nr(l); ++mi) {
                 const int m = mi - I::mm(l);
                 float acc = 0.f;
 #pragma unroll
-                for (int j = 0; j < 2 * l + 1; ++j) acc = fmaf(W_AT(W, I::w_off(l) + mi * (2 * l + 1) + j), xv[j], acc);
+                for (int j = 0; j < 2 * l + 1; ++j) acc = fmaf(W_AT(W, I::w_off(l) + mi * (2 * l + 1) + j), xv[l * l + j], acc);
                 if (MODE == 0) {
-                    float rv = rad ? rad[ro + I::rad_row(l, m) * 2 * C] : 1.f;
-                    if (act) out[eo + I::mpos(l, m) * 2 * C] = acc * rv;
+                    if (RAD) acc *= rv[I::rad_row(l, m)];
+                    if (act) out[eo + I::mpos(l, m) * 2 * C] = acc;
                 } else {
-                    gr[I::rad_row(l, m)] = fmaf(g_out[eo + I::mpos(l, m) * 2 * C], acc, gr[I::rad_row(l, m)]);
+                    rv[I::rad_row(l, m)] = fmaf(gv[I::mpos(l, m)], acc, rv[I::rad_row(l, m)]);
                 }
             }
         }
         if (MODE == 1 && act) {
 #pragma unroll
-            for (int i = 0; i < I::RAD_ROWS; ++i) out[ro + i * 2 * C] = gr[i];
+            for (int i = 0; i < I::RAD_ROWS; ++i) out[ro + i * 2 * C] = rv[i];
         }
     }
 }
@@ -241,7 +249,7 @@ __global__ void __launch_bounds__(64) gather_rotate_kernel(const float* __restri
 struct __attribute__((aligned(16))) F4U {
     float v[4];
 };
-template <int L, int M, int C, int SIDE>
+template <int L, int M, int C, int SIDE, bool RAD>
 __global__ void __launch_bounds__(256) gather_rotate_bwd_node_kernel(const float* __restrict__ g_out, const float* __restrict__ wr,
                                               const float* __restrict__ rad, const int* __restrict__ ptr,
                                               const int* __restrict__ eperm, float* __restrict__ gx, int N) {
@@ -284,14 +292,20 @@ __global__ void __launch_bounds__(256) gather_rotate_bwd_node_kernel(const float
                     w[4 * (q - lo4)] = t.v[0]; w[4 * (q - lo4) + 1] = t.v[1]; w[4 * (q - lo4) + 2] = t.v[2]; w[4 * (q - lo4) + 3] = t.v[3];
                 }
                 const int sh = I::w_off(l) - 4 * lo4;
+                // all loads of the block first (RAD is a template flag: a run-time `if (rad)` per row made the compiler
+                // serialise the row loads - load, wait, branch, load, wait: ~40 memory round trips per edge)
+                float gv[2 * M + 1];
 #pragma unroll
                 for (int mi = 0; mi < I::nr(l); ++mi) {
                     const int m = mi - I::mm(l);
-                    float g = g_out[eo + I::mpos(l, m) * 2 * C] * live;
-                    if (rad) g *= rad[ro + I::rad_row(l, m) * 2 * C];
+                    gv[mi] = g_out[eo + I::mpos(l, m) * 2 * C] * live;
+                    if (RAD) gv[mi] *= rad[ro + I::rad_row(l, m) * 2 * C];
+                }
+#pragma unroll
+                for (int mi = 0; mi < I::nr(l); ++mi) {
 #pragma unroll
                     for (int j = 0; j < 2 * l + 1; ++j)
-                        acc[l * l + j] = fmaf(w[sh + mi * (2 * l + 1) + j], g, acc[l * l + j]);
+                        acc[l * l + j] = fmaf(w[sh + mi * (2 * l + 1) + j], gv[mi], acc[l * l + j]);
                 }
             }
         }
@@ -2984,8 +2998,12 @@ int singa_gather_rotate_fwd(const float* x_src, const float* x_dst, const int32_
     if (C != 16) return fail(SINGA_E_SHAPE, "gather_rotate: built for C = 16 sphere channels");
     if (E <= 0) return SINGA_OK;
     SINGA_DISPATCH_L(lmax, mmax, {
-        SINGA_LAUNCH(SINGA_PROF_K4_FWD, E, 0, (gather_rotate_kernel<L_, 2, 16, 0>), dim3(grid_for(E)), dim3(64),
-                     (hipStream_t)stream, x_src, x_dst, src, dst, wr, rad, (const float*)nullptr, out, E);
+        if (rad)
+            SINGA_LAUNCH(SINGA_PROF_K4_FWD, E, 0, (gather_rotate_kernel<L_, 2, 16, 0, true>), dim3(grid_for(E)), dim3(64),
+                         (hipStream_t)stream, x_src, x_dst, src, dst, wr, rad, (const float*)nullptr, out, E);
+        else
+            SINGA_LAUNCH(SINGA_PROF_K4_FWD, E, 0, (gather_rotate_kernel<L_, 2, 16, 0, false>), dim3(grid_for(E)), dim3(64),
+                         (hipStream_t)stream, x_src, x_dst, src, dst, wr, rad, (const float*)nullptr, out, E);
     });
     return check_launch("gather_rotate_fwd");
 }
@@ -3001,14 +3019,24 @@ int singa_gather_rotate_bwd(const float* g_out, const float* x_src, const float*
     SINGA_DISPATCH_L(lmax, mmax, {
         hipStream_t st = (hipStream_t)stream;
         if (g_rad && E > 0)
-            SINGA_LAUNCH(SINGA_PROF_K4_BWD_RAD, E, 0, (gather_rotate_kernel<L_, 2, 16, 1>), dim3(grid_for(E)), dim3(64), st,
+            SINGA_LAUNCH(SINGA_PROF_K4_BWD_RAD, E, 0, (gather_rotate_kernel<L_, 2, 16, 1, true>), dim3(grid_for(E)), dim3(64), st,
                          x_src, x_dst, src, dst, wr, rad, g_out, g_rad, E);
-        if (Nd > 0)
-            SINGA_LAUNCH(SINGA_PROF_K4_BWD_DST, E, Nd, (gather_rotate_bwd_node_kernel<L_, 2, 16, 0>), dim3(grid_for((Nd + 15) / 16)),
-                         dim3(256), st, g_out, wr, rad, row_ptr, (const int*)nullptr, gx_dst, Nd);
-        if (Ns > 0)
-            SINGA_LAUNCH(SINGA_PROF_K4_BWD_SRC, E, Ns, (gather_rotate_bwd_node_kernel<L_, 2, 16, 1>), dim3(grid_for((Ns + 15) / 16)),
-                         dim3(256), st, g_out, wr, rad, col_ptr, eperm, gx_src, Ns);
+        if (Nd > 0) {
+            if (rad)
+                SINGA_LAUNCH(SINGA_PROF_K4_BWD_DST, E, Nd, (gather_rotate_bwd_node_kernel<L_, 2, 16, 0, true>),
+                             dim3(grid_for((Nd + 15) / 16)), dim3(256), st, g_out, wr, rad, row_ptr, (const int*)nullptr, gx_dst, Nd);
+            else
+                SINGA_LAUNCH(SINGA_PROF_K4_BWD_DST, E, Nd, (gather_rotate_bwd_node_kernel<L_, 2, 16, 0, false>),
+                             dim3(grid_for((Nd + 15) / 16)), dim3(256), st, g_out, wr, rad, row_ptr, (const int*)nullptr, gx_dst, Nd);
+        }
+        if (Ns > 0) {
+            if (rad)
+                SINGA_LAUNCH(SINGA_PROF_K4_BWD_SRC, E, Ns, (gather_rotate_bwd_node_kernel<L_, 2, 16, 1, true>),
+                             dim3(grid_for((Ns + 15) / 16)), dim3(256), st, g_out, wr, rad, col_ptr, eperm, gx_src, Ns);
+            else
+                SINGA_LAUNCH(SINGA_PROF_K4_BWD_SRC, E, Ns, (gather_rotate_bwd_node_kernel<L_, 2, 16, 1, false>),
+                             dim3(grid_for((Ns + 15) / 16)), dim3(256), st, g_out, wr, rad, col_ptr, eperm, gx_src, Ns);
+        }
     });
     return check_launch("gather_rotate_bwd");
 }

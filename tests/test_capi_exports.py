@@ -46,7 +46,7 @@ def test_argument_errors_without_gpu(built_lib):
     assert lib.singa_wigner_rows(None, None, 4, 6, 2, None) == -1            # SINGA_E_NULL
     kr, wsz, rr = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     assert lib.singa_dims(6, 2, ctypes.byref(kr), ctypes.byref(wsz), ctypes.byref(rr)) == 0
-    assert (kr.value, wsz.value, rr.value) == (29, 235, 18)
+    assert (kr.value, wsz.value, rr.value) == (29, 236, 18)      # 235 Wigner entries, padded to 16-byte records
     assert lib.singa_dims(5, 2, None, None, None) == -2                      # SINGA_E_LMAX (built for 2, 4, 6)
     assert b"lmax" in lib.singa_last_error_string()
 

@@ -61,7 +61,8 @@ def reduced_rows(w, L, M=2):
     for l in range(L + 1):
         mm = min(l, M)
         out.append(w[:, l * l + l - mm: l * l + l + mm + 1, l * l:(l + 1) ** 2].reshape(w.shape[0], -1))
-    return torch.cat(out, 1)
+    out = torch.cat(out, 1)
+    return torch.nn.functional.pad(out, (0, -out.shape[1] % 4))       # records are padded to 16 bytes (so3_index.h), pad = 0
 
 
 def rad_row_index(lay):

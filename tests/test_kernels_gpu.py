@@ -35,7 +35,8 @@ def reduced_rows(w, L, M=2):
     for l in range(L + 1):
         mm = min(l, M)
         out.append(w[:, l * l + l - mm: l * l + l + mm + 1, l * l:(l + 1) ** 2].reshape(w.shape[0], -1))
-    return torch.cat(out, 1)
+    out = torch.cat(out, 1)
+    return torch.nn.functional.pad(out, (0, -out.shape[1] % 4))       # records are padded to 16 bytes (so3_index.h), pad = 0
 
 
 def rad_row_index(lay):
@@ -61,6 +62,7 @@ def test_wigner_rows(L):
     rot = rand_rot(rs, 1000)
     wr = ops.wigner_rows(rot.to(DEV), L)
     ref = reduced_rows(O.wigner_dense(rot, L), L)
+    assert wr.shape == ref.shape and wr.shape[1] % 4 == 0     # records padded to a multiple of 4 floats, pad = 0
     assert float((wr.cpu() - ref).abs().max()) < 3e-5
     # orthogonality of full blocks l <= 2: rows of D_l are orthonormal
     blk = wr[:, 1:10].view(-1, 3, 3)
