@@ -7,8 +7,11 @@ the bench workload).  Shapes are static per capture; a batch with different size
 
 Multi-GPU: forward+backward replay -> bucketed RCCL all-reduce (singa_amd.dp, eager) -> optimizer replay.
 """
+import math
+
 import torch
 
+from . import graph as G
 from .graph import E_LL, E_LP, E_PL, E_PP, LA, PA
 from .model import EF_layers
 
@@ -79,7 +82,13 @@ def _prep_tensors(prep):
 
 
 class TrainStep:
-    def __init__(self, model, optimizer, reducer=None, use_graph=True, max_grad_norm=float("inf")):
+    """bucket=True (graph mode): ragged batches - every real CrossDocked batch has its own atom and edge counts - are
+    padded with inert atoms / edges (graph.pad_batch) to the capacities of a geometric size class (x `growth` per class),
+    so that all batches of a class replay ONE capture; a few captures (`max_cached`, least recently used evicted) are
+    kept side by side.  Without it a batch whose shapes differ from the capture triggers a re-capture."""
+
+    def __init__(self, model, optimizer, reducer=None, use_graph=True, max_grad_norm=float("inf"), bucket=False,
+                 growth=1.08, max_cached=3):
         self.model, self.opt, self.reducer = model, optimizer, reducer
         self.use_graph, self.max_grad_norm = use_graph, max_grad_norm
         self.crit = torch.nn.CrossEntropyLoss()
@@ -87,6 +96,58 @@ class TrainStep:
         self.g_fb = self.g_opt = None
         self.captures = 0
         self._aux = None
+        self.bucket, self.growth, self.max_cached = bucket and use_graph, growth, max_cached
+        self._base = None                  # sizes of the first batch: the size classes are multiples of these
+        self._mx = {PA: 0, LA: 0}          # widest graph seen so far per node type (dense-layout width, only grows)
+        self._knn_cap = {}                 # (class, node type) -> kNN edge capacity
+        self._slots = {}                   # signature -> captured state (insertion order = recency)
+        self._active = None
+
+    # ------------------------------------------------------------------------------------------------ size classes
+    def _class_caps(self, sizes):
+        if self._base is None:
+            self._base = tuple(max(1, v) for v in sizes)
+        r = max(v / b for v, b in zip(sizes, self._base))
+        c = int(math.ceil(math.log(r) / math.log(self.growth) - 1e-9))
+        scale = self.growth ** c
+        up = lambda v, g: -(-int(math.ceil(v)) // g) * g
+        n_p, n_l, e_pp, e_ll, e_x = (b * scale for b in self._base)
+        # at least 64 padding atoms per type: the padding edges are spread over them (no heavy segment)
+        return c, (up(n_p + 64, 64), up(n_l + 64, 64), up(e_pp, 256), up(e_ll, 256), up(e_x, 256))
+
+    def _stage(self, batch):
+        """Pad `batch` to its size class and build the graph structure of the padded batch (bucket mode).  Returns the
+        padded batch; its extras['pad']['sig'] identifies the capture it replays."""
+        if "pad" in batch.extras and "sig" in batch.extras["pad"]:
+            return batch
+        B = batch.num_graphs
+        for nt, et in ((PA, E_PP), (LA, E_LL)):
+            if "lap_pe" not in batch[nt]:
+                batch[nt]["lap_pe"] = G.laplacian_pe_batched(batch[et]["edge_index"], batch[nt]["batch"], B,
+                                                             self.model.config.model.encoder.lap_dim)
+        c, caps = self._class_caps(G.batch_sizes(batch))
+        widths = torch.stack([(batch[nt]["ptr"][1:] - batch[nt]["ptr"][:-1]).max() for nt in (PA, LA)]).tolist()
+        for nt, w in zip((PA, LA), widths):
+            self._mx[nt] = max(self._mx[nt], -(-int(w) // 16) * 16)
+        pb = G.pad_batch(batch, *caps)
+        EF_layers._edge_cache.clear()
+        for attempt in range(3):
+            kp, kl = self._knn_cap.get((c, PA)), self._knn_cap.get((c, LA))
+            pb.extras["pad"].update(mx_p=self._mx[PA], mx_l=self._mx[LA], knn_p=kp, knn_l=kl)
+            pb.extras.pop("prepared", None)
+            try:
+                prep = self.model.prepare(pb)
+            except OverflowError:                       # a denser batch than the class has seen: forget, measure again
+                self._knn_cap.pop((c, PA), None)
+                self._knn_cap.pop((c, LA), None)
+                continue
+            if kp is not None and kl is not None:
+                break
+            # first batch of this class: its edge counts (+4 %) become the class capacities, then prepare with them
+            for nt, key in ((PA, "p"), (LA, "l")):
+                self._knn_cap[(c, nt)] = -(-int(prep[key]["edges"].n_edges * 1.04) // 1024) * 1024
+        pb.extras["pad"]["sig"] = (c, self._mx[PA], self._mx[LA], self._knn_cap[(c, PA)], self._knn_cap[(c, LA)])
+        return pb
 
     # ------------------------------------------------------------------------------------------------ eager pieces
     def _fwd_bwd(self, batch):
@@ -127,9 +188,12 @@ class TrainStep:
         with torch.cuda.stream(self._aux):
             if callable(batch):
                 batch = batch()
-            EF_layers._edge_cache.clear()      # a new batch: sort its edges again
-            batch.extras.pop("prepared", None)
-            self.model.prepare(batch)
+            if self.bucket:
+                batch = self._stage(batch)     # padded to its size class, structure built on the padded batch
+            else:
+                EF_layers._edge_cache.clear()  # a new batch: sort its edges again
+                batch.extras.pop("prepared", None)
+                self.model.prepare(batch)
             batch.extras["prepared_by_prefetch"] = True
             batch.extras["prefetched"] = torch.cuda.Event()
             batch.extras["prefetched"].record(self._aux)
@@ -153,9 +217,9 @@ class TrainStep:
     def _prepared(self, batch):
         """The batch's graph structure: taken from `prefetch` if it ran, else built now."""
         self._join_prefetch(batch)
-        if "prepared" in batch.extras and batch.extras.get("prepared_by_prefetch"):
-            batch.extras.pop("prepared_by_prefetch")
-            return batch.extras["prepared"]
+        if "prepared" in batch.extras and (batch.extras.pop("prepared_by_prefetch", False) or
+                                           "sig" in batch.extras.get("pad", {})):
+            return batch.extras["prepared"]      # built by `prefetch`, or together with the padding (`_stage`)
         EF_layers._edge_cache.clear()          # a new batch: sort its edges again
         batch.extras.pop("prepared", None)
         return self.model.prepare(batch)
@@ -176,7 +240,7 @@ class TrainStep:
         st.nodes = _clone_tree(batch.nodes)
         st.edges = _clone_tree(batch.edges)
         st.globals = _clone_tree(batch.globals)
-        st.extras = type(batch.extras)((k, _clone_tree(v)) for k, v in batch.extras.items()
+        st.extras = type(batch.extras)((k, (dict(v) if k == "pad" else _clone_tree(v))) for k, v in batch.extras.items()
                                        if k not in ("prepared", "prefetched", "prepared_by_prefetch"))
         EF_layers._edge_cache.clear()
         prep = self.model.prepare(st)
@@ -199,8 +263,9 @@ class TrainStep:
         pairs = []
         ok = (_copy_tree(st.nodes, batch.nodes, pairs) and _copy_tree(st.edges, batch.edges, pairs)
               and _copy_tree(st.globals, batch.globals, pairs))
-        ok = ok and all(k in batch.extras for k in st.extras)
-        ok = ok and _copy_tree(dict(st.extras), {k: batch.extras[k] for k in st.extras}, pairs)
+        keys = [k for k in st.extras if k != "pad"]
+        ok = ok and all(k in batch.extras for k in keys)
+        ok = ok and _copy_tree({k: st.extras[k] for k in keys}, {k: batch.extras[k] for k in keys}, pairs)
         ok = ok and _copy_tree(_prep_tensors(self.static_prep), _prep_tensors(prep), pairs)
         if ok:
             _flush_copies(pairs)
@@ -245,8 +310,38 @@ class TrainStep:
             self._update()
         self.captures += 1
 
+    # ------------------------------------------------------------------------------------------------ capture slots
+    _SLOT_FIELDS = ("static", "static_prep", "_sig", "g_fb", "g_opt", "static_loss")
+
+    def _activate(self, sig):
+        """Make the capture of signature `sig` the current one (bucket mode): its static buffers, graphs and - because the
+        gradients live in each capture's private pool - its .grad tensors."""
+        if self._active == sig:
+            return
+        slot = self._slots[sig]
+        for f in self._SLOT_FIELDS:
+            setattr(self, f, slot[f])
+        for p, g in zip(self.model.parameters(), slot["grads"]):
+            p.grad = g
+        self._slots[sig] = self._slots.pop(sig)            # most recently used last
+        self._active = sig
+
+    def _store(self, sig):
+        slot = {f: getattr(self, f) for f in self._SLOT_FIELDS}
+        slot["grads"] = [p.grad for p in self.model.parameters()]
+        slot["g_ptr"] = getattr(self.opt, "g_ptr", None)   # the address table the optimizer graph reads: keep it alive
+        self._slots[sig] = slot
+        self._active = sig
+        while len(self._slots) > self.max_cached:
+            old = next(iter(self._slots))
+            self._slots.pop(old)                           # its graphs and pool are freed with the last reference
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+
     def release(self):
         """Drop the captured graphs and their private memory pool (e.g. before running large eager steps)."""
+        self._slots.clear()
+        self._active = None
         self.g_fb = self.g_opt = self.static = self.static_prep = self.static_loss = None
         EF_layers._edge_pinned.clear()
         self.opt.zero_grad(set_to_none=True)
@@ -261,6 +356,8 @@ class TrainStep:
     def step(self, batch):
         if not self.use_graph:
             return self.eager_step(batch)
+        if self.bucket:
+            return self._bucket_step(batch)
         need = self.static is None or not self._load(batch)
         if self.reducer is not None:
             # a re-capture runs two warm-up steps with their own all-reduces: every rank has to take that path together
@@ -269,6 +366,9 @@ class TrainStep:
             self._capture(batch)
             ok = self._load(batch)
             assert ok, "the batch does not fit the buffers captured from it"
+        return self._replay()
+
+    def _replay(self):
         self.g_fb.replay()
         if self.reducer is not None:
             self.reducer.reduce()
@@ -276,3 +376,20 @@ class TrainStep:
             self.opt.sync_hyper()                            # scheduler-updated learning rate -> device scalar
         self.g_opt.replay()
         return self.static_loss
+
+    def _bucket_step(self, batch):
+        self._join_prefetch(batch)
+        pb = self._stage(batch)
+        sig = pb.extras["pad"]["sig"]
+        need = sig not in self._slots
+        if self.reducer is not None:
+            need = self.reducer.any_rank(need)               # NB: the ranks' batches must then fall into the same class
+        if need:
+            self.static = None
+            self._capture(pb)
+            self._store(sig)
+        else:
+            self._activate(sig)
+        ok = self._load(pb)
+        assert ok, "a padded batch does not fit the buffers of its own size class"
+        return self._replay()

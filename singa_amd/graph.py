@@ -246,6 +246,71 @@ def synthetic_batch(n_graphs, first_id=0, ragged=None, ids=None, **kw):
     return collate([synthetic_graph(i, **graph_sizes(i, ragged, **kw)) for i in ids])
 
 
+# ----------------------------------------------------------------------------------------------- padding to capacities
+def batch_sizes(batch):
+    """(protein atoms, ligand atoms, E_pp, E_ll, E_x) of a collated batch - from tensor shapes, no device read-back."""
+    return (batch[PA]["x"].shape[0], batch[LA]["x"].shape[0], batch[E_PP]["edge_index"].shape[1],
+            batch[E_LL]["edge_index"].shape[1], batch[E_LP]["edge_index"].shape[1])
+
+
+def pad_batch(batch, n_p, n_l, e_pp, e_ll, e_x):
+    """The batch grown to fixed capacities with INERT padding, so that batches of different sizes share one captured HIP
+    graph (real CrossDocked batches are ragged: reference utils/Data.py:230, train.py:113-133).  Padding atoms belong to
+    no graph (batch id = num_graphs): they sit far away from everything, get no kNN neighbours, never reach the
+    transformer's dense layout and therefore receive a zero gradient; padding edges only connect padding atoms (spread
+    evenly over them, never a self loop, so every edge frame is well defined).  Logits, loss and every parameter gradient
+    of the padded batch equal the unpadded ones (tests/test_padding_gpu.py).  Needs `lap_pe` on the node stores."""
+    r_p, r_l, r_pp, r_ll, r_x = batch_sizes(batch)
+    d_p, d_l = n_p - r_p, n_l - r_l
+    assert d_p >= 2 and d_l >= 2 and e_pp >= r_pp and e_ll >= r_ll and e_x >= r_x, "capacities must exceed the batch"
+    dev = batch[PA]["x"].device
+    B = batch.num_graphs
+    out = HeteroGraph()
+    out.num_graphs = B
+    for nt, real, extra, yoff in ((PA, r_p, d_p, 1.0e3), (LA, r_l, d_l, 2.0e3)):
+        st, o = batch.nodes[nt], out.nodes[nt]
+        assert "lap_pe" in st, "pad_batch: compute the Laplacian encodings before padding"
+        far = torch.zeros(extra, 3, device=dev)
+        far[:, 0] = 1.0e3 + 4.0 * torch.arange(extra, device=dev)
+        far[:, 1] = yoff
+        far[:, 2] = 1.0e3
+        o["x"] = torch.cat([st["x"], st["x"].new_zeros(extra, st["x"].shape[1])])
+        o["pos"] = torch.cat([st["pos"], far.to(st["pos"].dtype)])
+        o["batch"] = torch.cat([st["batch"], st["batch"].new_full((extra,), B)])
+        o["lap_pe"] = torch.cat([st["lap_pe"], st["lap_pe"].new_zeros(extra, st["lap_pe"].shape[1])])
+        o["ptr"] = st["ptr"]
+        z = batch.globals["atomicnum"][nt]
+        out.globals["atomicnum"][nt] = torch.cat([z, z.new_full((extra,), 6)])
+    out.globals["ligand_data"] = batch.globals["ligand_data"]
+
+    def ring(count, base_s, n_s, base_d, n_d, same):
+        """`count` padding edges: source i % n_s, destination shifted so that (same node set) it never equals the source."""
+        i = torch.arange(count, device=dev)
+        s = i % n_s
+        if same:
+            d = (s + 1 + (i // n_s) % (n_s - 1)) % n_s
+        else:
+            d = (i + i // n_s) % n_d
+        return torch.stack([base_s + s, base_d + d])
+
+    pads = {E_PP: ring(e_pp - r_pp, r_p, d_p, r_p, d_p, True), E_LL: ring(e_ll - r_ll, r_l, d_l, r_l, d_l, True),
+            E_LP: ring(e_x - r_x, r_l, d_l, r_p, d_p, False)}
+    pads[E_PL] = pads[E_LP].flip(0)                                   # mirrored in the same order (Q5)
+    for et in (E_PP, E_LL, E_LP, E_PL):
+        out.edges[et]["edge_index"] = torch.cat([batch.edges[et]["edge_index"], pads[et].to(batch.edges[et]["edge_index"].dtype)], 1)
+    for k, v in batch.extras.items():
+        if k == "rot_rand":
+            fill = torch.tensor([0.1, 0.5, 0.9], device=dev)
+            want = {"pp": e_pp, "ll": e_ll, "lp": e_x}
+            out.extras[k] = {kk: torch.cat([t, fill.to(t.dtype).expand(want[kk] - t.shape[0], 3)]) for kk, t in v.items()}
+        elif k in ("edge_rot_mat", "knn"):
+            raise ValueError(f"pad_batch: pinned '{k}' inputs (parity fixtures) cannot be padded")
+        elif k not in ("prepared", "prefetched", "prepared_by_prefetch", "pad"):
+            out.extras[k] = v
+    out.extras["pad"] = {"n_real": {PA: r_p, LA: r_l}}
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- reference .pt graphs
 def load_reference_pt(path, with_lap=True):
     """Read a pickled PyG `HeteroData` graph of the reference (example/*.pt, dataset/crossdocked_graph10_v3/*.pt) without

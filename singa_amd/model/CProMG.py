@@ -46,26 +46,39 @@ class GaussianSmearing(nn.Module):
 class DenseMap:
     """to_dense_batch bookkeeping for one node type of one batch: flat positions of the nodes inside the
     padded [B, max_nodes] layout and the validity mask.  Built once per batch (one host sync for max_nodes) and reused
-    by every layer, so the forward itself stays free of host synchronisation."""
+    by every layer, so the forward itself stays free of host synchronisation.  Nodes whose batch id is >= batch_size
+    (the inert padding atoms of graph.pad_batch) are outside the layout: `dense` drops them into a trash row behind the
+    last real one, `gather` hands them row 0 (their values are never used)."""
 
     def __init__(self, batch, batch_size, mx=None):
-        num = torch.zeros(batch_size, dtype=torch.int64, device=batch.device).index_add_(0, batch, torch.ones_like(batch))
+        inside = batch < batch_size
+        bc = batch.clamp(max=batch_size)
+        num = torch.zeros(batch_size + 1, dtype=torch.int64, device=batch.device).index_add_(0, bc, torch.ones_like(batch))
+        num = num[:batch_size]
         self.B = batch_size
         self.mx = int(num.max()) if mx is None else int(mx)
         start = num.cumsum(0) - num
-        self.idx = torch.arange(batch.numel(), device=batch.device) - start[batch] + batch * self.mx
-        self.mask = torch.zeros(batch_size * self.mx, dtype=torch.bool, device=batch.device)
-        self.mask[self.idx] = True
-        self.mask = self.mask.view(batch_size, self.mx)
+        trash = batch_size * self.mx
+        bi = batch.clamp(max=batch_size - 1)
+        self.idx = torch.where(inside, torch.arange(batch.numel(), device=batch.device) - start[bi] + bi * self.mx,
+                               torch.full_like(batch, trash))
+        self.gidx = torch.where(inside, self.idx, torch.zeros_like(self.idx))
+        mask = torch.zeros(trash + 1, dtype=torch.bool, device=batch.device)
+        mask[self.idx] = True
+        self.mask = mask[:trash].view(batch_size, self.mx)
         self.pad_mask = ~self.mask.unsqueeze(1)
 
     def tensors(self):
-        return [self.idx, self.mask, self.pad_mask]
+        return [self.idx, self.gidx, self.mask, self.pad_mask]
 
     def dense(self, x):
-        out = x.new_zeros((self.B * self.mx,) + tuple(x.shape[1:]))
+        out = x.new_zeros((self.B * self.mx + 1,) + tuple(x.shape[1:]))
         out = out.index_copy(0, self.idx, x)
-        return out.view(self.B, self.mx, *x.shape[1:])
+        return out[:self.B * self.mx].view(self.B, self.mx, *x.shape[1:])
+
+    def gather(self, dense_flat):
+        """Per-node rows of a [B * max_nodes, ...] tensor (the inverse of `dense`)."""
+        return dense_flat.index_select(0, self.gidx)
 
 
 def to_dense_batch(x, batch, batch_size):
@@ -86,9 +99,9 @@ def knn_graph(pos, k, batch, batch_size, dm=None):
     d = d + torch.diag_embed(torch.full((mx,), float("inf"), device=pos.device)).unsqueeze(0)
     kk = min(k, mx - 1)
     dist, nb = d.topk(kk, dim=2, largest=False)
-    node_of = torch.full((batch_size * mx,), -1, dtype=torch.long, device=pos.device)
+    node_of = torch.full((batch_size * mx + 1,), -1, dtype=torch.long, device=pos.device)
     node_of[idx] = torch.arange(pos.shape[0], device=pos.device)
-    node_of = node_of.view(batch_size, mx)
+    node_of = node_of[:batch_size * mx].view(batch_size, mx)
     centre = node_of.unsqueeze(2).expand(-1, -1, kk)
     neigh = torch.gather(node_of.unsqueeze(1).expand(-1, mx, -1), 2, nb)
     ok = torch.isfinite(dist) & (centre >= 0)
@@ -101,7 +114,9 @@ class KnnEdges:
     smearing and get_laplacian (self-loops appended; 2-D weights, Q12), then sorted by centre node -> CSR row_ptr.
     Coalescing is a radix sort + adjacent-difference + prefix sum (two scalar read-backs for the counts)."""
 
-    def __init__(self, pos, knn_ei, smear):
+    def __init__(self, pos, knn_ei, smear, cap=None, n_real=None):
+        """cap / n_real: pad the edge list (before the N self loops) with inert edges among the padding atoms
+        [n_real, N) up to `cap` edges in total, so that the arrays have a fixed size (graph.pad_batch)."""
         N = pos.shape[0]
         dev = pos.device
         valid = (knn_ei[0] >= 0) & (knn_ei[1] >= 0)
@@ -136,6 +151,17 @@ class KnnEdges:
             ln = torch.zeros(n_groups, device=dev).index_add_(0, gid, ln2)[:n_edges] / cnt
         row, col = ukey // N, ukey % N
         ea = smear(ln)
+        self.n_edges = n_edges + N                       # undirected kNN edges + self loops, before any padding
+        if cap is not None:
+            extra = cap - self.n_edges
+            nd = N - n_real
+            if extra < 0 or nd < 2:
+                raise OverflowError(f"KnnEdges: {self.n_edges} edges do not fit the capacity {cap}")
+            i = torch.arange(extra, device=dev)
+            ps = (i * nd) // max(extra, 1)               # non-decreasing: rows stay sorted (the padding atoms come last)
+            row = torch.cat([row, n_real + ps])
+            col = torch.cat([col, n_real + (ps + 1 + i % (nd - 1)) % nd])
+            ea = torch.cat([ea, ea.new_zeros(extra, ea.shape[1])])
         # per-node sum of the edge features (get_laplacian's degree for 2-D weights, Q12).  `row` is sorted, so this is a
         # segment sum - index_add_ spent 9 ms per call on ~2e8 float atomics at the bench size
         if ea.is_cuda:
@@ -339,7 +365,7 @@ class EncoderLayer2(nn.Module):
                 before_cross(idx)
             kv = self.proj(atom_msa_outputs[idx])
             cross = self.cross_attn(dm.dense(msa_outputs), kv, kv, atom_mask)
-            msa_outputs = ops.layer_norm_residual(msa_outputs, cross.reshape(-1, cross.size(-1)).index_select(0, dm.idx), self.layer_norm)
+            msa_outputs = ops.layer_norm_residual(msa_outputs, dm.gather(cross.reshape(-1, cross.size(-1))), self.layer_norm)
         return self.pos_ffn(msa_outputs)
 
 
@@ -354,12 +380,13 @@ class Encoder(nn.Module):
         self.out = Linear(config.hidden_channels, config.hidden_channels, device=device)       # unused (Q10)
         self.layer_norm = LayerNorm(config.hidden_channels, device=device)                      # unused (Q10)
 
-    def prepare(self, pos, batch, batch_size, knn=None):
-        """Per-batch graph structure (no parameters involved): dense-batch map, kNN edges (CP:293-298)."""
-        dm = DenseMap(batch, batch_size)
+    def prepare(self, pos, batch, batch_size, knn=None, mx=None, cap=None, n_real=None):
+        """Per-batch graph structure (no parameters involved): dense-batch map, kNN edges (CP:293-298).  mx / cap /
+        n_real: fixed layout width and edge capacity for padded batches (graph.pad_batch)."""
+        dm = DenseMap(batch, batch_size, mx)
         if knn is None:
             knn = knn_graph(pos, self.config.knn, batch, batch_size, dm)
-        return {"dense": dm, "edges": KnnEdges(pos, knn, self.distance_expansion)}
+        return {"dense": dm, "edges": KnnEdges(pos, knn, self.distance_expansion, cap, n_real)}
 
     def forward(self, protein_atom_feature, pos, batch, atom_laplacian, batch_size=None, knn=None, prep=None,
                 layer_done=None):
@@ -389,11 +416,11 @@ class Encoder2(nn.Module):
         self.out = Linear(config.hidden_channels, config.hidden_channels, device=device)       # unused (Q10)
         self.layer_norm = LayerNorm(config.hidden_channels, device=device)                      # unused (Q10)
 
-    def prepare(self, aa_pos, aa_batch, batch_size, knn=None):
-        dm = DenseMap(aa_batch, batch_size)
+    def prepare(self, aa_pos, aa_batch, batch_size, knn=None, mx=None, cap=None, n_real=None):
+        dm = DenseMap(aa_batch, batch_size, mx)
         if knn is None:
             knn = knn_graph(aa_pos, 30, aa_batch, batch_size, dm)                  # CP:330
-        return {"dense": dm, "edges": KnnEdges(aa_pos, knn, self.distance_expansion)}
+        return {"dense": dm, "edges": KnnEdges(aa_pos, knn, self.distance_expansion, cap, n_real)}
 
     def forward(self, aa_feature, aa_pos, aa_batch, aa_laplacian, atom_mask, atom_msa_outputs, batch_size=None, knn=None,
                 prep=None, before_cross=None):

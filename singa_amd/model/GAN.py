@@ -61,8 +61,12 @@ class SINGA(nn.Module):
             if "lap_pe" not in g[nt]:      # deterministic per-graph Laplacian PE, batched eigensolve on the GPU
                 g[nt]["lap_pe"] = laplacian_pe_batched(g[et]["edge_index"], g[nt]["batch"], B, self.config.model.encoder.lap_dim)
         knn = getattr(g, "extras", {}).get("knn", {})
-        prep = {"p": self.model.encoder.prepare(g[PA]["pos"], g[PA]["batch"], B, knn.get(PA)),
-                "l": self.model.encoder2.prepare(g[LA]["pos"], g[LA]["batch"], B, knn.get(LA))}
+        pad = getattr(g, "extras", {}).get("pad") or {}         # fixed capacities of a padded batch (graph.pad_batch)
+        nr = pad.get("n_real", {})
+        prep = {"p": self.model.encoder.prepare(g[PA]["pos"], g[PA]["batch"], B, knn.get(PA), pad.get("mx_p"),
+                                                pad.get("knn_p"), nr.get(PA)),
+                "l": self.model.encoder2.prepare(g[LA]["pos"], g[LA]["batch"], B, knn.get(LA), pad.get("mx_l"),
+                                                 pad.get("knn_l"), nr.get(LA))}
         prep.update({
                 "es": {"pp": edge_set(g[E_PP]["edge_index"], n_p, n_p), "ll": edge_set(g[E_LL]["edge_index"], n_l, n_l),
                        "lp": edge_set(g[E_LP]["edge_index"], n_l, n_p), "pl": edge_set(g[E_PL]["edge_index"], n_p, n_l)}})

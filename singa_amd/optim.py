@@ -53,7 +53,12 @@ class Adam(torch.optim.Optimizer):
         """Device table of the CURRENT .grad addresses (they change when grads are re-created; static under replay)."""
         ids = tuple(p.grad.data_ptr() for p in self.active)
         if ids != self._grad_ids:
-            self.g_ptr = torch.tensor(ids, dtype=torch.int64, device=self.p_ptr.device)
+            # tables stay alive: a captured optimizer graph has the address of the table it was captured with baked in
+            if not hasattr(self, "_tables"):
+                self._tables = {}
+            if ids not in self._tables:
+                self._tables[ids] = torch.tensor(ids, dtype=torch.int64, device=self.p_ptr.device)
+            self.g_ptr = self._tables[ids]
             self._grad_ids = ids
         return self.g_ptr
 

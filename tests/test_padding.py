@@ -1,0 +1,75 @@
+"""CPU: the inert padding of graph.pad_batch and the padding-aware graph structure (DenseMap, kNN edges) - structure only,
+the numerics run on the GPU (tests/test_padding_gpu.py).  Real batches are ragged (reference utils/Data.py:230), a
+captured HIP graph needs fixed shapes."""
+import torch
+
+from singa_amd import graph as G
+from singa_amd.model import CProMG as CP
+
+KW = dict(n_protein=40, n_ligand=10, e_pp=160, e_ll=20, e_x=24)
+
+
+def _batch(ids):
+    return G.synthetic_batch(len(ids), ids=ids, **KW)
+
+
+def test_pad_batch_structure():
+    b = _batch([1, 2, 3])
+    r = G.batch_sizes(b)
+    caps = (r[0] + 70, r[1] + 66, r[2] + 100, r[3] + 7, r[4] + 50)
+    pb = G.pad_batch(b, *caps)
+    assert G.batch_sizes(pb) == caps and pb.num_graphs == 3
+    for nt, n_real in ((G.PA, r[0]), (G.LA, r[1])):
+        assert torch.equal(pb[nt]["x"][:n_real], b[nt]["x"]) and float(pb[nt]["x"][n_real:].abs().max()) == 0.0
+        assert bool((pb[nt]["batch"][n_real:] == 3).all()) and torch.equal(pb[nt]["batch"][:n_real], b[nt]["batch"])
+        assert pb.extras["pad"]["n_real"][nt] == n_real
+    for et, (ns, nd) in {G.E_PP: (r[0], r[0]), G.E_LL: (r[1], r[1]), G.E_LP: (r[1], r[0]), G.E_PL: (r[0], r[1])}.items():
+        ei, real = pb[et]["edge_index"], b[et]["edge_index"]
+        assert torch.equal(ei[:, :real.shape[1]], real)
+        pad = ei[:, real.shape[1]:]
+        assert bool((pad[0] >= ns).all()) and bool((pad[1] >= nd).all())           # padding edges touch padding atoms only
+        if et[0] == et[2]:
+            assert bool((pad[0] != pad[1]).all())                                   # never a self loop: frames are defined
+        deg = torch.bincount(pad[1] - nd)
+        assert int(deg.max()) <= -(-pad.shape[1] // max(1, min(caps[0] - r[0], caps[1] - r[1]))) + 1   # spread evenly
+    # mirrored hetero edges in the same order (Q5)
+    assert torch.equal(pb[G.E_PL]["edge_index"], pb[G.E_LP]["edge_index"].flip(0))
+    # every padding edge has a usable length
+    for et, (a, c) in {G.E_PP: (G.PA, G.PA), G.E_LP: (G.LA, G.PA)}.items():
+        ei = pb[et]["edge_index"]
+        d = (pb[a]["pos"][ei[0]] - pb[c]["pos"][ei[1]]).norm(dim=1)
+        assert float(d.min()) > 0.5
+    assert pb.extras["rot_rand"]["pp"].shape == (caps[2], 3) and pb.extras["rot_rand"]["lp"].shape == (caps[4], 3)
+
+
+def test_dense_map_and_knn_edges_ignore_padding_atoms():
+    b = _batch([4, 5])
+    r = G.batch_sizes(b)
+    pb = G.pad_batch(b, r[0] + 64, r[1] + 64, r[2] + 8, r[3] + 8, r[4] + 8)
+    smear = CP.GaussianSmearing(stop=15, num_gaussians=64, device="cpu")
+    pos, batch = b[G.PA]["pos"], b[G.PA]["batch"]
+    dm = CP.DenseMap(batch, 2)
+    ref = CP.KnnEdges(pos, CP.knn_graph(pos, 8, batch, 2, dm), smear)
+    ppos, pbatch = pb[G.PA]["pos"], pb[G.PA]["batch"]
+    pdm = CP.DenseMap(pbatch, 2, mx=dm.mx + 5)
+    assert torch.equal(pdm.mask[:, :dm.mx], dm.mask) and not bool(pdm.mask[:, dm.mx:].any())
+    x = torch.randn(ppos.shape[0], 3)
+    dense = pdm.dense(x)
+    assert torch.equal(dense[:, :dm.mx][dm.mask], x[:r[0]])                        # padding atoms never enter the layout
+    assert torch.equal(pdm.gather(dense.reshape(-1, 3))[:r[0]], x[:r[0]])
+    cap = ref.n_edges + 64 + 37
+    pe = CP.KnnEdges(ppos, CP.knn_graph(ppos, 8, pbatch, 2, pdm), smear, cap=cap + 64, n_real=r[0])
+    N, Np = pos.shape[0], ppos.shape[0]
+    assert pe.row.numel() == cap + 64 and pe.n_edges == ref.n_edges + 64           # + the self loops of the padding atoms
+    real = (pe.row < N) & (pe.col < N)
+    assert int(real.sum()) == ref.row.numel()
+    a = torch.sort(pe.row[real] * N + pe.col[real])
+    c = torch.sort(ref.row * N + ref.col)
+    assert torch.equal(a.values, c.values) and torch.allclose(pe.attr[real][a.indices], ref.attr[c.indices], atol=1e-6)
+    assert bool(((pe.row >= N) == (pe.col >= N)).all())                            # no edge between real and padding atoms
+    assert int(pe.row_ptr[-1]) == cap + 64 and bool((pe.row[1:] >= pe.row[:-1]).all())
+    try:
+        CP.KnnEdges(ppos, CP.knn_graph(ppos, 8, pbatch, 2, pdm), smear, cap=ref.n_edges, n_real=r[0])
+        raise AssertionError("capacity overflow not reported")
+    except OverflowError:
+        pass
