@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="build each batch's graph structure inside its own step instead of on a second stream during the previous one")
+    ap.add_argument("--distinct-batches", type=int, default=3,
+                    help="different resident batches cycled through the timed steps (ragged sizes -> padded / bucketed replay; "
+                         "1 = the same batch every step)")
+    ap.add_argument("--growth", type=float, default=1.04, help="width of a size class of the bucketed replay")
     ap.add_argument("--roofline-steps", type=int, default=2, help="instrumented eager steps after the timed region")
     ap.add_argument("--cpu-graphs", type=int, default=8, help="graphs in the bounded CPU-oracle sample")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -268,22 +272,31 @@ def main():
         ids = list(range(rank * n_graphs, (rank + 1) * n_graphs))
         graphs_per_step = n_graphs * world
     t_gen = time.perf_counter()
-    batch = G.synthetic_batch(len(ids), ids=ids, **kw).to(dev)
-    # a second resident copy: steps alternate between the two, so that batch i+1 can be prepared while step i computes
+    # D different batches of this rank's graphs, resident in HBM, cycled through the steps.  Their atom / edge counts differ
+    # (config 3 is ragged), so the replayed step pads each batch to its size class (TrainStep bucket mode).  D = 1: the
+    # same batch every step (two resident copies, so that batch i+1 can be prepared while step i computes).
     import copy
-    batches = [batch, batch if args.no_prefetch else copy.deepcopy(batch)]
+    D = max(1, args.distinct_batches)
+    stride = n_graphs * world if args.scaling != "strong" else n_graphs
+    batches = [G.synthetic_batch(len(ids), ids=[i + k * stride for i in ids], **kw).to(dev) for k in range(D)]
+    batch = batches[0]
+    if D == 1 and not args.no_prefetch:
+        batches.append(copy.deepcopy(batch))
     from singa_amd.engine import TrainStep
+    bucket = use_graph and D > 1
     engine = TrainStep(model, opt, reducer if world > 1 else None, use_graph=use_graph,
-                       max_grad_norm=float(cfg.train.max_grad_norm))
+                       max_grad_norm=float(cfg.train.max_grad_norm), bucket=bucket, growth=args.growth, max_cached=4)
     n_nodes = batch[G.PA]["x"].shape[0] + batch[G.LA]["x"].shape[0]
     n_edges = sum(int(batch[et]["edge_index"].shape[1]) for et in (G.E_PP, G.E_LL, G.E_LP, G.E_PL))
     log(f"workload {args.workload}: {len(ids)} graphs on this GPU ({n_nodes} atoms, {n_edges} edges), L={L}, generated in "
         f"{time.perf_counter() - t_gen:.1f} s; {'HIP-graph replay' if use_graph else 'eager'} step")
-    for i in range(args.warmup):
+    nb = len(batches)
+    for i in range(max(args.warmup, nb if bucket else 0)):      # (bucket mode: every batch once, so that all captures exist)
         t_w = time.perf_counter()
-        loss = engine.step(batch)
+        loss = engine.step(batches[i % nb])
         torch.cuda.synchronize()
         log(f"warmup step {i}: {time.perf_counter() - t_w:.3f} s")
+    captures_before = engine.captures
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, MAX over ranks.  Every step handles its
     # batch as newly arrived: the graph structure (edge sorting, kNN graphs, dense maps) is rebuilt K times inside the
     # region - by default on a second stream while the previous step computes (TrainStep.prefetch), the way a loader
@@ -293,10 +306,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    nxt = batches[0]
     for i in range(args.steps):
-        loss = engine.step(batches[i % 2])
+        loss = engine.step(nxt)
+        nxt = batches[(i + 1) % nb]
         if not args.no_prefetch:
-            engine.prefetch(batches[(i + 1) % 2])
+            nxt = engine.prefetch(nxt)          # (bucket mode: returns the padded batch the next step replays)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -393,7 +408,10 @@ def main():
                           "parallelism": f"dp{world}",
                           "step": "prepare+zero_grad+fwd+CE+bwd+allreduce+clip+Adam of the generator (the reference has no discriminator)",
                           "launch": "hipGraph replay" if use_graph else "eager",
-                          "batches": "one resident batch per GPU, its graph structure rebuilt every step",
+                          "batches": (f"{D} different resident batches per GPU cycled through the steps, each padded to its "
+                                      f"size class (x{args.growth} per class) and its graph structure rebuilt every step"
+                                      if bucket else "one resident batch per GPU, its graph structure rebuilt every step"),
+                          "captures_in_timed_region": engine.captures - captures_before,
                           "prepare": "in step" if args.no_prefetch else "prefetched on a second stream during the previous step",
                           "prepare_ms_of_step": round(prepare_ms, 2), "graph_captures": engine.captures,
                           "grad_allreduce_bytes": reducer.payload_bytes},

@@ -105,8 +105,8 @@ class TrainStep:
 
     # ------------------------------------------------------------------------------------------------ size classes
     def _class_caps(self, sizes):
-        if self._base is None:
-            self._base = tuple(max(1, v) for v in sizes)
+        if self._base is None:      # the first batch sits in the middle of class 0 (batches a few % larger share it)
+            self._base = tuple(max(1, v) * math.sqrt(self.growth) for v in sizes)
         r = max(v / b for v, b in zip(sizes, self._base))
         c = int(math.ceil(math.log(r) / math.log(self.growth) - 1e-9))
         scale = self.growth ** c

@@ -59,8 +59,8 @@ def main():
     ap.add_argument("--max-iters", type=int, default=None)
     ap.add_argument("--batch-size", type=int, default=None, help="graphs per step over all ranks")
     ap.add_argument("--graph", action="store_true",
-                    help="capture the step into HIP graphs and replay it (needs same-shape batches, e.g. --data golden; "
-                         "a batch with different edge counts triggers a re-capture)")
+                    help="capture the step into HIP graphs and replay it; batches of different sizes are padded to size "
+                         "classes, one capture per class")
     ap.add_argument("--resume", type=str, default=None, help="checkpoint to load (model, optimizer, scheduler, iteration)")
     args = ap.parse_args()
     assert args.device.startswith("cuda"), "the hot path is the HIP path: there is no CPU fallback"
@@ -124,7 +124,9 @@ def main():
     if reducer:
         reducer.check_same_init()
         reducer.set_shard_weight(hi - lo, batch_size)        # token-weighted combination: exact for unequal shards too
-    engine = TrainStep(model, opt, reducer, use_graph=args.graph, max_grad_norm=float(cfg.train.max_grad_norm))
+    # --graph: ragged batches are padded to size classes and replay a few captured HIP graphs (TrainStep bucket mode)
+    engine = TrainStep(model, opt, reducer, use_graph=args.graph, max_grad_norm=float(cfg.train.max_grad_norm),
+                       bucket=args.graph)
     early = EarlyStopping(patience=20, delta=0.00005)
 
     def evaluate(split, n_batches=2):
