@@ -2684,7 +2684,15 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
     // two register sets: the loads of K step s+2 are issued at the start of step s and written to LDS at the end of step
     // s+1, so every load has two steps (~8,000 MFMA cycles) to arrive - one step did not cover an HBM miss under load
     float4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
-    auto load_rc = [&](float4* reg, const float* const* rows, int n, long long r0) {
+    // `full`: the tile lies inside the matrices and every K step is complete - loads without predicates (8 exec-mask
+    // round trips per step less, and the compiler batches them)
+    const bool full = i0 + BM <= P.I && j0 + BN <= P.J && r_end > r_begin && (r_end - r_begin) % BK == 0;
+    auto load_rc = [&](float4* reg, const float* const* rows, int n, long long r0, bool all) {
+        if (all) {
+#pragma unroll
+            for (int j = 0; j < n; ++j) reg[j] = *reinterpret_cast<const float4*>(rows[j] + r0);
+            return;
+        }
         const bool in = r0 + 4 * kq < r_end;
 #pragma unroll
         for (int j = 0; j < n; ++j) {
@@ -2693,9 +2701,15 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
         }
     };
     auto load_oc = [&](float4* reg, const float* base, long long ld, int grp, long long gld, int o0, int lim, int n, int width4,
-                       long long r0) {
+                       long long r0, bool all) {
         const int c4 = tid % width4, rq = tid / width4, rows = 256 / width4;
         const int i = o0 + 4 * c4;
+        if (all && grp == (1 << 30)) {
+            const float* b = base + (r0 + rq) * ld + i;
+#pragma unroll
+            for (int j = 0; j < n; ++j) reg[j] = *reinterpret_cast<const float4*>(b + (long long)(rows * j) * ld);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < n; ++j) {
             const long long r = r0 + rq + rows * j;
@@ -2716,10 +2730,10 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
         for (int j = 0; j < n; ++j) *reinterpret_cast<float4*>(S + (rq + rows * j) * pitch + 4 * c4) = reg[j];
     };
     auto load_ab = [&](float4* ra, float4* rb, long long r0) {
-        if (A_RC) load_rc(ra, arow, NA, r0);
-        else load_oc(ra, P.A, P.lda, P.a_group, P.a_gld, i0, P.I, NA, BM / 4, r0);
-        if (B_RC) load_rc(rb, brow, NB, r0);
-        else load_oc(rb, P.B, P.ldb, P.b_group, P.b_gld, j0, P.J, NB, BN / 4, r0);
+        if (A_RC) load_rc(ra, arow, NA, r0, full);
+        else load_oc(ra, P.A, P.lda, P.a_group, P.a_gld, i0, P.I, NA, BM / 4, r0, full);
+        if (B_RC) load_rc(rb, brow, NB, r0, full);
+        else load_oc(rb, P.B, P.ldb, P.b_group, P.b_gld, j0, P.J, NB, BN / 4, r0, full);
     };
     auto store_ab = [&](const float4* ra, const float4* rb, int buf) {
         if (A_RC) store_rc(As0 + buf * SZA, ra, NA);

@@ -82,5 +82,5 @@ def test_laplacian_pe_batched_on_gpu_against_oracle_spectrum():
             ritz = v.T @ lap @ v
             assert np.abs(lap @ v - v @ ritz).max() < 1e-5
             assert np.abs(np.linalg.eigvalsh(ritz) - w[1:9]).max() < 1e-5
-            top = v[np.abs(v).argmax(0), np.arange(8)]
-            assert (top > 0).all()
+            # sign convention: the entry of largest magnitude is positive (up to ties between mirror-image atoms)
+            assert (v.max(0) >= (-v).max(0) - 1e-6).all()
