@@ -250,7 +250,7 @@ struct __attribute__((aligned(16))) F4U {
     float v[4];
 };
 template <int L, int M, int C, int SIDE, bool RAD>
-__global__ void __launch_bounds__(256) gather_rotate_bwd_node_kernel(const float* __restrict__ g_out, const float* __restrict__ wr,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((L > 4 ? 1 : 4), (L > 4 ? 2 : 8)))) gather_rotate_bwd_node_kernel(const float* __restrict__ g_out, const float* __restrict__ wr,
                                               const float* __restrict__ rad, const int* __restrict__ ptr,
                                               const int* __restrict__ eperm, float* __restrict__ gx, int N) {
     using I = SO3Idx<L, M>;
@@ -281,9 +281,10 @@ __global__ void __launch_bounds__(256) gather_rotate_bwd_node_kernel(const float
             const long long ro = (long long)e * I::RAD_ROWS * 2 * C + co;
 #pragma unroll
             for (int l = 0; l <= L; ++l) {
-                // this degree's block of the record, [w_off(l), w_off(l+1)), fetched as the float4 chunks that cover it
-                constexpr int dummy = 0;
-                (void)dummy;
+                // this degree's block of the record, [w_off(l), w_off(l+1)), fetched as the float4 chunks that cover it.
+                // L = 6: the scheduler may not hoist the loads of degrees 4..6 above the arithmetic of degrees 0..3 (all
+                // 235 + 47 loads in flight at once needed 350 registers and spilled)
+                if (L > 4 && l == 4) __builtin_amdgcn_sched_barrier(0);
                 const int lo4 = I::w_off(l) / 4, hi4 = (I::w_off(l + 1) + 3) / 4;
                 float w[(2 * L + 1) * (2 * M + 1) + 6];
 #pragma unroll
