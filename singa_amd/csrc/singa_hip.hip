@@ -2672,7 +2672,9 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const int i = i0 + rr + 32 * j;
-            arow[j] = i < P.I ? P.A + (long long)(i / P.a_group) * P.a_gld + (long long)(i % P.a_group) * P.lda + 4 * kq : nullptr;
+            const long long off = P.a_group == (1 << 30) ? (long long)i * P.lda
+                                                         : (long long)(i / P.a_group) * P.a_gld + (long long)(i % P.a_group) * P.lda;
+            arow[j] = i < P.I ? P.A + off + 4 * kq : nullptr;
         }
     }
     if (B_RC) {
@@ -2851,7 +2853,8 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
             float4 v = *reinterpret_cast<const float4*>(stage + rloc * PE + 4 * c4);
             if (i < P.I && jcol < P.J) {
                 v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
-                const long long row = (long long)(i / P.c_group) * P.c_gld + (long long)(i % P.c_group) * P.ldc;
+                const long long row = P.c_group == (1 << 30) ? (long long)i * P.ldc
+                                                             : (long long)(i / P.c_group) * P.c_gld + (long long)(i % P.c_group) * P.ldc;
                 *reinterpret_cast<float4*>(Cb + row + jcol) = v;
             }
         }
