@@ -352,17 +352,33 @@ def test_edge_head_logits_and_activation():
         assert rel(d.grad, r.grad) < 1e-4
 
 
+
+def cpu_f64(fn, inputs, grad_outs, wrt=None):
+    """Evaluate `fn` on float64 CPU copies of `inputs` (the CPU reference of a kernel: same formula as the reference's
+    torch code, computed away from the GPU) and return (outputs, gradients w.r.t. inputs[wrt]) as float32 CUDA tensors."""
+    ins = [t.detach().cpu().double().requires_grad_(True) if (torch.is_tensor(t) and t.is_floating_point()) else
+           (t.cpu() if torch.is_tensor(t) else t) for t in inputs]
+    outs = fn(*ins)
+    single = torch.is_tensor(outs)
+    outs_l = [outs] if single else list(outs)
+    gos = [g.detach().cpu().double() for g in ([grad_outs] if torch.is_tensor(grad_outs) else grad_outs)]
+    idx = range(len(ins)) if wrt is None else wrt
+    grads = torch.autograd.grad(outs_l, [ins[i] for i in idx], gos)
+    to = lambda t: t.detach().float().to(DEV)
+    return (to(outs) if single else [to(o) for o in outs_l]), [to(g) for g in grads]
+
+
 @pytest.mark.parametrize("M", [1, 63, 56448])
 def test_ln_silu_matches_torch(M):
-    """k6a against torch's LayerNorm + SiLU (outputs, input gradient, d gamma, d beta)."""
+    """k6a against LayerNorm + SiLU evaluated in float64 on the CPU (outputs, input gradient, d gamma, d beta)."""
     from singa_amd import ops
     torch.manual_seed(M)
     x = (torch.randn(M, 16, device="cuda") * 2 + 0.3).requires_grad_(True)
     gamma = torch.randn(16, device="cuda", requires_grad=True)
     beta = torch.randn(16, device="cuda", requires_grad=True)
     g = torch.randn(M, 16, device="cuda")
-    want = torch.nn.functional.silu(torch.nn.functional.layer_norm(x, (16,), gamma, beta, 1e-5))
-    want_g = torch.autograd.grad(want, (x, gamma, beta), g)
+    want, want_g = cpu_f64(lambda x_, ga, be: torch.nn.functional.silu(torch.nn.functional.layer_norm(x_, (16,), ga, be, 1e-5)),
+                           (x, gamma, beta), g)
     got = ops.ln_silu(x, gamma, beta, 1e-5)
     got_g = torch.autograd.grad(got, (x, gamma, beta), g)
     assert float((got - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
@@ -378,8 +394,7 @@ def test_bias_ssp_matches_torch():
     u = (torch.randn(5003, 64, device="cuda") * 6).requires_grad_(True)
     b = torch.randn(64, device="cuda", requires_grad=True)
     g = torch.randn(5003, 64, device="cuda")
-    want = torch.nn.functional.softplus(u + b) - math.log(2.0)
-    want_g = torch.autograd.grad(want, (u, b), g)
+    want, want_g = cpu_f64(lambda u_, b_: torch.nn.functional.softplus(u_ + b_) - math.log(2.0), (u, b), g)
     got = ops.bias_ssp(u, b)
     got_g = torch.autograd.grad(got, (u, b), g)
     assert float((got - want).abs().max()) < 1e-5 * float(want.abs().max())
@@ -399,8 +414,10 @@ def test_layer_norm_256_residual_matches_torch(M, res):
     r = torch.randn(M, 256, device="cuda", requires_grad=True) if res else None
     g = torch.randn(M, 256, device="cuda")
     ins = (a, r, ln.weight, ln.bias) if res else (a, ln.weight, ln.bias)
-    want = ln(a + r if res else a)
-    want_g = torch.autograd.grad(want, ins, g)
+    if res:
+        want, want_g = cpu_f64(lambda a_, r_, w_, b_: torch.nn.functional.layer_norm(a_ + r_, (256,), w_, b_, ln.eps), ins, g)
+    else:
+        want, want_g = cpu_f64(lambda a_, w_, b_: torch.nn.functional.layer_norm(a_, (256,), w_, b_, ln.eps), ins, g)
     got = ops.layer_norm_residual(a, r, ln)
     got_g = torch.autograd.grad(got, ins, g)
     assert float((got - want).abs().max()) < 2e-5 * max(1.0, float(want.abs().max()))
@@ -419,8 +436,12 @@ def test_edge_mlp_pair_matches_module_path(E):
     nets = [(torch.nn.Linear(64, H, device="cuda"), torch.nn.Linear(H, H, device="cuda")) for H in (32, 64)]
     gk, gv = torch.randn(E, 32, device="cuda"), torch.randn(E, 64, device="cuda")
     params = [p for l1, l2 in nets for p in (l1.weight, l1.bias, l2.weight, l2.bias)]
-    want = [l2(torch.nn.functional.softplus(l1(attr)) - math.log(2.0)) for l1, l2 in nets]
-    want_g = torch.autograd.grad(want, params, [gk, gv])
+    F = torch.nn.functional
+
+    def ref(a, w1k, b1k, w2k, b2k, w1v, b1v, w2v, b2v):       # CP:41-48: Linear -> softplus - ln 2 -> Linear, both nets
+        return [F.linear(F.softplus(F.linear(a, w1k, b1k)) - math.log(2.0), w2k, b2k),
+                F.linear(F.softplus(F.linear(a, w1v, b1v)) - math.log(2.0), w2v, b2v)]
+    want, want_g = cpu_f64(ref, [attr] + params, [gk, gv], wrt=range(1, 9))
     got = ops.edge_mlp_pair(attr, nets[0], nets[1])
     got_g = torch.autograd.grad(list(got), params, [gk, gv])
     for a, b in zip(got, want):
@@ -444,8 +465,9 @@ def test_masked_softmax_matches_torch(S, expanded):
         mask[:, :, 0] = False
     g = torch.randn(B * heads, T, S, device="cuda")
     scale = 1.0 / 32 ** 0.5
-    ref = torch.softmax((s.view(B, heads, T, S) * scale).masked_fill(mask.unsqueeze(1), -1e9), -1).view(B * heads, T, S)
-    ref_g, = torch.autograd.grad(ref, s, g)
+    mask_c = mask.cpu()
+    ref, (ref_g,) = cpu_f64(lambda s_: torch.softmax((s_.view(B, heads, T, S) * scale).masked_fill(mask_c.unsqueeze(1), -1e9), -1)
+                            .view(B * heads, T, S), (s,), g)
     got = ops.masked_softmax(s, mask, scale, heads)
     got_g, = torch.autograd.grad(got, s, g)
     assert float((got - ref).abs().max()) < 1e-6
@@ -473,9 +495,12 @@ def test_attention_matches_torch(T, S, kind):
         mask = torch.zeros(B, 1, S, dtype=torch.bool, device="cuda")
     g = torch.randn(B * heads, T, 64, device="cuda")
     scale = 1.0 / math.sqrt(32)
-    sc = (torch.bmm(q, k.transpose(1, 2)) * scale).view(B, heads, T, S).masked_fill(mask.unsqueeze(1), -1e9)
-    want = torch.bmm(torch.softmax(sc, -1).view(B * heads, T, S), v)
-    want_g = torch.autograd.grad(want, (q, k, v), g)
+    mask_c = mask.cpu()
+
+    def ref(q_, k_, v_):                                   # CP:107-117 / 136-148
+        sc = (torch.bmm(q_, k_.transpose(1, 2)) * scale).view(B, heads, T, S).masked_fill(mask_c.unsqueeze(1), -1e9)
+        return torch.bmm(torch.softmax(sc, -1).view(B * heads, T, S), v_)
+    want, want_g = cpu_f64(ref, (q, k, v), g)
     got = ops.attention(q, k, v, mask, scale, heads)
     got_g = torch.autograd.grad(got, (q, k, v), g)
     assert float((got - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))

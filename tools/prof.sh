@@ -12,7 +12,7 @@ out=gpurun_out/prof_${tag}
 raw=/tmp/prof_raw_${tag}
 mkdir -p $out $raw
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/trace -- python3 bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > $out/trace.log 2>&1 || echo "trace run failed"
-tail -1 $out/trace.log > $out/bench_under_rocprof.json
+grep "^{\"metric" $out/trace.log > $out/bench_under_rocprof.json
 echo "trace done" > $out/progress.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   SINGA_CALIB=1 timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $raw/pmc_$c -- python3 bench.py --workload $wl --eager --steps 2 --warmup 1 --roofline-steps 1 --no-cpu-baseline > $out/pmc_$c.log 2>&1 || echo "pmc $c run failed"
