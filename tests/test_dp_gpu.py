@@ -1,0 +1,71 @@
+"""-m gpu: the data-parallel training step end to end on ONE GPU box: two ranks (two processes sharing the device, gloo
+collectives - RCCL refuses two ranks on one device) run TrainStep with the bucketed all-reduce between the replayed
+forward+backward graph and the optimizer graph, each on its own shard of graphs; the result must equal one process
+training on the union batch (a shard of G graphs is a reference batch of size G; equal token counts ->
+the average of the rank gradients is the global-batch gradient).  Covers what the 8-GPU run does apart from the
+transport: same-seed init check, shard weighting, collective capture decision, replay + eager all-reduce + replay."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KW = dict(n_protein=40, n_ligand=12, e_pp=200, e_ll=24, e_x=30)
+STEPS = 3
+
+
+def _train(rank, world, ids, use_graph):
+    sys.path.insert(0, ROOT)
+    from singa_amd import dp, graph as G
+    from singa_amd.config import load_config
+    from singa_amd.engine import TrainStep
+    from singa_amd.model.GAN import SINGA
+    from singa_amd.optim import Adam
+    torch.manual_seed(11)
+    model = SINGA(load_config(lmax=2), device="cuda").eval()       # dropout off: the ranks must see the same numbers
+    reducer = dp.GradAllReducer(model) if world > 1 else None
+    if reducer:
+        reducer.check_same_init()
+        reducer.set_shard_weight(len(ids), len(ids) * world)
+    eng = TrainStep(model, Adam(model.parameters(), lr=1e-4), reducer, use_graph=use_graph)
+    batch = G.synthetic_batch(len(ids), ids=ids, **KW).to("cuda")
+    losses = [float(eng.step(batch).detach()) for _ in range(STEPS)]
+    probe = {n: p.detach().cpu().clone() for n, p in model.named_parameters()
+             if n in ("model.projection.weight", "embedding.blocks.0.ga.alpha_dot", "embedding.blocks.2.ffn.so3_linear_2.weight")}
+    return losses, probe, (reducer.payload_bytes if reducer else 0)
+
+
+def _worker(rank, world, port, out, use_graph):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    ids = [100, 101] if rank == 0 else [102, 103]
+    res = _train(rank, world, ids, use_graph)
+    torch.save(res, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_two_ranks_equal_one_process_on_the_union_batch(tmp_path, use_graph):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "r")
+    mp.spawn(_worker, args=(2, port, out, use_graph), nprocs=2, join=True)
+    (l0, p0, bytes0), (l1, p1, _) = torch.load(out + ".0"), torch.load(out + ".1")
+    ref_l, ref_p, _ = _train(0, 1, [100, 101, 102, 103], False)
+    assert bytes0 > 90e6                                              # L = 2 model: ~96 MB of gradients per step
+    for n in ref_p:                                                   # both ranks hold the same parameters ...
+        assert torch.equal(p0[n], p1[n]), n
+        d = (p0[n] - ref_p[n]).norm() / (ref_p[n].norm() + 1e-12)     # ... and they are the union-batch parameters
+        assert float(d) < 2e-6, (n, float(d))
+    # the union batch's loss is the mean of the shard losses (equal token counts)
+    for a, b, r in zip(l0, l1, ref_l):
+        assert abs(0.5 * (a + b) - r) < 2e-4 * abs(r), (l0, l1, ref_l)
