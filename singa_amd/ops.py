@@ -805,6 +805,8 @@ def colsum(t):
     reductions (bias gradients of Linear layers, broadcast gradients, `t.sum(0)`) go through a multi-block kernel with
     global semaphores that returned garbage (1e12..1e36) for a few outputs per step under HIP-graph replay on this ROCm
     build; this kernel has no cross-launch state and a fixed summation order."""
+    if t.shape[0] == 0:                       # nothing to add up (an empty edge / node set)
+        return torch.zeros(t.shape[1:], device=t.device, dtype=torch.float32)
     t2 = t.reshape(t.shape[0], -1)
     _dev(t2)
     if t2.stride(1) != 1:

@@ -141,3 +141,22 @@ def test_so3_linear_matches_oracle(L, cin, cout):
             assert rel_err(b.grad.cpu(), sdo["p.bias"].grad) < 1e-5
         finally:
             ops.USE_OWN_GEMM, ops._GEMM_SPLIT_ROWS = True, 2048
+
+
+def test_so2_and_so3_linear_on_empty_inputs():
+    """An edge type without edges / a node type without nodes (possible in real batches): empty outputs, zero weight
+    gradients, no launch."""
+    from singa_amd import ops
+    X = torch.zeros(0, 96, device=DEV, requires_grad=True)
+    w0, b0 = torch.randn(40, 48, device=DEV, requires_grad=True), torch.randn(40, device=DEV, requires_grad=True)
+    w1, w2 = torch.randn(32, 32, device=DEV, requires_grad=True), torch.randn(16, 16, device=DEV, requires_grad=True)
+    h0, h1, h2 = ops.so2_linear3(X, w0, b0, w1, w2, 48, 32)
+    assert h0.shape == (0, 40) and h1.shape == (0, 32) and h2.shape == (0, 16)
+    (h0.sum() + h1.sum() + h2.sum()).backward()
+    assert float(w0.grad.abs().max()) == 0.0 and float(w2.grad.abs().max()) == 0.0 and float(b0.grad.abs().max()) == 0.0
+    x = torch.zeros(0, 9, 16, device=DEV, requires_grad=True)
+    w, b = torch.randn(3, 32, 16, device=DEV, requires_grad=True), torch.randn(32, device=DEV, requires_grad=True)
+    y = ops.so3_linear(x, w, b, 2)
+    assert y.shape == (0, 9, 32)
+    y.sum().backward()
+    assert float(w.grad.abs().max()) == 0.0
