@@ -89,9 +89,15 @@ struct SegsMut {
     int rows[3];
 };
 
-__device__ __forceinline__ float silu(float u) { return u / (1.0f + __expf(-u)); }
+// v_rcp_f32 (1 ulp) for the sigmoids: `1.0f / x` and `__frcp_rn` are the correctly rounded reciprocal, i.e. the
+// ten-instruction IEEE division sequence (div_scale / rcp / fma x 4 / div_fmas / div_fixup) - 28 % of the S2 kernel's
+// instructions before this
+#ifndef SINGA_RCP
+#define SINGA_RCP(x) __builtin_amdgcn_rcpf(x)
+#endif
+__device__ __forceinline__ float silu(float u) { return u * SINGA_RCP(1.0f + __expf(-u)); }
 __device__ __forceinline__ float silu_grad(float u) {
-    float s = 1.0f / (1.0f + __expf(-u));
+    float s = SINGA_RCP(1.0f + __expf(-u));
     return s * (1.0f + u * (1.0f - s));
 }
 
@@ -513,9 +519,9 @@ __device__ __forceinline__ float half_sum(float v) {
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-__device__ __forceinline__ float smooth_leaky(float a) { return 0.6f * a + 0.4f * a * (2.0f / (1.0f + __expf(-a)) - 1.0f); }
+__device__ __forceinline__ float smooth_leaky(float a) { return 0.6f * a + 0.4f * a * (2.0f * SINGA_RCP(1.0f + __expf(-a)) - 1.0f); }
 __device__ __forceinline__ float smooth_leaky_grad(float a) {
-    const float sg = 1.0f / (1.0f + __expf(-a));
+    const float sg = SINGA_RCP(1.0f + __expf(-a));
     return 0.2f + 0.8f * sg + 0.8f * a * sg * (1.0f - sg);
 }
 
@@ -1100,7 +1106,7 @@ __global__ void __launch_bounds__(256) bias_ssp_bwd_kernel(const float* __restri
     const float4 v = *reinterpret_cast<const float4*>(u + i * 4);
     const float4 bb = *reinterpret_cast<const float4*>(b + c);
     const float4 gg = *reinterpret_cast<const float4*>(g + i * 4);
-    auto s = [](float x) { return 1.f / (1.f + __expf(-x)); };
+    auto s = [](float x) { return SINGA_RCP(1.f + __expf(-x)); };
     *reinterpret_cast<float4*>(gu + i * 4) = make_float4(gg.x * s(v.x + bb.x), gg.y * s(v.y + bb.y), gg.z * s(v.z + bb.z),
                                                          gg.w * s(v.w + bb.w));
 }
@@ -1612,7 +1618,7 @@ __global__ void __launch_bounds__(256, 2) edge_mlp_mfma_bwd_kernel(const float* 
         for (int r = 0; r < 16; ++r) {
             const int j = 8 * (r >> 2) + 4 * half + (r & 3);
             const float p = pacc[r];
-            const float sg = 1.f / (1.f + __expf(-p));
+            const float sg = SINGA_RCP(1.f + __expf(-p));
             th[i * LD + j] = ok ? ssp_fast(p) : 0.f;
             tg[i * LD + j] = ok ? gacc[r] * sg : 0.f;
         }
@@ -2266,9 +2272,9 @@ constexpr FourTab<RA, MM> make_four_tab() {
         }
     return t;
 }
-__device__ __forceinline__ float silu_fast(float u) { return u * __frcp_rn(1.0f + __expf(-u)); }
+__device__ __forceinline__ float silu_fast(float u) { return u * SINGA_RCP(1.0f + __expf(-u)); }
 __device__ __forceinline__ float silu_grad_fast(float u) {
-    const float sg = __frcp_rn(1.0f + __expf(-u));
+    const float sg = SINGA_RCP(1.0f + __expf(-u));
     return sg * (1.0f + u * (1.0f - sg));
 }
 

@@ -42,6 +42,7 @@ static inline hipError_t hipMemcpyToSymbol(T& sym, const void* src, size_t n, si
 }
 #define __expf(x) expf(x)
 static inline float __frcp_rn(float x) { return 1.0f / x; }
+#define SINGA_RCP(x) (1.0f / (x))
 #define __logf(x) logf(x)
 static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 enum { hipErrorInvalidValue = 1 };
