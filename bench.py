@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--cpu-graphs", type=int, default=8, help="graphs in the bounded CPU-oracle sample")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-state", type=str, default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -149,7 +150,7 @@ def host_cores():
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (oracle)
-def cpu_baseline_worker(workload, n_graphs, threads):
+def cpu_baseline_worker(workload, n_graphs, threads, state=None):
     """Runs in a child process that never touches the GPU: times the CPU oracle (kind 'port':
     oracle/singa_oracle.py, pinned to the reference by tests/golden) on a bounded sample of the same workload -
     forward + CrossEntropy + backward of the first `n_graphs` synthetic graphs - and prints one JSON object."""
@@ -164,6 +165,8 @@ def cpu_baseline_worker(workload, n_graphs, threads):
     cfg = load_config(lmax=L)
     torch.manual_seed(cfg.train.seed)
     model = SINGA(cfg, device="cpu")          # parameter container only; the product forward is never called here
+    if state:                                 # the GPU run's initial parameters (drawn with the device generator there)
+        model.load_state_dict(torch.load(state, map_location="cpu"))
     graphs = [G.synthetic_graph(i, **G.graph_sizes(i, **kw)) for i in range(n_graphs)]
     b, rots, lap_p, lap_l = O.batch_from_graphs(graphs)
     sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
@@ -176,17 +179,18 @@ def cpu_baseline_worker(workload, n_graphs, threads):
         loss.backward()
         times.append(time.perf_counter() - t0)
         print(f"[cpu-baseline] pass {it}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
-    print(json.dumps({"value": round(n_graphs / times[-1], 4), "unit": "graphs/s", "cores": threads, "kind": "port",
+    print(json.dumps({"loss": float(loss.detach()),
+                      "value": round(n_graphs / times[-1], 4), "unit": "graphs/s", "cores": threads, "kind": "port",
                       "sample": f"first {n_graphs} graphs of {workload}: oracle forward+CE+backward (no Adam), "
                                 f"{threads} torch threads, {times[-1]:.1f} s"}), flush=True)
 
 
-def cpu_baseline(workload, n_graphs, limit_s=300):
+def cpu_baseline(workload, n_graphs, limit_s=300, state=None):
     threads = host_cores()
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads),
                MKL_NUM_THREADS=str(threads))
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--workload", workload, "--cpu-graphs",
-           str(n_graphs), "--cpu-threads", str(threads)]
+           str(n_graphs), "--cpu-threads", str(threads)] + (["--cpu-state", state] if state else [])
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=limit_s, check=True)
         return json.loads(r.stdout.decode().strip().splitlines()[-1])
@@ -213,7 +217,7 @@ def spawn_ranks(n):
 def main():
     args = parse()
     if args.cpu_baseline_worker:
-        return cpu_baseline_worker(args.workload, args.cpu_graphs, args.cpu_threads or host_cores())
+        return cpu_baseline_worker(args.workload, args.cpu_graphs, args.cpu_threads or host_cores(), args.cpu_state)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -286,6 +290,22 @@ def main():
     bucket = use_graph and D > 1
     engine = TrainStep(model, opt, reducer if world > 1 else None, use_graph=use_graph,
                        max_grad_norm=float(cfg.train.max_grad_norm), bucket=bucket, growth=args.growth, max_cached=4)
+    # the HIP path's loss on the CPU-baseline sample (the first graphs of the workload, initial parameters, dropout off):
+    # compared below with the loss the oracle computes on the same graphs while it is being timed
+    hip_sample_loss = state_file = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import tempfile
+        state_file = os.path.join(tempfile.mkdtemp(prefix="singa_bench_"), "init_state.pt")
+        torch.save({k: v.cpu() for k, v in model.state_dict().items()}, state_file)
+        sample = G.synthetic_batch(args.cpu_graphs, ids=list(range(args.cpu_graphs)), **kw).to(dev)
+        model.eval()
+        with torch.no_grad():
+            EF_layers._edge_cache.clear()
+            model.prepare(sample)
+            lg = model(sample)
+            hip_sample_loss = float(torch.nn.functional.cross_entropy(lg, sample["ligand_data"]["smiIndices_tgt"].reshape(-1)))
+        model.train()
+        del sample, lg
     n_nodes = batch[G.PA]["x"].shape[0] + batch[G.LA]["x"].shape[0]
     n_edges = sum(int(batch[et]["edge_index"].shape[1]) for et in (G.E_PP, G.E_LL, G.E_LP, G.E_PL))
     log(f"workload {args.workload}: {len(ids)} graphs on this GPU ({n_nodes} atoms, {n_edges} edges), L={L}, generated in "
@@ -418,7 +438,16 @@ def main():
                "final_loss": round(final_loss, 5), "roofline": roof}
         if not args.no_cpu_baseline and world == 1:
             log("timing the CPU oracle on the bounded sample ...")
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_graphs)
+            cb = cpu_baseline(args.workload, args.cpu_graphs, state=state_file)
+            if state_file:
+                import shutil
+                shutil.rmtree(os.path.dirname(state_file), ignore_errors=True)
+            lo = cb.pop("loss", None)
+            out["cpu_baseline"] = cb
+            if lo is not None and hip_sample_loss is not None:
+                out["oracle_check"] = {"what": f"CrossEntropy of the first {args.cpu_graphs} graphs at the initial parameters, "
+                                               "dropout off: HIP path vs CPU oracle", "loss_hip": round(hip_sample_loss, 6),
+                                       "loss_oracle": round(lo, 6), "rel_diff": abs(hip_sample_loss - lo) / abs(lo)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

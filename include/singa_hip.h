@@ -249,6 +249,18 @@ int singa_so3_rmsnorm_bwd(const float* x, const float* weight, const float* gy, 
 long long singa_colsum_work(long long M, int n);
 int singa_colsum(const float* x, long long ld, long long M, int n, float* work, float* out, void* stream);
 
+/* The parameter-gradient reductions of one backward pass in two launches per 36 jobs (replaces one torch `sum(0)` /
+ * AccumulateGrad pair per parameter: torch/autograd, used by every bias / affine / split-GEMM weight gradient of
+ * model/EF_layers.py and model/CProMG.py).  Job k adds the column sums of x[k] [M[k], n[k]] (row stride ld[k]) INTO its
+ * destination segments: segments job_seg0[k] .. job_seg0[k+1]-1 (the last job ends at n_segs); segment q receives columns
+ * seg_col0[q] .. (next segment's col0 or n[k]) - 1 at seg_dst[q][column - seg_col0[q]].  The first segment of a job
+ * starts at column 0, col0 ascends.  The tables are host memory and are consumed by the call (they ride in the kernel
+ * arguments, so a captured launch needs no copy).  work: sum over jobs of singa_colsum_multi_work(M, n) floats. */
+long long singa_colsum_multi_work(long long M, int n);
+int singa_colsum_multi(int n_jobs, const float* const* x, const long long* ld, const long long* M, const int* n,
+                       const int* job_seg0, int n_segs, const int* seg_col0, float* const* seg_dst, float* work,
+                       long long work_floats, void* stream);
+
 /* Adam step of train.py:127 (torch.optim.Adam: lr, betas, eps; no weight decay) for ALL parameter tensors in one launch.
  * p/g/m/v: DEVICE arrays of device pointers (one per tensor); sizes[t] = elements of tensor t; (chunk_tensor, chunk_off)
  * [nchunks]: the flattened work list, `chunk` elements each; step (float, number of steps taken) and lr live in device

@@ -2048,6 +2048,104 @@ __global__ void colsum_pass_kernel(const float* __restrict__ x, long long ld, lo
 }
 
 
+// Many column sums in two launches (the parameter-gradient reductions of one backward pass, singa_colsum_multi): the job
+// table travels in the kernel arguments, so a captured launch carries it without a host-to-device copy.  Job k reduces
+// x_k [M, n] over its rows; column j is ADDED to dst[j - col0] of the segment that holds it (a job feeds several
+// parameter gradients when its columns are [d gamma | d beta | ...]).  Pass 1: one thread per (slab of R rows, column),
+// as colsum_pass_kernel; jobs with a single slab finish there.  Pass 2: one thread per column adds the <= COLSUM_R slab
+// partials in slab order.  Each gradient element is touched by exactly one thread per launch: fixed summation order.
+constexpr int COLSUM_MJ = 36;     // jobs per launch
+constexpr int COLSUM_MS = 72;     // destination segments per launch
+
+struct ColsumJob {
+    const float* x;
+    float* work;          // [slabs, n] partials (unused when slabs == 1)
+    long long ld;
+    int M, n, R, slabs;
+    int blk1, blk2;       // first block of this job in pass 1 / pass 2
+    int seg0, nseg;
+};
+struct ColsumSeg {
+    float* dst;
+    int col0;
+    int pad_;
+};
+struct ColsumBatch {
+    ColsumJob job[COLSUM_MJ];
+    ColsumSeg seg[COLSUM_MS];
+    int n_jobs;
+};
+static_assert(sizeof(ColsumBatch) <= 3968, "the job table must fit the kernel-argument segment");
+
+__device__ inline void colsum_multi_emit(const ColsumBatch& b, const ColsumJob& jb, int j, float v) {
+    int s = jb.seg0;
+    for (int k = 1; k < jb.nseg; ++k)
+        if (j >= b.seg[jb.seg0 + k].col0) s = jb.seg0 + k;
+    float* d = b.seg[s].dst + (j - b.seg[s].col0);
+    *d += v;
+}
+
+__global__ void __launch_bounds__(256) colsum_multi_pass1_kernel(const ColsumBatch b) {
+    int k = 0;
+    for (int q = 1; q < b.n_jobs; ++q)
+        if ((int)blockIdx.x >= b.job[q].blk1) k = q;
+    const ColsumJob& jb = b.job[k];
+    const long long t = (long long)((int)blockIdx.x - jb.blk1) * 256 + threadIdx.x;
+    if (t >= (long long)jb.slabs * jb.n) return;
+    const int slab = (int)(t / jb.n);
+    const int j = (int)(t - (long long)slab * jb.n);
+    const long long r0 = (long long)slab * jb.R;
+    const long long r1 = r0 + jb.R < jb.M ? r0 + jb.R : jb.M;
+    const float* __restrict__ x = jb.x;
+    const long long ld = jb.ld;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+    long long i = r0;
+    for (; i + 7 < r1; i += 8) {
+        a0 += x[i * ld + j];
+        a1 += x[(i + 1) * ld + j];
+        a2 += x[(i + 2) * ld + j];
+        a3 += x[(i + 3) * ld + j];
+        a4 += x[(i + 4) * ld + j];
+        a5 += x[(i + 5) * ld + j];
+        a6 += x[(i + 6) * ld + j];
+        a7 += x[(i + 7) * ld + j];
+    }
+    for (; i < r1; ++i) a0 += x[i * ld + j];
+    const float v = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    if (jb.slabs == 1)
+        colsum_multi_emit(b, jb, j, v);
+    else
+        jb.work[(long long)slab * jb.n + j] = v;
+}
+
+__global__ void __launch_bounds__(256) colsum_multi_pass2_kernel(const ColsumBatch b) {
+    int k = 0;
+    for (int q = 1; q < b.n_jobs; ++q)
+        if ((int)blockIdx.x >= b.job[q].blk2) k = q;
+    const ColsumJob& jb = b.job[k];
+    if (jb.slabs == 1) return;
+    const int j = ((int)blockIdx.x - jb.blk2) * 256 + threadIdx.x;
+    if (j >= jb.n) return;
+    const float* __restrict__ w = jb.work;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int s = 0;
+    for (; s + 3 < jb.slabs; s += 4) {
+        a0 += w[(long long)s * jb.n + j];
+        a1 += w[(long long)(s + 1) * jb.n + j];
+        a2 += w[(long long)(s + 2) * jb.n + j];
+        a3 += w[(long long)(s + 3) * jb.n + j];
+    }
+    for (; s < jb.slabs; ++s) a0 += w[(long long)s * jb.n + j];
+    colsum_multi_emit(b, jb, j, (a0 + a1) + (a2 + a3));
+}
+
+// rows per slab of one job: a power of two >= 16 that leaves at most COLSUM_R slabs
+static inline int colsum_multi_r(long long M) {
+    long long r = 16;
+    while ((M + r - 1) / r > COLSUM_R) r <<= 1;
+    return (int)r;
+}
+
 // ------------------------------------------------------------------------------------------------ fused Adam
 // One launch updates every parameter tensor (torch.optim.Adam semantics, no weight decay / amsgrad): block b handles
 // chunk b of the flattened (tensor, offset) table.  The step count and the learning rate live in device memory so the
@@ -3701,6 +3799,70 @@ int singa_colsum(const float* x, long long ld, long long M, int n, float* work, 
         R = COLSUM_R;
     }
     return check_launch("colsum");
+}
+
+long long singa_colsum_multi_work(long long M, int n) {
+    if (M <= 0 || n <= 0) return 0;
+    const int r = colsum_multi_r(M);
+    const long long slabs = (M + r - 1) / r;
+    return slabs > 1 ? slabs * (long long)n : 0;
+}
+
+int singa_colsum_multi(int n_jobs, const float* const* x, const long long* ld, const long long* M, const int* n,
+                       const int* job_seg0, int n_segs, const int* seg_col0, float* const* seg_dst, float* work,
+                       long long work_floats, void* stream) {
+    if (n_jobs < 0 || n_segs < 0) return fail(SINGA_E_SHAPE, "colsum_multi: negative count");
+    if (n_jobs == 0) return SINGA_OK;
+    if (!x || !ld || !M || !n || !job_seg0 || !seg_col0 || !seg_dst) return fail(SINGA_E_NULL, "colsum_multi: null table");
+    long long woff = 0;
+    int k = 0;
+    while (k < n_jobs) {
+        ColsumBatch b;
+        memset(&b, 0, sizeof(b));
+        int nj = 0, ns = 0, blk1 = 0, blk2 = 0;
+        while (k < n_jobs && nj < COLSUM_MJ) {
+            const int s0 = job_seg0[k], s1 = k + 1 < n_jobs ? job_seg0[k + 1] : n_segs;
+            if (s0 < 0 || s1 <= s0 || s1 > n_segs || s1 - s0 > COLSUM_MS) return fail(SINGA_E_SHAPE, "colsum_multi: bad segment table");
+            if (ns + (s1 - s0) > COLSUM_MS) break;
+            if (M[k] <= 0 || n[k] <= 0) { ++k; continue; }          // nothing to add
+            if (!x[k] || M[k] > 0x7fffffffLL) return fail(SINGA_E_SHAPE, "colsum_multi: bad job");
+            ColsumJob& jb = b.job[nj];
+            jb.x = x[k];
+            jb.ld = ld[k];
+            jb.M = (int)M[k];
+            jb.n = n[k];
+            jb.R = colsum_multi_r(M[k]);
+            jb.slabs = (int)((M[k] + jb.R - 1) / jb.R);
+            jb.blk1 = blk1;
+            jb.blk2 = blk2;
+            jb.seg0 = ns;
+            jb.nseg = s1 - s0;
+            for (int q = s0; q < s1; ++q) {
+                if (!seg_dst[q] || seg_col0[q] < 0 || seg_col0[q] >= n[k] || (q > s0 && seg_col0[q] <= seg_col0[q - 1]) ||
+                    (q == s0 && seg_col0[q] != 0))
+                    return fail(SINGA_E_SHAPE, "colsum_multi: segments must start at column 0 and ascend");
+                b.seg[ns].dst = seg_dst[q];
+                b.seg[ns].col0 = seg_col0[q];
+                ++ns;
+            }
+            if (jb.slabs > 1) {
+                const long long need = (long long)jb.slabs * jb.n;
+                if (!work || woff + need > work_floats) return fail(SINGA_E_SHAPE, "colsum_multi: workspace too small");
+                jb.work = work + woff;
+                woff += need;
+                blk2 += (jb.n + 255) / 256;
+            }
+            blk1 += (int)(((long long)jb.slabs * jb.n + 255) / 256);
+            ++nj;
+            ++k;
+        }
+        if (nj == 0) continue;
+        b.n_jobs = nj;
+        hipLaunchKernelGGL(colsum_multi_pass1_kernel, dim3((unsigned)blk1), dim3(256), 0, (hipStream_t)stream, b);
+        if (blk2 > 0)
+            hipLaunchKernelGGL(colsum_multi_pass2_kernel, dim3((unsigned)blk2), dim3(256), 0, (hipStream_t)stream, b);
+    }
+    return check_launch("colsum_multi");
 }
 
 int singa_so3_rmsnorm_nparts(int N) { return grid_for(N, 2048); }

@@ -11,7 +11,7 @@ import math
 
 import torch
 
-from . import graph as G
+from . import graph as G, ops
 from .graph import E_LL, E_LP, E_PL, E_PP, LA, PA
 from .model import EF_layers
 
@@ -88,7 +88,7 @@ class TrainStep:
     kept side by side.  Without it a batch whose shapes differ from the capture triggers a re-capture."""
 
     def __init__(self, model, optimizer, reducer=None, use_graph=True, max_grad_norm=float("inf"), bucket=False,
-                 growth=1.08, max_cached=3):
+                 growth=1.08, max_cached=3, direct_grads=True):
         self.model, self.opt, self.reducer = model, optimizer, reducer
         self.use_graph, self.max_grad_norm = use_graph, max_grad_norm
         self.crit = torch.nn.CrossEntropyLoss()
@@ -102,6 +102,8 @@ class TrainStep:
         self._knn_cap = {}                 # (class, node type) -> kNN edge capacity
         self._slots = {}                   # signature -> captured state (insertion order = recency)
         self._active = None
+        self.direct_grads = direct_grads   # see _fwd_bwd
+        self._sink_params = None           # parameters whose gradients are accumulated in place (found in the first step)
 
     # ------------------------------------------------------------------------------------------------ size classes
     def _class_caps(self, sizes):
@@ -151,9 +153,33 @@ class TrainStep:
 
     # ------------------------------------------------------------------------------------------------ eager pieces
     def _fwd_bwd(self, batch):
-        logits = self.model(batch)
-        loss = self.crit(logits, batch["ligand_data"]["smiIndices_tgt"].reshape(-1))
-        loss.backward()
+        """Forward, CrossEntropy, backward.  Parameter gradients that are column sums (biases, affine parameters,
+        split-reduction weight gradients) or small transposed products are accumulated straight into `.grad` buffers
+        (ops._GradSink): the first call only records which parameters are produced that way; afterwards their buffers
+        are zeroed in one multi-tensor launch, the backward functions queue / accumulate into them and one launch pair
+        reduces the whole queue (instead of two reductions and an add per parameter)."""
+        sink = ops._GradSink
+        if not self.direct_grads:
+            sink.on, sink.found = False, None
+        elif self._sink_params is None:
+            sink.on, sink.found = False, {}
+        else:
+            for p in self._sink_params:
+                if p.grad is None:
+                    p.grad = torch.empty_like(p, memory_format=torch.contiguous_format)
+            if self._sink_params:
+                torch._foreach_zero_([p.grad for p in self._sink_params])
+            sink.on, sink.found = True, None
+        try:
+            logits = self.model(batch)
+            loss = self.crit(logits, batch["ligand_data"]["smiIndices_tgt"].reshape(-1))
+            loss.backward()
+            if sink.on:
+                sink.flush()
+            elif sink.found is not None:
+                self._sink_params = list(sink.found.values())
+        finally:
+            sink.on, sink.found, sink.jobs = False, None, []
         return loss
 
     def _update(self):

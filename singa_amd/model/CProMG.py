@@ -211,9 +211,8 @@ class MultiHeadAttention(nn.Module):
 
     def _grouped(self, conv, h):
         N, heads = h.shape[0], self.num_heads
-        w = conv.weight[:, :, 0]
-        og, ig = w.shape[0] // heads, w.shape[1]
-        return ops.grouped_linear(h, w.view(heads, og, ig))
+        # the Conv1d weight [heads*og, ig, 1] as it is (a `[:, :, 0]` select would cost a zero-fill and a copy backward)
+        return ops.grouped_linear(h, conv.weight, heads)
 
     def _edge_mlp(self, net, x):
         # first Linear as a plain GEMM, its bias inside the activation kernel (one pass instead of three)
@@ -303,8 +302,8 @@ class PoswiseFeedForwardNet(nn.Module):
         self.batch_norm = BatchNorm1d(hidden_channels, device=device)
 
     def forward(self, inputs):
-        h = F.relu(ops.linear(inputs, self.conv1.weight[:, :, 0], self.conv1.bias))
-        return ops.layer_norm_residual(ops.linear(h, self.conv2.weight[:, :, 0], self.conv2.bias), inputs, self.layer_norm)
+        h = F.relu(ops.linear(inputs, self.conv1.weight, self.conv1.bias))
+        return ops.layer_norm_residual(ops.linear(h, self.conv2.weight, self.conv2.bias), inputs, self.layer_norm)
 
 
 class PoswiseFeedForwardDeNet(nn.Module):
@@ -315,8 +314,8 @@ class PoswiseFeedForwardDeNet(nn.Module):
         self.layer_norm = LayerNorm(hidden_channels, device=device)
 
     def forward(self, inputs):
-        h = F.relu(ops.linear(inputs, self.conv1.weight[:, :, 0], self.conv1.bias))
-        return ops.layer_norm_residual(ops.linear(h, self.conv2.weight[:, :, 0], self.conv2.bias), inputs, self.layer_norm)
+        h = F.relu(ops.linear(inputs, self.conv1.weight, self.conv1.bias))
+        return ops.layer_norm_residual(ops.linear(h, self.conv2.weight, self.conv2.bias), inputs, self.layer_norm)
 
 
 class PositionalEncoding(nn.Module):

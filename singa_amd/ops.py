@@ -358,6 +358,7 @@ class _EdgeHead(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h0, h1, h2, ln_w, ln_b, dot, heads, A, C, L, M, eps):
+        ctx.params = (ln_w, ln_b, dot)
         h0, h1, h2 = _rows(h0), _rows(h1), _rows(h2)
         ln_w, ln_b, dot = ln_w.contiguous(), ln_b.contiguous(), dot.contiguous()
         _dev(h0, h1, h2, ln_w, ln_b, dot)
@@ -393,7 +394,10 @@ class _EdgeHead(torch.autograd.Function):
         part = torch.empty(nslots, (2 + heads) * A, device=h0.device, dtype=torch.float32)
         _chk(lib.singa_alpha_logits_bwd(_p(h0), h0.stride(0), _p(ln_w), _p(ln_b), _p(dot), _p(g_logits), _p(g_alpha_in),
                                         _p(part), E, heads, A, eps, _stream()), "singa_alpha_logits_bwd")
-        pg = colsum(part)
+        pw, pb, pd = ctx.params
+        g_lnw, g_lnb, g_dot = param_colsum(part, [(0, A, pw), (A, A, pb), (2 * A, heads * A, pd)])
+        if g_dot is not None:
+            g_dot = g_dot.view(heads, A)
         P, Q, Az = _grid_factors(L, M, True, h0.device)
         gx = torch.empty(E, lay.KR * C, device=h0.device, dtype=torch.float32)
         gg = torch.empty(E, C, device=h0.device, dtype=torch.float32)
@@ -404,8 +408,7 @@ class _EdgeHead(torch.autograd.Function):
                                      _p(Az), _p(g_act), _p(gx), _p(gg), E, C, L, _stream()), "singa_s2act_sep_bwd")
         n0, n1 = lay.seg_rows[0] * C, lay.seg_rows[1] * C
         g_h0 = torch.cat([g_alpha_in, gg, gx[:, :n0]], 1)
-        return (g_h0, gx[:, n0:n0 + n1], gx[:, n0 + n1:], pg[:A], pg[A:2 * A], pg[2 * A:].view(heads, A),
-                None, None, None, None, None, None)
+        return (g_h0, gx[:, n0:n0 + n1], gx[:, n0 + n1:], g_lnw, g_lnb, g_dot, None, None, None, None, None, None)
 
 
 def edge_head(h0, h1, h2, ln_w, ln_b, alpha_dot, heads, A, C, L, M=2, eps=1e-5):
@@ -472,6 +475,7 @@ def _degree_index(L, device):
 class _SO3RMSNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, L, eps):
+        ctx.params = (weight, bias)
         x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
         _dev(x, weight, bias)
         N, K, C = x.shape
@@ -495,7 +499,7 @@ class _SO3RMSNorm(torch.autograd.Function):
         _chk(_lib.lib().singa_so3_rmsnorm_bwd(_p(x), _p(weight), _p(gy), _p(gx), _p(gwp), _p(gbp), N, C, L, eps,
                                               _stream()), "singa_so3_rmsnorm_bwd")
         gw = _degree_onehot(L, x.device) @ colsum(gwp)
-        return gx, gw, colsum(gbp), None, None
+        return gx, gw, param_colsum(gbp, [(0, C, ctx.params[1])])[0], None, None
 
 
 def so3_rmsnorm(x, weight, bias, L, eps=1e-5):
@@ -569,6 +573,7 @@ def gather_wsum(alpha, wv, hv, edges):
 class _LnSilu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
+        ctx.params = (gamma, beta)
         x, gamma, beta = x.contiguous(), gamma.contiguous(), beta.contiguous()
         _dev(x, gamma, beta)
         C = x.shape[-1]
@@ -590,8 +595,8 @@ class _LnSilu(torch.autograd.Function):
         part = torch.empty(lib.singa_ln_silu_nparts(M), 2 * C, device=x.device, dtype=torch.float32)
         _chk(lib.singa_ln_silu_bwd(_p(x), _p(gamma), _p(beta), _p(g), _p(gx), _p(part), M, C, ctx.eps, _stream()),
              "singa_ln_silu_bwd")
-        gg = colsum(part)
-        return gx, gg[:C], gg[C:], None
+        gg, gb = param_colsum(part, [(0, C, ctx.params[0]), (C, C, ctx.params[1])])
+        return gx, gg, gb, None
 
 
 def ln_silu(x, gamma, beta, eps=1e-5):
@@ -693,6 +698,7 @@ def attention(q, k, v, mask, scale, heads):
 class _LayerNorm256(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, r, gamma, beta, eps):
+        ctx.params = (gamma, beta)
         a = a.contiguous()
         r = r.contiguous() if r is not None else None
         gamma, beta = gamma.contiguous(), beta.contiguous()
@@ -715,8 +721,8 @@ class _LayerNorm256(torch.autograd.Function):
         part = torch.empty(lib.singa_ln256_nparts(M), 512, device=a.device, dtype=torch.float32)
         _chk(lib.singa_ln256_bwd(_p(a), _p(r) if r is not None else None, _p(gamma), _p(g), _p(gs), _p(part), M, 256, ctx.eps,
                                  _stream()), "singa_ln256_bwd")
-        gg = colsum(part)
-        return gs, (gs if r is not None else None), gg[:256], gg[256:], None
+        gg, gb = param_colsum(part, [(0, 256, ctx.params[0]), (256, 256, ctx.params[1])])
+        return gs, (gs if r is not None else None), gg, gb, None
 
 
 def layer_norm_residual(a, r, ln):
@@ -730,6 +736,7 @@ def layer_norm_residual(a, r, ln):
 class _BiasSsp(torch.autograd.Function):
     @staticmethod
     def forward(ctx, u, b):
+        ctx.param = b
         u, b = u.contiguous(), b.contiguous()
         _dev(u, b)
         n = u.shape[-1]
@@ -745,7 +752,7 @@ class _BiasSsp(torch.autograd.Function):
         n = u.shape[-1]
         gu = torch.empty_like(u)
         _chk(_lib.lib().singa_bias_ssp_bwd(_p(u), _p(b), _p(g), _p(gu), u.numel() // n, n, _stream()), "singa_bias_ssp_bwd")
-        return gu, colsum(gu.reshape(-1, n))
+        return gu, param_colsum(gu.reshape(-1, n), [(0, n, ctx.param)])[0]
 
 
 def bias_ssp(u, b):
@@ -819,14 +826,108 @@ def colsum(t):
     return out.view(t.shape[1:])
 
 
+class _GradSink:
+    """Direct accumulation of parameter gradients (TrainStep turns it on around its backward pass).  A backward function
+    whose output is the gradient of a leaf parameter that already owns a `.grad` buffer does not return it to autograd
+    (which would launch one AccumulateGrad add per parameter on top of the reduction that produced it): column-sum
+    reductions are queued and run as ONE multi-job launch pair that adds into the `.grad` buffers
+    (singa_colsum_multi), GEMM-shaped weight gradients accumulate in the GEMM itself (beta = 1).  `flush()` must run after
+    the backward pass and before anything reads the gradients.  Off (the default): every backward returns its gradients."""
+    on = False
+    found = None       # a dict while the engine records which parameters are produced by sink-aware backward functions
+    jobs = []          # (src [M, n] kept alive until the flush, [(col0, flat .grad view)])
+
+    @staticmethod
+    def takes(*params):
+        """True when every given parameter can receive its gradient directly."""
+        if _GradSink.found is not None:
+            for p in params:
+                if p is not None and p.is_leaf and p.requires_grad:
+                    _GradSink.found[id(p)] = p
+        if not _GradSink.on:
+            return False
+        for p in params:
+            if p is None or not (p.is_leaf and p.requires_grad) or p.grad is None or not p.grad.is_contiguous():
+                return False
+        return True
+
+    @staticmethod
+    def flush():
+        jobs, _GradSink.jobs = _GradSink.jobs, []
+        jobs = [j for j in jobs if j[0].shape[0] > 0 and j[0].shape[1] > 0]
+        if not jobs:
+            return
+        # jobs of one call run concurrently, so two jobs that add into the same buffer (a parameter used several times
+        # per forward pass) go to different rounds, in queue order: a fixed summation order, no atomics
+        seen, rounds = {}, []
+        for job in jobs:
+            r = max(seen.get(g.data_ptr(), 0) for _, g in job[1])
+            for _, g in job[1]:
+                seen[g.data_ptr()] = r + 1
+            while len(rounds) <= r:
+                rounds.append([])
+            rounds[r].append(job)
+        lib = _lib.lib()
+        for jobs in rounds:
+            nj = len(jobs)
+            ns = sum(len(j[1]) for j in jobs)
+            xs, lds, Ms, ns_ = ((ctypes.c_void_p * nj)(), (ctypes.c_longlong * nj)(), (ctypes.c_longlong * nj)(),
+                                (ctypes.c_int * nj)())
+            seg0, col0, dst = (ctypes.c_int * nj)(), (ctypes.c_int * ns)(), (ctypes.c_void_p * ns)()
+            q = total = 0
+            for k, (src, segs) in enumerate(jobs):
+                xs[k], lds[k], Ms[k], ns_[k], seg0[k] = src.data_ptr(), src.stride(0), src.shape[0], src.shape[1], q
+                total += lib.singa_colsum_multi_work(src.shape[0], src.shape[1])
+                for c0, g in segs:
+                    col0[q], dst[q] = c0, g.data_ptr()
+                    q += 1
+            work = torch.empty(max(total, 1), device=jobs[0][0].device, dtype=torch.float32)
+            _chk(lib.singa_colsum_multi(nj, xs, lds, Ms, ns_, seg0, ns, col0, dst, _p(work), total, _stream()),
+                 "singa_colsum_multi")
+
+
+def param_colsum(src, targets):
+    """Column sums of src [M, n] split over parameters: targets = [(col0, ncols, param)] covering 0..n in order.  Returns
+    one gradient per target - None where the sum was queued to be added straight into param.grad (_GradSink).  Runs of
+    neighbouring targets of the same kind share one job / one immediate reduction."""
+    src = src.reshape(src.shape[0], -1)
+    if src.stride(1) != 1:
+        src = src.contiguous()
+    direct = [src.shape[0] > 0 and _GradSink.takes(t[2]) for t in targets]
+    out = [None] * len(targets)
+    i = 0
+    while i < len(targets):
+        j = i
+        while j + 1 < len(targets) and direct[j + 1] == direct[i]:
+            j += 1
+        c0, c1 = targets[i][0], targets[j][0] + targets[j][1]
+        blk = src[:, c0:c1]
+        if direct[i]:
+            _GradSink.jobs.append((blk, [(t[0] - c0, t[2].grad) for t in targets[i:j + 1]]))
+        else:
+            tot = colsum(blk)
+            for k in range(i, j + 1):
+                out[k] = tot[targets[k][0] - c0: targets[k][0] - c0 + targets[k][1]]
+        i = j + 1
+    return out
+
+
+def _mm_acc(out, a, b):
+    """out += a @ b (beta = 1 in the GEMM)."""
+    with _blas(a.shape[0], b.shape[1], a.shape[1], b.stride(0) == 1 and b.stride(1) != 1):
+        out.addmm_(a, b)
+
+
 class _BiasAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, b):
+        ctx.param = b
         return x + b
 
     @staticmethod
     def backward(ctx, g):
-        return g, colsum(g.reshape(-1, g.shape[-1]))
+        n = g.shape[-1]
+        return g, param_colsum(g.reshape(-1, n), [(0, n, ctx.param)])[0]
 
 
 def bias_add(x, b):
@@ -839,22 +940,32 @@ import os as _os
 _SPLITK_MIN_ROWS = int(_os.environ.get("SINGA_SPLITK_MIN", "8192"))
 
 
-def _splitk_tn(a, b):
+def _splitk_tn(a, b, param=None):
     """a^T @ b for tall-skinny a [M,p], b [M,q] (M >> p,q): batched split-K so that the library GEMM has enough
     workgroups (a single [p,M]x[M,q] GEMM launches p*q/tile workgroups only).  The number of splits grows as the
     output shrinks (about 512 workgroups in total, at most 64 splits, at least 256 rows each); rows are divided evenly,
-    so the remainder product has fewer rows than there are splits."""
+    so the remainder product has fewer rows than there are splits.  `param`: the [p, q] parameter this is the gradient
+    of - when the gradient sink takes it, the product is added into param.grad and None is returned."""
     M, p = a.shape
     q = b.shape[1]
-    if M <= _SPLITK_MIN_ROWS:
-        return _mm(a.t(), b)
+    direct = param is not None and M > 0 and _GradSink.takes(param)
+    acc = param.grad.view(p, q) if direct else None
     tiles = -(-p // 32) * -(-q // 32)
-    S = min(64, max(M // 8192, -(-512 // tiles)), M // 256)
+    S = min(64, max(M // 8192, -(-512 // tiles)), M // 256) if M > _SPLITK_MIN_ROWS else 1
     if S < 2:
+        if direct:
+            _mm_acc(acc, a.t(), b)
+            return None
         return _mm(a.t(), b)
     chunk = M // S
     Mc = S * chunk
-    out = colsum(torch.bmm(a[:Mc].view(S, chunk, p).transpose(1, 2), b[:Mc].view(S, chunk, q)))
+    part = torch.bmm(a[:Mc].view(S, chunk, p).transpose(1, 2), b[:Mc].view(S, chunk, q))
+    if direct:
+        _GradSink.jobs.append((part.view(S, p * q), [(0, param.grad)]))
+        if Mc < M:
+            _mm_acc(acc, a[Mc:].t(), b[Mc:])
+        return None
+    out = colsum(part)
     if Mc < M:
         out = out + _mm(a[Mc:].t(), b[Mc:])
     return out
@@ -933,6 +1044,9 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b):
         x2 = x.reshape(-1, x.shape[-1])
+        ctx.params = (w, b)
+        if w.dim() == 3:                      # a 1x1 Conv1d weight [out, in, 1] used as it is
+            w = w.view(w.shape[0], w.shape[1])
         ctx.save_for_backward(x2, w)
         ctx.xshape, ctx.has_bias = x.shape, b is not None
         lib = _blas(x2.shape[0], w.shape[0], x2.shape[1], True)
@@ -957,8 +1071,11 @@ class _Linear(torch.autograd.Function):
                 gx = _mm(g2, w.t().contiguous().t()).view(ctx.xshape)
             else:
                 gx = _mm(g2, w).view(ctx.xshape)
-        gw = _splitk_tn(g2, x2) if ctx.needs_input_grad[1] else None
-        gb = colsum(g2) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        wp, bp = ctx.params
+        gw = _splitk_tn(g2, x2, wp) if ctx.needs_input_grad[1] else None
+        if gw is not None:
+            gw = gw.view(wp.shape)
+        gb = param_colsum(g2, [(0, g2.shape[1], bp)])[0] if ctx.has_bias and ctx.needs_input_grad[2] else None
         return gx, gw, gb
 
 
@@ -1006,6 +1123,7 @@ class _SO2Linear3(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, w0, b0, w1, w2, n0, n1):
+        ctx.params = (w0, w1, w2, b0)
         X = _rows(X)
         ws = [_rows(w0), _rows(w1), _rows(w2)]
         b0 = b0.contiguous()
@@ -1055,16 +1173,16 @@ class _SO2Linear3(torch.autograd.Function):
             items.append(dict(a=g.data_ptr(), lda=g.stride(0), b=X.data_ptr() + 4 * ai, ldb=X.stride(0),
                               c=part.data_ptr() + 4 * off, ldc=k, I=o, J=k, R=E, c_split_stride=tot))
             ai, off = ai + k, off + sz
+        pw = ctx.params[:3]
         if E > 0:
             _gemm(items, False, False, S)
-            gw = colsum(part) if S > 1 else part[0]
+            offs = [0, sizes[0], sizes[0] + sizes[1]]
+            gws = param_colsum(part, [(off, sz, p) for off, sz, p in zip(offs, sizes, pw)])
         else:
-            gw = torch.zeros(tot, device=X.device, dtype=torch.float32)
-        gws, off = [], 0
-        for o, k, sz in zip(outs, ins, sizes):
-            gws.append(gw[off:off + sz].view(o, k))
-            off += sz
-        return gX, gws[0], colsum(gs[0]), gws[1], gws[2], None, None
+            gws = list(torch.zeros(tot, device=X.device, dtype=torch.float32).split(sizes))
+        gws = [g.view(o, k) if g is not None else None for g, o, k in zip(gws, outs, ins)]
+        gb = param_colsum(gs[0], [(0, outs[0], ctx.params[3])])[0]
+        return gX, gws[0], gb, gws[1], gws[2], None, None
 
 
 class _SO2Linear3Lib(torch.autograd.Function):
@@ -1111,6 +1229,7 @@ class _SO3Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, L):
+        ctx.params = (weight, bias)
         x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
         _dev(x, weight, bias)
         N, K, cin = x.shape
@@ -1160,10 +1279,12 @@ class _SO3Linear(torch.autograd.Function):
                               c=part.data_ptr() + 4 * l * sz, ldc=cin, I=cout, J=cin, R=N * n, c_split_stride=(L + 1) * sz))
         if N > 0:
             _gemm(items, False, False, S)
-            gw = (colsum(part) if S > 1 else part[0]).view(L + 1, cout, cin)
+            gw = param_colsum(part, [(0, (L + 1) * sz, ctx.params[0])])[0]
+            if gw is not None:
+                gw = gw.view(L + 1, cout, cin)
         else:
             gw = torch.zeros(L + 1, cout, cin, device=x.device, dtype=torch.float32)
-        return gx, gw, colsum(g[:, 0, :]), None
+        return gx, gw, param_colsum(g[:, 0, :], [(0, cout, ctx.params[1])])[0], None
 
 
 class _SO3LinearLib(torch.autograd.Function):
@@ -1204,8 +1325,10 @@ class _GroupedLinear(torch.autograd.Function):
     copies forward or backward)."""
 
     @staticmethod
-    def forward(ctx, h, w):
+    def forward(ctx, h, w, heads):
         h = h.contiguous()
+        ctx.param = w
+        w = w.view(heads, w.shape[0] // heads, w.shape[1])       # the Conv1d weight [heads*og, ig, 1] (or [heads, og, ig])
         heads, og, ig = w.shape
         N = h.shape[0]
         out = torch.empty(N, heads, og, device=h.device, dtype=h.dtype)
@@ -1222,14 +1345,23 @@ class _GroupedLinear(torch.autograd.Function):
         g = g.contiguous()
         gT = g.transpose(0, 1)                                                    # [heads, N, og] view
         gh = torch.empty(N, heads, ig, device=h.device, dtype=h.dtype)
+        wp = ctx.param
         with _rocblas():
             torch.bmm(gT, w, out=gh.transpose(0, 1))
-            gw = torch.bmm(gT.transpose(1, 2), h.view(N, heads, ig).transpose(0, 1))
-        return gh.view(N, heads * ig), gw
+            if _GradSink.takes(wp):
+                wp.grad.view(heads, og, ig).baddbmm_(gT.transpose(1, 2), h.view(N, heads, ig).transpose(0, 1))
+                gw = None
+            else:
+                gw = torch.bmm(gT.transpose(1, 2), h.view(N, heads, ig).transpose(0, 1)).view(wp.shape)
+        return gh.view(N, heads * ig), gw, None
 
 
-def grouped_linear(h, w):
-    return _GroupedLinear.apply(h, w)
+def grouped_linear(h, w, heads=None):
+    """w: [heads, og, ig], or the grouped 1x1 Conv1d weight [heads*og, ig, 1] with `heads` given."""
+    if heads is None:
+        heads = w.shape[0]
+        w = w.reshape(w.shape[0] * w.shape[1], w.shape[2])
+    return _GroupedLinear.apply(h, w, heads)
 
 
 def linear(x, w, b=None):
@@ -1274,13 +1406,14 @@ class _RowDotBias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, b):
         ctx.save_for_backward(x, b)
+        ctx.param = b
         return (x * b).sum(-1)
 
     @staticmethod
     def backward(ctx, g):
         x, b = ctx.saved_tensors
         ge = g.unsqueeze(-1)
-        return ge * b, colsum((ge * x).reshape(-1, x.shape[-1]))
+        return ge * b, param_colsum((ge * x).reshape(-1, x.shape[-1]), [(0, x.shape[-1], ctx.param)])[0]
 
 
 def rowdot_bias(x, b):

@@ -9,7 +9,7 @@ from tests.helpers import NAMES, golden, product_batch, state_from_spec
 pytestmark = pytest.mark.gpu
 
 
-def _run(use_graph, steps=3, torch_adam=False):
+def _run(use_graph, steps=3, torch_adam=False, direct_grads=True):
     from singa_amd.config import load_config
     from singa_amd.engine import TrainStep
     from singa_amd.model.GAN import SINGA
@@ -20,7 +20,7 @@ def _run(use_graph, steps=3, torch_adam=False):
     from singa_amd.optim import Adam
     opt = (torch.optim.Adam(model.parameters(), lr=1e-4, betas=(0.99, 0.999)) if torch_adam
            else Adam(model.parameters(), lr=1e-4, betas=(0.99, 0.999)))
-    eng = TrainStep(model, opt, None, use_graph=use_graph)
+    eng = TrainStep(model, opt, None, use_graph=use_graph, direct_grads=direct_grads)
     z = golden(f"singa_L{L}_B3.npz")
     batch = product_batch(NAMES, z)
     losses, norms = [], []
@@ -139,6 +139,23 @@ def test_graph_replay_gradients_match_eager_per_parameter():
         if not (err < 2e-3) and float((p.grad - q.grad).abs().max()) > 1e-9:
             bad.append((n, err, float(p.grad.abs().max()), float(q.grad.abs().max())))
     assert not bad, bad[:8]
+
+
+def test_direct_parameter_gradients_equal_autograd_accumulation():
+    """TrainStep(direct_grads=True) (bias / affine / split-reduction weight gradients added straight into .grad by one
+    multi-job reduction) follows the same trajectory as direct_grads=False (every gradient returned to autograd), eager
+    and replayed; and the direct path is the one in use."""
+    from singa_amd import ops
+    base, e0 = _run(False, steps=4, direct_grads=False)
+    assert e0._sink_params is None
+    for use_graph in (False, True):
+        got, e1 = _run(use_graph, steps=4)
+        assert len(e1._sink_params) > 150, len(e1._sink_params)
+        for a, b in zip(got, base):
+            assert abs(a - b) < 2e-4 * abs(b), (got, base)
+        for a, b in zip(e1.norms, e0.norms):
+            assert abs(a - b) < 2e-3 * abs(b), (e1.norms, e0.norms)
+    assert ops._GradSink.on is False and not ops._GradSink.jobs
 
 
 def test_fused_adam_matches_torch_adam():

@@ -255,6 +255,42 @@ def test_colsum(emul):
         assert np.abs(out - x[:, :n].astype(np.float64).sum(0)).max() < 1e-3
 
 
+def test_colsum_multi(emul):
+    """Many column sums in one call, each ADDED into its destination segments (the parameter-gradient queue of one
+    backward pass): single-slab and multi-slab jobs, strided sources, several segments per job, more jobs and segments
+    than one launch carries."""
+    rs = np.random.RandomState(3)
+    shapes = [(1, 5, 5), (17, 3, 3), (700, 33, 40), (5000, 300, 300), (40000, 7, 9), (0, 4, 4)] + \
+             [(int(rs.randint(1, 3000)), int(rs.randint(1, 70)), 80) for _ in range(90)]
+    xs, dsts, refs, segs = [], [], [], []
+    for M, n, ld in shapes:
+        x = rs.randn(M, ld).astype(np.float32)
+        cuts = sorted(set([0] + ([int(c) for c in rs.randint(1, n, size=rs.randint(0, 3))] if n > 1 else [])))
+        d = [rs.randn(b - a).astype(np.float32) for a, b in zip(cuts, cuts[1:] + [n])]
+        tot = x[:, :n].astype(np.float64).sum(0)
+        refs.append([di.astype(np.float64) + tot[a:a + di.size] for di, a in zip(d, cuts)])
+        xs.append(x)
+        dsts.append(d)
+        segs.append(cuts)
+    nj = len(shapes)
+    ns = sum(len(c) for c in segs)
+    X, LD, MM, NN = (ctypes.c_void_p * nj)(), (ctypes.c_longlong * nj)(), (ctypes.c_longlong * nj)(), (ctypes.c_int * nj)()
+    S0, C0, D = (ctypes.c_int * nj)(), (ctypes.c_int * ns)(), (ctypes.c_void_p * ns)()
+    q = work = 0
+    for k, ((M, n, ld), x) in enumerate(zip(shapes, xs)):
+        X[k], LD[k], MM[k], NN[k], S0[k] = x.ctypes.data, ld, M, n, q
+        work += emul.singa_colsum_multi_work(M, n)
+        for c, d in zip(segs[k], dsts[k]):
+            C0[q], D[q] = c, d.ctypes.data
+            q += 1
+    w = np.zeros(work + 1, np.float32)
+    assert emul.singa_colsum_multi(nj, X, LD, MM, NN, S0, ns, C0, D, ptr(w), work, None) == 0
+    for d, r in zip(dsts, refs):
+        for di, ri in zip(d, r):
+            assert np.abs(di - ri).max() < 2e-3
+    assert emul.singa_colsum_multi(nj, X, LD, MM, NN, S0, ns, C0, D, ptr(w), work - 1, None) == -3     # workspace too small
+
+
 @pytest.mark.parametrize("L,edge", [(2, True), (4, True), (6, True), (2, False), (4, False), (6, False)])
 def test_s2act_separable(emul, L, edge):
     """Separable (Legendre x Fourier) S2 activation == the dense-grid oracle, forward and backward."""
