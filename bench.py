@@ -74,6 +74,16 @@ def kernel_bytes(tag, E, N, L, C=16, CH=112, heads=7):
         return 2 * N * K * C * 4 + E * (KR * 2 * C * 4 + WSZ * 4 + 8) + E * R * 4
     if tag in ("k4_bwd_dst", "k4_bwd_src"):   # reads one half of d out and of rad, Wigner rows, the CSR; writes N node rows
         return E * (KR * C * 4 + R // 2 * 4 + WSZ * 4 + (4 if tag == "k4_bwd_src" else 0)) + N * K * C * 4 + (N + 1) * 4
+    # k8, separable S2 activation.  Attention grid: E edge rows of KR coefficients x 128 channels (+ the 128 gate
+    # scalars); feed-forward grid: E = node rows of K coefficients x 512 channels (+ 512 gate scalars)
+    if tag == "s2_edge_fwd":
+        return E * ((KR + 1) * 128 * 4 + KR * 128 * 4)
+    if tag == "s2_edge_bwd":  # reads the input, the gate and d out; writes d input and d gate
+        return E * ((KR + 1) * 128 * 4 + KR * 128 * 4 + (KR + 1) * 128 * 4)
+    if tag == "s2_node_fwd":
+        return E * ((K + 1) * 512 * 4 + K * 512 * 4)
+    if tag == "s2_node_bwd":
+        return E * ((K + 1) * 512 * 4 + K * 512 * 4 + (K + 1) * 512 * 4)
     raise KeyError(tag)
 
 
@@ -391,6 +401,18 @@ def main():
                 ach = by / (us * 1e-6) / 1e9
                 per[tag] = {"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_us": round(us, 2),
                             "bytes_per_launch": by, "launches": len(sel)}
+            # k8 (S2 activation): the largest launch of each kind - the attention grid on the bonded edges, the
+            # feed-forward grid on all atoms
+            for tag in ("s2_edge_fwd", "s2_edge_bwd", "s2_node_fwd", "s2_node_bwd"):
+                rows = max((r[2] for r in recs if r[0] == tag), default=0)
+                sel = [r for r in recs if r[0] == tag and r[2] == rows]
+                if not sel:
+                    continue
+                us = 1e3 * sum(r[1] for r in sel) / len(sel)
+                by = kernel_bytes(tag, rows, 0, L)
+                ach = by / (us * 1e-6) / 1e9
+                per[tag] = {"achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4), "avg_launch_us": round(us, 2),
+                            "bytes_per_launch": by, "launches": len(sel), "rows": rows}
             log("bonded-edge launches (us): " + "; ".join(f"{k} {v['avg_launch_us']}" for k, v in per.items()))
         if "k10_fwd" in per:
             k = per["k10_fwd"]

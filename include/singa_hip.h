@@ -320,6 +320,10 @@ int singa_prof_collect(float* ms, int* edges, int* nodes, int cap); /* after syn
 #define SINGA_PROF_GEMM_NT 7     /* singa_gemm_f32 (1,1): nodes field = number of 128 x 128 tiles */
 #define SINGA_PROF_GEMM_NN 8
 #define SINGA_PROF_GEMM_TN 9
+#define SINGA_PROF_S2_EDGE_FWD 10   /* separable S2 activation on the attention grid (edge rows, 128 channels) */
+#define SINGA_PROF_S2_EDGE_BWD 11
+#define SINGA_PROF_S2_NODE_FWD 12   /* ... on the feed-forward grid (node rows, 512 channels) */
+#define SINGA_PROF_S2_NODE_BWD 13
 int singa_prof_collect_tagged(float* ms, int* tags, int* edges, int* nodes, int cap);
 int singa_calib_copy(const float* src, float* dst, long long n, void* stream);
 

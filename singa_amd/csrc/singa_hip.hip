@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <type_traits>
 
 #include "../../include/singa_hip.h"
 #include "so3_index.h"
@@ -2794,59 +2795,75 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
     // `full`: the tile lies inside the matrices and every K step is complete - loads without predicates (8 exec-mask
     // round trips per step less, and the compiler batches them)
     const bool full = i0 + BM <= P.I && j0 + BN <= P.J && r_end > r_begin && (r_end - r_begin) % BK == 0;
-    auto load_rc = [&](float4* reg, const float* const* rows, int n, long long r0, bool all) {
-        if (all) {
+    // Ragged tiles / K steps and grouped rows: every load is still issued unconditionally - from a clamped, valid address -
+    // and a per-register-set bit mask says which registers hold data; the zeros are selected when the registers are
+    // written to LDS.  (Predicated loads put branches into the K loop, and the compiler then waits for ALL outstanding
+    // loads - vmcnt(0) - before each LDS write: the two-step prefetch collapsed to none, 5.7 us per K step on the
+    // grouped-row gradients of SO3_LinearV2.)
+    auto load_rc = [&](auto all_c, float4* reg, unsigned& mask, const float* const* rows, const float* dummy, int n, long long r0) {
+        if constexpr (decltype(all_c)::value) {
 #pragma unroll
             for (int j = 0; j < n; ++j) reg[j] = *reinterpret_cast<const float4*>(rows[j] + r0);
-            return;
-        }
-        const bool in = r0 + 4 * kq < r_end;
+            mask = ~0u;
+        } else {
+            const bool in = r0 + 4 * kq < r_end;
+            mask = 0;
 #pragma unroll
-        for (int j = 0; j < n; ++j) {
-            reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (in && rows[j]) reg[j] = *reinterpret_cast<const float4*>(rows[j] + r0);
-        }
-    };
-    auto load_oc = [&](float4* reg, const float* base, long long ld, int grp, long long gld, int o0, int lim, int n, int width4,
-                       long long r0, bool all) {
-        const int c4 = tid % width4, rq = tid / width4, rows = 256 / width4;
-        const int i = o0 + 4 * c4;
-        if (all && grp == (1 << 30)) {
-            const float* b = base + (r0 + rq) * ld + i;
-#pragma unroll
-            for (int j = 0; j < n; ++j) reg[j] = *reinterpret_cast<const float4*>(b + (long long)(rows * j) * ld);
-            return;
-        }
-#pragma unroll
-        for (int j = 0; j < n; ++j) {
-            const long long r = r0 + rq + rows * j;
-            reg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < r_end && i < lim) {
-                const long long row = grp == (1 << 30) ? r * ld : (r / grp) * gld + (r % grp) * ld;
-                reg[j] = *reinterpret_cast<const float4*>(base + row + i);
+            for (int j = 0; j < n; ++j) {
+                const bool ok = in && rows[j] != nullptr;
+                const float* src = ok ? rows[j] + r0 : dummy + r_begin;      // dummy: the first row of the matrix
+                reg[j] = *reinterpret_cast<const float4*>(src);
+                mask |= (ok ? 1u : 0u) << j;
             }
         }
     };
-    auto store_rc = [&](float* S, const float4* reg, int n) {
+    auto load_oc = [&](auto all_c, float4* reg, unsigned& mask, const float* base, long long ld, int grp, long long gld, int o0,
+                       int lim, int n, int width4, long long r0) {
+        const int c4 = tid % width4, rq = tid / width4, rows = 256 / width4;
+        const int i = o0 + 4 * c4;
+        if constexpr (decltype(all_c)::value) {           // host side: `full` tiles of ungrouped operands only
+            const float* b = base + (r0 + rq) * ld + i;
 #pragma unroll
-        for (int j = 0; j < n; ++j) *reinterpret_cast<float4*>(S + (rr + 32 * j) * PR + 4 * kq) = reg[j];
+            for (int j = 0; j < n; ++j) reg[j] = *reinterpret_cast<const float4*>(b + (long long)(rows * j) * ld);
+            mask = ~0u;
+        } else {
+            const int ic = i < lim ? i : o0;
+            mask = 0;
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                const long long r = r0 + rq + rows * j;
+                const bool ok = r < r_end && i < lim;
+                // R is an int: 32-bit unsigned division (a 64-bit one is ~150 instructions, per row and K step); an
+                // ungrouped operand has grp = 2^30 > R: quotient 0, the same formula - no branch in the K loop
+                const unsigned ru = (unsigned)(r < r_end ? r : r_begin), gq = ru / (unsigned)grp;
+                const long long row = (long long)gq * gld + (long long)(ru - gq * (unsigned)grp) * ld;
+                reg[j] = *reinterpret_cast<const float4*>(base + row + ic);
+                mask |= (ok ? 1u : 0u) << j;
+            }
+        }
     };
-    auto store_oc = [&](float* S, const float4* reg, int pitch, int n, int width4) {
+    auto store_rc = [&](float* S, const float4* reg, unsigned mask, int n) {
+#pragma unroll
+        for (int j = 0; j < n; ++j)
+            *reinterpret_cast<float4*>(S + (rr + 32 * j) * PR + 4 * kq) = (mask >> j) & 1u ? reg[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_oc = [&](float* S, const float4* reg, unsigned mask, int pitch, int n, int width4) {
         const int c4 = tid % width4, rq = tid / width4, rows = 256 / width4;
 #pragma unroll
-        for (int j = 0; j < n; ++j) *reinterpret_cast<float4*>(S + (rq + rows * j) * pitch + 4 * c4) = reg[j];
+        for (int j = 0; j < n; ++j)
+            *reinterpret_cast<float4*>(S + (rq + rows * j) * pitch + 4 * c4) = (mask >> j) & 1u ? reg[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    auto load_ab = [&](float4* ra, float4* rb, long long r0) {
-        if (A_RC) load_rc(ra, arow, NA, r0, full);
-        else load_oc(ra, P.A, P.lda, P.a_group, P.a_gld, i0, P.I, NA, BM / 4, r0, full);
-        if (B_RC) load_rc(rb, brow, NB, r0, full);
-        else load_oc(rb, P.B, P.ldb, P.b_group, P.b_gld, j0, P.J, NB, BN / 4, r0, full);
+    auto load_ab = [&](auto all_c, float4* ra, float4* rb, unsigned& ma, unsigned& mb, long long r0) {
+        if (A_RC) load_rc(all_c, ra, ma, arow, P.A, NA, r0);
+        else load_oc(all_c, ra, ma, P.A, P.lda, P.a_group, P.a_gld, i0, P.I, NA, BM / 4, r0);
+        if (B_RC) load_rc(all_c, rb, mb, brow, P.B, NB, r0);
+        else load_oc(all_c, rb, mb, P.B, P.ldb, P.b_group, P.b_gld, j0, P.J, NB, BN / 4, r0);
     };
-    auto store_ab = [&](const float4* ra, const float4* rb, int buf) {
-        if (A_RC) store_rc(As0 + buf * SZA, ra, NA);
-        else store_oc(As0 + buf * SZA, ra, LDA, NA, BM / 4);
-        if (B_RC) store_rc(Bs0 + buf * SZB, rb, NB);
-        else store_oc(Bs0 + buf * SZB, rb, LDB, NB, BN / 4);
+    auto store_ab = [&](const float4* ra, const float4* rb, unsigned ma, unsigned mb, int buf) {
+        if (A_RC) store_rc(As0 + buf * SZA, ra, ma, NA);
+        else store_oc(As0 + buf * SZA, ra, ma, LDA, NA, BM / 4);
+        if (B_RC) store_rc(Bs0 + buf * SZB, rb, mb, NB);
+        else store_oc(Bs0 + buf * SZB, rb, mb, LDB, NB, BN / 4);
     };
     // fragments of k-group t (8 reduction indices = 4 MFMA k-steps) for the wavefront's MT / NT 32-wide blocks
     const int ia = wrow + l31, jb = wcol + l31;
@@ -2868,7 +2885,9 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    auto compute = [&](int buf) {
+    // nt8: k-groups of 8 reduction indices that hold data in this step (4, fewer in a ragged last step: a reduction of
+    // 16 - the 16-channel side of SO3_LinearV2 - then costs 32 MFMAs per wavefront instead of 64 on zero padding)
+    auto compute = [&](int buf, int nt8) {
         const float* Sa = As0 + buf * SZA;
         const float* Sb = Bs0 + buf * SZB;
         float fa[2][MT][4], fb[2][NT][4];
@@ -2878,6 +2897,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
         for (int b = 0; b < NT; ++b) frag(Sb, B_RC, LDB, jb + 32 * b, 0, fb[0][b]);
 #pragma unroll
         for (int t = 0; t < BK / 8; ++t) {
+            if (t >= nt8) break;
             const int cur = t & 1;
             if (t + 1 < BK / 8) {            // the next group's fragments travel behind this group's MFMAs
 #pragma unroll
@@ -2896,41 +2916,69 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
     };
 
     const long long nsteps = r_end > r_begin ? (r_end - r_begin + BK - 1) / BK : 0;
-    if (nsteps > 0) {
-        load_ab(ra0, rb0, r_begin);
-        if (nsteps > 1) load_ab(ra1, rb1, r_begin + BK);
-        store_ab(ra0, rb0, 0);
-    }
-    __syncthreads();
-    // step st computes LDS buffer st & 1; register set (st + 1) & 1 holds step st + 1 (written at the end of this step), the
-    // other set is free for step st + 2
+    const int last8 = nsteps > 0 ? (int)((r_end - r_begin - (nsteps - 1) * BK + 7) / 8) : 0;   // k-groups of the last step
+    // Step st computes LDS buffer st & 1; register set (st + 1) & 1 holds step st + 1 (written to LDS at the end of this
+    // step), the other set receives step st + 2.  The steady-state loop has NO branch around its loads and the scheduler
+    // may not move anything across the marks: only then does the compiler wait with a COUNT (the older set's loads) before
+    // the LDS writes instead of vmcnt(0), i.e. only then are two steps of loads really in flight.  (With `if (st + 2 <
+    // nsteps) load` inside one loop it issued vmcnt(0) at every join and hoisted the LDS writes above the new loads.)
+    auto k_loop = [&](auto all_c) {
+        unsigned ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;
+        if (nsteps > 0) {
+            load_ab(all_c, ra0, rb0, ma0, mb0, r_begin);
+            if (nsteps > 1) load_ab(all_c, ra1, rb1, ma1, mb1, r_begin + BK);
+            store_ab(ra0, rb0, ma0, mb0, 0);
+        }
+        __syncthreads();
+        long long st = 0;
+#if !defined(SINGA_GEMM_LAB_NOLOAD) && !defined(SINGA_GEMM_LAB_NOSYNC)
+        // all prologue loads land before the loop: otherwise the compiler's wait insertion merges "a prologue load into
+        // register X may be pending" into the loop header and waits for vmcnt(0) there on EVERY iteration
+        if (nsteps > 3) __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0) only
+        for (; st + 3 < nsteps; st += 2) {
+            load_ab(all_c, ra0, rb0, ma0, mb0, r_begin + (st + 2) * BK);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(0, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            store_ab(ra1, rb1, ma1, mb1, 1);
+            __syncthreads();
+            load_ab(all_c, ra1, rb1, ma1, mb1, r_begin + (st + 3) * BK);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(1, 4);
+            __builtin_amdgcn_sched_barrier(0);
+            store_ab(ra0, rb0, ma0, mb0, 0);
+            __syncthreads();
+        }
+#endif
+        for (; st < nsteps; st += 2) {         // the last (up to three) steps, and the tools/lab variants
 #if defined(SINGA_GEMM_LAB_NOLOAD) || defined(SINGA_GEMM_LAB_NOSYNC)   // tools/lab only: which part of a step costs what
-    for (long long st = 0; st < nsteps; st += 2) {
-        compute(0);
+            compute(0, 4);
 #ifndef SINGA_GEMM_LAB_NOSYNC
-        if (st + 1 < nsteps) store_ab(ra1, rb1, 1);
-        __syncthreads();
+            if (st + 1 < nsteps) store_ab(ra1, rb1, ma1, mb1, 1);
+            __syncthreads();
 #endif
-        if (st + 1 >= nsteps) break;
-        compute(1);
+            if (st + 1 >= nsteps) break;
+            compute(1, 4);
 #ifndef SINGA_GEMM_LAB_NOSYNC
-        if (st + 2 < nsteps) store_ab(ra0, rb0, 0);
-        __syncthreads();
+            if (st + 2 < nsteps) store_ab(ra0, rb0, ma0, mb0, 0);
+            __syncthreads();
 #endif
-    }
 #else
-    for (long long st = 0; st < nsteps; st += 2) {
-        if (st + 2 < nsteps) load_ab(ra0, rb0, r_begin + (st + 2) * BK);
-        compute(0);
-        if (st + 1 < nsteps) store_ab(ra1, rb1, 1);
-        __syncthreads();
-        if (st + 1 >= nsteps) break;
-        if (st + 3 < nsteps) load_ab(ra1, rb1, r_begin + (st + 3) * BK);
-        compute(1);
-        if (st + 2 < nsteps) store_ab(ra0, rb0, 0);
-        __syncthreads();
-    }
+            if (st + 2 < nsteps) load_ab(all_c, ra0, rb0, ma0, mb0, r_begin + (st + 2) * BK);
+            compute(0, st + 1 == nsteps ? last8 : 4);
+            if (st + 1 < nsteps) store_ab(ra1, rb1, ma1, mb1, 1);
+            __syncthreads();
+            if (st + 1 >= nsteps) break;
+            if (st + 3 < nsteps) load_ab(all_c, ra1, rb1, ma1, mb1, r_begin + (st + 3) * BK);
+            compute(1, st + 2 == nsteps ? last8 : 4);
+            if (st + 2 < nsteps) store_ab(ra0, rb0, ma0, mb0, 0);
+            __syncthreads();
 #endif
+        }
+    };
+    // `full` tiles of ungrouped operands take the unpredicated loads
+    if (full && P.a_group == (1 << 30) && P.b_group == (1 << 30)) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
     // ---- epilogue.  Accumulator register q of a 32 x 32 tile holds row (q & 3) + 8 (q >> 2) + 4 half, column lane & 31.
     // Every wavefront owns 32 x PE floats of LDS (all K-loop reads are behind the barrier above); one 32-row block at a time:
     // registers -> [row][col] image -> float4 rows -> global, bias added on the way.
@@ -3411,8 +3459,9 @@ int singa_s2act_sep_fwd(const singa_seg_t* x, int nseg, const float* gate, int64
     if (E <= 0) return SINGA_OK;
     long long EC = (long long)E * C;
     int blocks = (int)((EC + 255) / 256);
-    SINGA_DISPATCH_S2SEP(lmax, edge, hipLaunchKernelGGL((s2act_sep_fwd_kernel<L_, EDGE_, C_>), dim3(blocks), dim3(256), 0,
-                                                        (hipStream_t)stream, s, gate, (long long)ldg, P, Q, A, out, EC));
+    const int tag = edge ? SINGA_PROF_S2_EDGE_FWD : SINGA_PROF_S2_NODE_FWD;
+    SINGA_DISPATCH_S2SEP(lmax, edge, SINGA_LAUNCH(tag, E, 0, (s2act_sep_fwd_kernel<L_, EDGE_, C_>), dim3(blocks), dim3(256),
+                                                  (hipStream_t)stream, s, gate, (long long)ldg, P, Q, A, out, EC));
     return check_launch("s2act_sep_fwd");
 }
 
@@ -3431,9 +3480,10 @@ int singa_s2act_sep_bwd(const singa_seg_t* x, int nseg, const float* gate, int64
     if (E <= 0) return SINGA_OK;
     long long EC = (long long)E * C;
     int blocks = (int)((EC + 255) / 256);
-    SINGA_DISPATCH_S2SEP(lmax, edge, hipLaunchKernelGGL((s2act_sep_bwd_kernel<L_, EDGE_, C_>), dim3(blocks), dim3(256), 0,
-                                                        (hipStream_t)stream, s, gate, (long long)ldg, P, Q, A, g_out, gx,
-                                                        g_gate, EC));
+    const int tag = edge ? SINGA_PROF_S2_EDGE_BWD : SINGA_PROF_S2_NODE_BWD;
+    SINGA_DISPATCH_S2SEP(lmax, edge, SINGA_LAUNCH(tag, E, 0, (s2act_sep_bwd_kernel<L_, EDGE_, C_>), dim3(blocks), dim3(256),
+                                                  (hipStream_t)stream, s, gate, (long long)ldg, P, Q, A, g_out, gx, g_gate,
+                                                  EC));
     return check_launch("s2act_sep_bwd");
 }
 

@@ -6,6 +6,7 @@ inputs exactly as in the reference (`.detach()` at EF:490-491, 2351); backward k
 rotated intermediates.
 """
 import ctypes
+import math
 import warnings
 
 import torch
@@ -26,7 +27,8 @@ def profile_start():
     _chk(_lib.lib().singa_prof_enable(1), "singa_prof_enable")
 
 
-PROF_TAGS = {1: "k10_fwd", 2: "k10_bwd", 3: "k4_fwd", 4: "k4_bwd_rad", 5: "k4_bwd_dst", 6: "k4_bwd_src"}   # include/singa_hip.h
+PROF_TAGS = {1: "k10_fwd", 2: "k10_bwd", 3: "k4_fwd", 4: "k4_bwd_rad", 5: "k4_bwd_dst", 6: "k4_bwd_src",           # include/singa_hip.h
+             10: "s2_edge_fwd", 11: "s2_edge_bwd", 12: "s2_node_fwd", 13: "s2_node_bwd"}
 
 
 def profile_collect():
@@ -890,7 +892,7 @@ def param_colsum(src, targets):
     """Column sums of src [M, n] split over parameters: targets = [(col0, ncols, param)] covering 0..n in order.  Returns
     one gradient per target - None where the sum was queued to be added straight into param.grad (_GradSink).  Runs of
     neighbouring targets of the same kind share one job / one immediate reduction."""
-    src = src.reshape(src.shape[0], -1)
+    src = src.reshape(src.shape[0], math.prod(src.shape[1:]))
     if src.stride(1) != 1:
         src = src.contiguous()
     direct = [src.shape[0] > 0 and _GradSink.takes(t[2]) for t in targets]

@@ -49,6 +49,27 @@ if f:  # per (kernel, grid) durations: the stats file mixes launches of differen
         for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
             w.writerow(list(k) + [len(v), round(sum(v) / len(v) / 1e3, 2), round(min(v) / 1e3, 2), round(max(v) / 1e3, 2),
                                   round(sum(v) / 1e6, 3)])
+    # one replayed step: everything dispatched between two consecutive adam_kernel launches of the timed region (the
+    # steps of the region are identical replays; the one with the fewest dispatches in between is a pure replay + the next
+    # batch's prepare on the side stream)
+    tr = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))))
+    marks = [i for i, t in enumerate(tr) if "adam_kernel" in t[2]]
+    step = None
+    for a, b in zip(marks, marks[1:]):
+        if step is None or b - a < step[1] - step[0]:
+            step = (a, b)
+    if step:
+        per = collections.defaultdict(lambda: [0, 0])
+        for t in tr[step[0] + 1: step[1] + 1]:
+            per[short(t[2]) if "anonymous namespace" in t[2] and "at::" not in t[2] else t[2][:90]][0] += 1
+            per[short(t[2]) if "anonymous namespace" in t[2] and "at::" not in t[2] else t[2][:90]][1] += t[1] - t[0]
+        replay = {"launches": step[1] - step[0], "kernel_ms": round(sum(v[1] for v in per.values()) / 1e6, 3),
+                  "wall_ms": round((tr[step[1]][0] - tr[step[0]][0]) / 1e6, 3)}
+        with open(os.path.join(out, "replayed_step_kernels.csv"), "w", newline="") as o:
+            w = csv.writer(o)
+            w.writerow(["kernel", "launches", "total_us", "share"])
+            for k, v in sorted(per.items(), key=lambda kv: -kv[1][1]):
+                w.writerow([k, v[0], round(v[1] / 1e3, 1), round(v[1] / max(1, sum(x[1] for x in per.values())), 4)])
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = first(f"pmc_{c}/**/*counter_collection.csv")
     if not f:
@@ -67,6 +88,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 
 # ---- MFMA counters (one pass: SQ_VALU_MFMA_BUSY_CYCLES, SQ_INSTS_VALU_MFMA_MOPS_F32, SQ_BUSY_CU_CYCLES, GRBM_GUI_ACTIVE)
 mfma = {}
+replay = globals().get("replay")
 f = first("pmc_MFMA/**/*counter_collection.csv")
 if f:
     per = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -100,6 +122,6 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for src in ("singa_amd/csrc/singa_hip.hip", "singa_amd/csrc/so3_index.h"):
     with open(os.path.join(root, src), "rb") as fh:
         h.update(fh.read())
-json.dump({"workload": workload, "lib_sha": h.hexdigest()[:12],
+json.dump({"workload": workload, "lib_sha": h.hexdigest()[:12], "replayed_step": replay,
            "mfma": {"counters": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), eager pass", "kernels": mfma}
                    if mfma else None}, open(os.path.join(out, "meta.json"), "w"), indent=1)
