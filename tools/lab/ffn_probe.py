@@ -37,3 +37,9 @@ for cin, cout in ((16, 512), (512, 16)):
     t_all = timeit(lambda: torch.autograd.grad(y, [x, w, b], g, retain_graph=True))
     print(f"so3_linear {cin}->{cout} N={N}: fwd {t_f:7.1f} us ({big / t_f * 1e6:5.0f} GB/s of the big tensor)  "
           f"dX-only {t_x:7.1f}  dW-only {t_w:7.1f}  bwd all {t_all:7.1f} us")
+
+# Tried and dropped (round 2): gate Linear + SO3 linear 16->512 + S2 activation as ONE kernel (thread = (node, hidden channel),
+# its (L+2)*16 weights in registers, the node's input rows through LDS, hidden tensor never stored).  At N = 50432, L = 4:
+# forward 1876 us vs 2364 us for the three ops, but the backward twin needs 274 VGPRs (one wavefront per SIMD) and took
+# 4681 us vs 3834 us - the S2 activation is VALU-bound and loses more to the lower occupancy than it gains from the saved
+# 2 x 2.6 GB of traffic.
