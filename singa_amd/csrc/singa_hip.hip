@@ -727,6 +727,16 @@ __global__ void segment_wsum_bwd_kernel(const float* __restrict__ g_out, const f
 }
 
 
+// Workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own 4 MiB L2.  The kNN kernels below take
+// one centre node per workgroup and gather the rows of its neighbours - atoms of the same molecule, i.e. rows a few
+// hundred indices away.  With the plain node = blockIdx mapping every XCD walks the whole batch and each molecule's rows
+// are pulled into all eight L2s from the Infinity Cache; handing XCD x the x-th contiguous eighth of the nodes keeps a
+// molecule's rows in ONE L2.  The grid is a multiple of 8 (kn_grid); ids past the end are skipped.
+__device__ __forceinline__ int xcd_range_id(int vb, int n8) { return (vb & 7) * (n8 >> 3) + (vb >> 3); }
+#define SINGA_XCD_NODE_LOOP(n, N)                                                       \
+    for (int vb_ = blockIdx.x, n8_ = ((N) + 7) / 8 * 8; vb_ < n8_; vb_ += gridDim.x)     \
+        if (const int n = xcd_range_id(vb_, n8_); n < (N))
+
 // ------------------------------------------------------------------------------------------------ k15b: fused graph attention
 // CProMG MultiHeadAttention (CP:59-74) with weight_k_lin / weight_v_lin hoisted to node level by linearity:
 //   qk[e,h]   = scale * sum_d qp[row,h,d] * wk[e,d] * hk[col,h,d] + cterm[row,h]
@@ -758,7 +768,7 @@ __global__ void __launch_bounds__(64) edge_logits_fwd_kernel(const float* __rest
     static_assert(D == 32 && H == 4, "lane mapping and the folded reduction are written for 32 key channels, 4 heads");
     constexpr int SL = 64 / D;
     const int lane = threadIdx.x, d = lane % D, slot = lane / D, grp = d >> 3;
-    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    SINGA_XCD_NODE_LOOP(n, N) {
         float q[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) q[h] = qp[((long long)n * H + h) * D + d] * scale;
@@ -795,7 +805,7 @@ __global__ void __launch_bounds__(64) edge_logits_bwd_row_kernel(const float* __
                                                                  float* __restrict__ g_cterm, int N, float scale) {
     constexpr int SL = 64 / D;
     const int lane = threadIdx.x, d = lane % D, slot = lane / D;
-    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    SINGA_XCD_NODE_LOOP(n, N) {
         float q[H], aq[H], ac[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) {
@@ -843,7 +853,7 @@ __global__ void __launch_bounds__(64) edge_logits_bwd_col_kernel(const float* __
                                                                  float* __restrict__ g_hk, int N, float scale) {
     constexpr int SL = 64 / D;
     const int lane = threadIdx.x, d = lane % D, slot = lane / D;
-    for (int j = blockIdx.x; j < N; j += gridDim.x) {
+    SINGA_XCD_NODE_LOOP(j, N) {
         float acc[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) acc[h] = 0.f;
@@ -875,7 +885,7 @@ __global__ void __launch_bounds__(64) gather_wsum_fwd_kernel(const float* __rest
                                                              const int* __restrict__ col, float* __restrict__ out, int N) {
     constexpr int F = 64;
     const int f = threadIdx.x;
-    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    SINGA_XCD_NODE_LOOP(n, N) {
         float acc[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) acc[h] = 0.f;
@@ -933,7 +943,7 @@ __global__ void __launch_bounds__(64) gather_wsum_bwd_row_kernel(const float* __
     static_assert(H == 4, "the four-way folded reduction is written for four heads");
     constexpr int F = 64;
     const int f = threadIdx.x, quarter = f >> 4;
-    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    SINGA_XCD_NODE_LOOP(n, N) {
         float gn[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) gn[h] = g[((long long)n * H + h) * F + f];
@@ -974,7 +984,7 @@ __global__ void __launch_bounds__(64) gather_wsum_bwd_col_kernel(const float* __
                                                                  float* __restrict__ g_hv, int N) {
     constexpr int F = 64;
     const int f = threadIdx.x;
-    for (int j = blockIdx.x; j < N; j += gridDim.x) {
+    SINGA_XCD_NODE_LOOP(j, N) {
         float acc[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) acc[h] = 0.f;
@@ -3018,6 +3028,12 @@ int grid_for(long long work, int cap = 256 * 32) {
     long long g = work < 1 ? 1 : work;
     return (int)(g > cap ? cap : g);
 }
+// one workgroup per node, rounded up to a multiple of 8 (SINGA_XCD_NODE_LOOP)
+int kn_grid(long long N) {
+    long long g = (N < 1 ? 1 : N);
+    g = (g + 7) / 8 * 8;
+    return (int)(g > (1 << 20) ? (1 << 20) : g);
+}
 
 bool pack(const singa_seg_t* s, int nseg, Segs* out) {
     if (!s || nseg < 1 || nseg > 3) return false;
@@ -3381,7 +3397,7 @@ int singa_edge_logits_fwd(const float* qp, const float* wk, const float* hk, con
     if (!qp || !wk || !hk || !cterm || !row_ptr || !col || !qk) return fail(SINGA_E_NULL, "edge_logits_fwd: null pointer");
     if (H != 4 || D != 32) return fail(SINGA_E_SHAPE, "edge_logits: built for H = 4 heads, D = 32 key channels per head");
     if (N <= 0) return SINGA_OK;
-    hipLaunchKernelGGL((edge_logits_fwd_kernel<32, 4>), dim3(grid_for(N, 1 << 20)), dim3(64), 0, (hipStream_t)stream, qp, wk,
+    hipLaunchKernelGGL((edge_logits_fwd_kernel<32, 4>), dim3(kn_grid(N)), dim3(64), 0, (hipStream_t)stream, qp, wk,
                        hk, cterm, row_ptr, col, qk, N, scale);
     return check_launch("edge_logits_fwd");
 }
@@ -3394,9 +3410,9 @@ int singa_edge_logits_bwd(const float* g, const float* qp, const float* wk, cons
         return fail(SINGA_E_NULL, "edge_logits_bwd: null pointer");
     if (H != 4 || D != 32) return fail(SINGA_E_SHAPE, "edge_logits: built for H = 4 heads, D = 32 key channels per head");
     if (N <= 0) return SINGA_OK;
-    hipLaunchKernelGGL((edge_logits_bwd_row_kernel<32, 4>), dim3(grid_for(N, 1 << 20)), dim3(64), 0, (hipStream_t)stream, g,
+    hipLaunchKernelGGL((edge_logits_bwd_row_kernel<32, 4>), dim3(kn_grid(N)), dim3(64), 0, (hipStream_t)stream, g,
                        qp, wk, hk, row_ptr, col, g_qp, g_wk, g_cterm, N, scale);
-    hipLaunchKernelGGL((edge_logits_bwd_col_kernel<32, 4>), dim3(grid_for(N, 1 << 20)), dim3(64), 0, (hipStream_t)stream, g,
+    hipLaunchKernelGGL((edge_logits_bwd_col_kernel<32, 4>), dim3(kn_grid(N)), dim3(64), 0, (hipStream_t)stream, g,
                        qp, wk, col_ptr, eperm, row, g_hk, N, scale);
     return check_launch("edge_logits_bwd");
 }
@@ -3406,7 +3422,7 @@ int singa_gather_wsum_fwd(const float* alpha, const float* wv, const float* hv, 
     if (!alpha || !wv || !hv || !row_ptr || !col || !out) return fail(SINGA_E_NULL, "gather_wsum_fwd: null pointer");
     if (H != 4 || F != 64) return fail(SINGA_E_SHAPE, "gather_wsum: built for H = 4 heads, F = 64 value channels per head");
     if (N <= 0) return SINGA_OK;
-    hipLaunchKernelGGL((gather_wsum_fwd_kernel<4>), dim3(grid_for(N, 1 << 20)), dim3(64), 0, (hipStream_t)stream, alpha, wv,
+    hipLaunchKernelGGL((gather_wsum_fwd_kernel<4>), dim3(kn_grid(N)), dim3(64), 0, (hipStream_t)stream, alpha, wv,
                        hv, row_ptr, col, out, N);
     return check_launch("gather_wsum_fwd");
 }
@@ -3418,9 +3434,9 @@ int singa_gather_wsum_bwd(const float* g, const float* alpha, const float* wv, c
         return fail(SINGA_E_NULL, "gather_wsum_bwd: null pointer");
     if (H != 4 || F != 64) return fail(SINGA_E_SHAPE, "gather_wsum: built for H = 4 heads, F = 64 value channels per head");
     if (N <= 0) return SINGA_OK;
-    hipLaunchKernelGGL((gather_wsum_bwd_row_kernel<4>), dim3(grid_for(N, 1 << 20)), dim3(64), 0, (hipStream_t)stream, g,
+    hipLaunchKernelGGL((gather_wsum_bwd_row_kernel<4>), dim3(kn_grid(N)), dim3(64), 0, (hipStream_t)stream, g,
                        alpha, wv, hv, row_ptr, col, g_alpha, g_wv, N);
-    hipLaunchKernelGGL((gather_wsum_bwd_col_kernel<4>), dim3(grid_for(N, 1 << 20)), dim3(64), 0, (hipStream_t)stream, g,
+    hipLaunchKernelGGL((gather_wsum_bwd_col_kernel<4>), dim3(kn_grid(N)), dim3(64), 0, (hipStream_t)stream, g,
                        alpha, wv, col_ptr, eperm, row, g_hv, N);
     return check_launch("gather_wsum_bwd");
 }
