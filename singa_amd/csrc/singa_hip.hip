@@ -69,6 +69,12 @@ int g_prof_edges_hint = 0;  // E of the next profiled launch (the kernel itself 
             hipLaunchKernelGGL(kern, grid, block, 0, (st), __VA_ARGS__);                                          \
     } while (0)
 
+// Workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own 4 MiB L2.  The kNN kernels below take
+// one centre node per workgroup and gather the rows of its neighbours - atoms of the same molecule, i.e. rows a few
+// hundred indices away.  With the plain node = blockIdx mapping every XCD walks the whole batch and each molecule's rows
+// are pulled into all eight L2s from the Infinity Cache; handing XCD x the x-th contiguous eighth of the nodes keeps a
+// molecule's rows in ONE L2.  The grid is a multiple of 8 (kn_grid); ids past the end are skipped.
+__device__ __forceinline__ int xcd_range_id(int vb, int n8) { return (vb & 7) * (n8 >> 3) + (vb >> 3); }
 constexpr int MAX_J = 2300;  // sum_{l<=11} (2l+1)^2
 __device__ float g_J[MAX_J];
 int g_lmax_init = -1;
@@ -199,6 +205,8 @@ __global__ void __launch_bounds__(64) gather_rotate_kernel(const float* __restri
     const int lane = threadIdx.x;
     const bool act = lane < 2 * C;       // lanes >= 2C shadow lanes 0..2C-1 (same loads, no stores): every lane of the
     const int ln = lane & (2 * C - 1);   // wave must stay live for the Wigner-record fetch and its lane broadcasts
+    // (edge = blockIdx + k * gridDim: contiguous runs of edges per workgroup with contiguous run ranges per XCD were tried
+    // for L2 locality of the node rows and were SLOWER, 131 vs 118 us at L = 4 - the rows sit in the Infinity Cache either way)
     for (int e = blockIdx.x; e < E; e += gridDim.x) {
         WRows<I::WSZ> W;
         W.load(wr + (long long)e * I::WSZ, lane);
@@ -727,12 +735,6 @@ __global__ void segment_wsum_bwd_kernel(const float* __restrict__ g_out, const f
 }
 
 
-// Workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has its own 4 MiB L2.  The kNN kernels below take
-// one centre node per workgroup and gather the rows of its neighbours - atoms of the same molecule, i.e. rows a few
-// hundred indices away.  With the plain node = blockIdx mapping every XCD walks the whole batch and each molecule's rows
-// are pulled into all eight L2s from the Infinity Cache; handing XCD x the x-th contiguous eighth of the nodes keeps a
-// molecule's rows in ONE L2.  The grid is a multiple of 8 (kn_grid); ids past the end are skipped.
-__device__ __forceinline__ int xcd_range_id(int vb, int n8) { return (vb & 7) * (n8 >> 3) + (vb >> 3); }
 #define SINGA_XCD_NODE_LOOP(n, N)                                                       \
     for (int vb_ = blockIdx.x, n8_ = ((N) + 7) / 8 * 8; vb_ < n8_; vb_ += gridDim.x)     \
         if (const int n = xcd_range_id(vb_, n8_); n < (N))
@@ -1746,7 +1748,9 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
                                                        float* __restrict__ lse, int BH, int T, int S, int heads, float scale) {
     const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
     const int qtiles = (T + 31) / 32;
-    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD b % 8 takes a contiguous eighth of the (batch x head, tile) list: the keys / values of one (batch, head) are
+    // then read into ONE L2 instead of all eight (grid: a multiple of 8 workgroups)
+    const long long w = (long long)xcd_range_id((int)blockIdx.x, (int)gridDim.x) * 4 + (threadIdx.x >> 6);
     if (w >= (long long)BH * qtiles) return;
     const int bh = (int)(w / qtiles), qt = (int)(w - (long long)bh * qtiles);
     const int tq = qt * 32 + i, tqc = tq < T ? tq : T - 1;
@@ -1848,7 +1852,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
                                                           int heads, float scale) {
     const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
     const int qtiles = (T + 31) / 32;
-    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD b % 8 takes a contiguous eighth of the (batch x head, tile) list: the keys / values of one (batch, head) are
+    // then read into ONE L2 instead of all eight (grid: a multiple of 8 workgroups)
+    const long long w = (long long)xcd_range_id((int)blockIdx.x, (int)gridDim.x) * 4 + (threadIdx.x >> 6);
     if (w >= (long long)BH * qtiles) return;
     const int bh = (int)(w / qtiles), qt = (int)(w - (long long)bh * qtiles);
     const int tq = qt * 32 + i, tqc = tq < T ? tq : T - 1;
@@ -1932,7 +1938,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
                                                            int heads, float scale) {
     const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
     const int ktiles = (S + 31) / 32;
-    const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD b % 8 takes a contiguous eighth of the (batch x head, tile) list: the keys / values of one (batch, head) are
+    // then read into ONE L2 instead of all eight (grid: a multiple of 8 workgroups)
+    const long long w = (long long)xcd_range_id((int)blockIdx.x, (int)gridDim.x) * 4 + (threadIdx.x >> 6);
     if (w >= (long long)BH * ktiles) return;
     const int bh = (int)(w / ktiles), kt = (int)(w - (long long)bh * ktiles);
     const int key = kt * 32 + i, keyc = key < S ? key : S - 1;
@@ -3814,7 +3822,7 @@ int singa_attn_fwd(const float* q, const float* k, const float* v, const unsigne
     if (heads <= 0 || BH % heads) return fail(SINGA_E_SHAPE, "attn: BH must be batch x heads");
     if (BH <= 0 || T <= 0 || S <= 0) return SINGA_OK;
     const long long waves = (long long)BH * ((T + 31) / 32);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, k, v, mask,
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(((waves + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, q, k, v, mask,
                        mask_stride_b, mask_stride_t, ctx, lse, BH, T, S, heads, scale);
     return check_launch("attn_fwd");
 }
@@ -3828,9 +3836,9 @@ int singa_attn_bwd(const float* q, const float* k, const float* v, const unsigne
     if (heads <= 0 || BH % heads) return fail(SINGA_E_SHAPE, "attn: BH must be batch x heads");
     if (BH <= 0 || T <= 0 || S <= 0) return SINGA_OK;
     const long long wq = (long long)BH * ((T + 31) / 32), wk = (long long)BH * ((S + 31) / 32);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)((wq + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, k, v, mask,
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((wq + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, q, k, v, mask,
                        mask_stride_b, mask_stride_t, ctx, lse, g_ctx, g_q, dsum, BH, T, S, heads, scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)((wk + 3) / 4)), dim3(256), 0, (hipStream_t)stream, q, k, v, mask,
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(((wk + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, q, k, v, mask,
                        mask_stride_b, mask_stride_t, lse, dsum, g_ctx, g_k, g_v, BH, T, S, heads, scale);
     return check_launch("attn_bwd");
 }
