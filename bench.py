@@ -234,7 +234,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     n_dev = torch.cuda.device_count()
-    if world > 1:
+    # stdout carries exactly ONE line, the JSON result: native libraries write to file descriptor 1 as well (RCCL prints a
+    # version banner there when its first communicator comes up), so everything else is sent to stderr from here on
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    # SINGA_RCCL_SELFTEST=1 with one rank: take every multi-rank branch below on a ONE-rank RCCL communicator (process
+    # group, barriers, bucketed all-reduce between the replayed graphs, capture next to the RCCL watchdog) - what a one-GPU
+    # box can exercise of the N-GPU path
+    selftest = world == 1 and os.environ.get("SINGA_RCCL_SELFTEST") == "1"
+    if selftest:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    multi = world > 1 or selftest
+    if multi:
         # RCCL ("nccl") is the product path.  SINGA_DIST_BACKEND=gloo exists only to rehearse the multi-rank control flow
         # on a one-GPU box (several ranks sharing a device, which RCCL refuses).
         backend = os.environ.get("SINGA_DIST_BACKEND", "nccl")
@@ -250,7 +267,7 @@ def main():
     import __graft_entry__
     if rank == 0:
         __graft_entry__.build()
-    if world > 1:
+    if multi:
         dist.barrier()
     from singa_amd import dp, graph as G, ops
     from singa_amd.config import load_config
@@ -264,7 +281,7 @@ def main():
     torch.manual_seed(cfg.train.seed)                     # same-seed init on every rank (no broadcast)
     model = SINGA(cfg, device=dev)
     model.train()
-    reducer = dp.GradAllReducer(model)
+    reducer = dp.GradAllReducer(model, always=selftest)
     reducer.check_same_init()
     use_graph = not args.eager
     from singa_amd.optim import Adam
@@ -298,7 +315,7 @@ def main():
         batches.append(copy.deepcopy(batch))
     from singa_amd.engine import TrainStep
     bucket = use_graph and D > 1
-    engine = TrainStep(model, opt, reducer if world > 1 else None, use_graph=use_graph,
+    engine = TrainStep(model, opt, reducer if multi else None, use_graph=use_graph,
                        max_grad_norm=float(cfg.train.max_grad_norm), bucket=bucket, growth=args.growth, max_cached=4)
     # the HIP path's loss on the CPU-baseline sample (the first graphs of the workload, initial parameters, dropout off):
     # compared below with the loss the oracle computes on the same graphs while it is being timed
@@ -332,7 +349,7 @@ def main():
     # region - by default on a second stream while the previous step computes (TrainStep.prefetch), the way a loader
     # thread would; with --no-prefetch at the start of the step itself.
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -343,11 +360,11 @@ def main():
         if not args.no_prefetch:
             nxt = engine.prefetch(nxt)          # (bucket mode: returns the padded batch the next step replays)
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -447,7 +464,7 @@ def main():
                           "atoms_on_this_gpu": n_nodes, "edges_on_this_gpu": n_edges,
                           "mean_protein_atoms": mean("n_protein"), "mean_ligand_atoms": mean("n_ligand"),
                           "mean_edges_per_graph": round(n_edges / len(ids), 1),
-                          "parallelism": f"dp{world}",
+                          "parallelism": f"dp{world}" + (" (RCCL self-test: the collectives run on a 1-rank communicator)" if selftest else ""),
                           "step": "prepare+zero_grad+fwd+CE+bwd+allreduce+clip+Adam of the generator (the reference has no discriminator)",
                           "launch": "hipGraph replay" if use_graph else "eager",
                           "batches": (f"{D} different resident batches per GPU cycled through the steps, each padded to its "
@@ -470,8 +487,8 @@ def main():
                 out["oracle_check"] = {"what": f"CrossEntropy of the first {args.cpu_graphs} graphs at the initial parameters, "
                                                "dropout off: HIP path vs CPU oracle", "loss_hip": round(hip_sample_loss, 6),
                                        "loss_oracle": round(lo, 6), "rel_diff": abs(hip_sample_loss - lo) / abs(lo)}
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        print(json.dumps(out), file=json_out, flush=True)
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -12,11 +12,13 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, module, bucket_mb=32.0, group=None):
+    def __init__(self, module, bucket_mb=32.0, group=None, always=False):
         self.module, self.group = module, group
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.buckets = None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # always: run the collectives on a one-rank group too (self-test of the RCCL path on a one-GPU box)
+        self.active = self.world > 1 or (always and dist.is_initialized())
 
     def _build(self):
         params = [p for p in reversed(list(self.module.parameters())) if p.grad is not None]
@@ -33,7 +35,7 @@ class GradAllReducer:
 
     def check_same_init(self):
         """Same-seed initialisation replaces a parameter broadcast; verify it with one checksum exchange."""
-        if self.world == 1:
+        if not self.active:
             return
         s = torch.stack([p.detach().double().sum() for p in self.module.parameters()]).sum().reshape(1)
         lo, hi = s.clone(), s.clone()
@@ -45,7 +47,7 @@ class GradAllReducer:
         """True on every rank if `flag` is true on any (host-side decision that all ranks must take together, e.g.
         re-capturing the step: its warm-up issues collectives).  Exchanged over a gloo group so that no device
         synchronisation is involved."""
-        if self.world == 1:
+        if not self.active:
             return bool(flag)
         if getattr(self, "_cpu_group", None) is None:
             self._cpu_group = (self.group if dist.get_backend(self.group) == "gloo"
@@ -65,7 +67,7 @@ class GradAllReducer:
     def reduce(self):
         """Combine .grad over ranks in place: the mean over ranks, or - after `set_shard_weight` - the token-weighted sum.
         Call after backward(), before the optimizer step."""
-        if self.world == 1:
+        if not self.active:
             return
         if self.buckets is None:
             self._build()

@@ -69,3 +69,23 @@ def test_two_ranks_equal_one_process_on_the_union_batch(tmp_path, use_graph):
     # the union batch's loss is the mean of the shard losses (equal token counts)
     for a, b, r in zip(l0, l1, ref_l):
         assert abs(0.5 * (a + b) - r) < 2e-4 * abs(r), (l0, l1, ref_l)
+
+
+def test_rccl_selftest_one_rank_bench():
+    """The N-rank code path of bench.py on a ONE-rank RCCL communicator (SINGA_RCCL_SELFTEST=1): process group on `nccl`,
+    same-init check, collective capture decision over the side gloo group, barriers, the bucketed all-reduce between the
+    replayed forward+backward graph and the optimizer graph, max-over-ranks timing.  (More ranks need more GPUs: RCCL
+    refuses two ranks on one device.)  The run must produce a normal bench line that moved the gradient payload."""
+    import json
+    import subprocess
+    env = dict(os.environ, SINGA_RCCL_SELFTEST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cfg2_b32_l2", "--steps", "4", "--warmup", "2",
+                        "--no-cpu-baseline", "--roofline-steps", "0"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["final_loss"] == line["final_loss"]
+    assert "RCCL self-test" in line["config"]["parallelism"]
+    assert line["config"]["grad_allreduce_bytes"] > 60e6            # the L = 2 model's 64 MB of gradients went through RCCL

@@ -7,7 +7,7 @@ from singa_amd import graph as G
 from singa_amd.config import load_config
 from singa_amd.model.GAN import SINGA
 from singa_amd.model import EF_layers
-wl = dict(G.WORKLOADS["cfg2_b32_l2"]); n = wl.pop("n_graphs"); L = wl.pop("lmax")
+wl = dict(G.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg3_b128_l4"]); n = wl.pop("n_graphs"); L = wl.pop("lmax")
 model = SINGA(load_config(lmax=L), device="cuda")
 batch = G.synthetic_batch(n, **wl).to("cuda")
 def prep():
