@@ -1,7 +1,16 @@
-"""FFN-grid / attention-grid S2 activation timing at the config-3 sizes (lab probe)."""
+"""FFN-grid / attention-grid S2 activation timing at the config-3 sizes (lab probe; SINGA_LAB_LIB=<.so> times a lab build).
+
+Floors of the FFN-grid forward at L = 4, N = 49,267 (this probe: 1574 us incl. the autograd wrapper; 1388 us in the step):
+a build that only copies the rows (no arithmetic) 852 us = 5.9 TB/s; a build without global loads / stores 1180 us - the
+kernel is VALU-bound (2,082 VALU instructions per thread, 222 of them quarter-rate v_exp / v_rcp), the memory time adds
+~0.3 ms on top.  A persistent variant that fetches the next item's rows before the arithmetic of the current one (25 more
+VGPRs, one wave less per SIMD) was slower: 1770 us."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
+from singa_amd import _lib
+if os.environ.get("SINGA_LAB_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["SINGA_LAB_LIB"])
 from singa_amd import ops
 dev = "cuda"
 def timeit(fn, n=10):
