@@ -255,6 +255,7 @@ class TrainStep:
         self.opt.zero_grad(set_to_none=True)
         loss = self._fwd_bwd(batch)
         if self.reducer is not None:
+            self.reducer.grads_token = None                          # fresh gradient tensors every eager step
             self.reducer.reduce()
         self._update()
         return loss
@@ -315,6 +316,7 @@ class TrainStep:
                 self.opt.zero_grad(set_to_none=True)
                 self._fwd_bwd(st)
                 if self.reducer is not None:
+                    self.reducer.grads_token = None
                     self.reducer.reduce()
                 self._update()
             if snap is not None:
@@ -335,9 +337,14 @@ class TrainStep:
         with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             self._update()
         self.captures += 1
+        TrainStep._serials += 1
+        self.serial = TrainStep._serials          # names this capture's fixed .grad tensors (GradAllReducer.grads_token)
+
+    _serials = 0
+    serial = None
 
     # ------------------------------------------------------------------------------------------------ capture slots
-    _SLOT_FIELDS = ("static", "static_prep", "_sig", "g_fb", "g_opt", "static_loss")
+    _SLOT_FIELDS = ("static", "static_prep", "_sig", "g_fb", "g_opt", "static_loss", "serial")
 
     def _activate(self, sig):
         """Make the capture of signature `sig` the current one (bucket mode): its static buffers, graphs and - because the
@@ -397,6 +404,7 @@ class TrainStep:
     def _replay(self):
         self.g_fb.replay()
         if self.reducer is not None:
+            self.reducer.grads_token = ("capture", self.serial)     # this capture's .grad tensors are fixed objects
             self.reducer.reduce()
         if hasattr(self.opt, "sync_hyper"):
             self.opt.sync_hyper()                            # scheduler-updated learning rate -> device scalar
