@@ -10,7 +10,7 @@ from singa_amd.config import load_config
 from singa_amd.engine import TrainStep
 from singa_amd.model.GAN import SINGA
 from singa_amd.optim import Adam
-wl = dict(G.WORKLOADS["cfg2_b32_l2"]); n = wl.pop("n_graphs"); L = wl.pop("lmax")
+wl = dict(G.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg3_b128_l4"]); n = wl.pop("n_graphs"); L = wl.pop("lmax")
 cfg = load_config(lmax=L); torch.manual_seed(0)
 model = SINGA(cfg, device="cuda").train()
 model.model.overlap_encoders = False
