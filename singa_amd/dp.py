@@ -69,26 +69,45 @@ class GradAllReducer:
         Call after backward(), before the optimizer step."""
         if not self.active:
             return
+        self.flatten()
+        self.allreduce()
+        self.unflatten()
+
+    # The three phases of reduce().  The step engine captures flatten() at the end of its forward+backward HIP graph and
+    # unflatten() at the start of its optimizer graph, so that only the RCCL calls themselves run between the two replays.
+    def flatten(self, fresh=False):
+        """gradients -> flat bucket buffers, scaled by the combination weight.  fresh: look the .grad tensors up again."""
+        if not self.active:
+            return
         if self.buckets is None:
             self._build()
         pre = self.weight if self.weight is not None else 1.0 / self.world
         # the per-tensor views of the flat buffers never change; the list of .grad tensors is rebuilt unless the caller
-        # vouches (grads_token) that they are the same objects as last time - a replayed HIP graph writes the gradients
-        # into fixed tensors, and building two 634-element lists per bucket cost 2 ms of host time per step, during which
-        # the GPU idles between the forward+backward graph and the optimizer graph
+        # vouches (grads_token) that they are the same objects as last time - building two 634-element lists per bucket
+        # cost 2 ms of host time per step
         if self._views is None:
             self._views = [list(flat.split([p.numel() for p in bucket])) for flat, bucket in zip(self.flat, self.buckets)]
-        if self.grads_token is None or self.grads_token != self._grads_for:
+        if fresh or self.grads_token is None or self.grads_token != self._grads_for:
             self._grads = [[p.grad.reshape(-1) for p in bucket] for bucket in self.buckets]
-            self._grads_for = self.grads_token
-        works = []
+            self._grads_for = None if fresh else self.grads_token
         for flat, views, grads in zip(self.flat, self._views, self._grads):
             torch._foreach_copy_(views, grads)
             if pre != 1.0:
                 flat.mul_(pre)
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-        for w, views, grads in zip(works, self._views, self._grads):
+
+    def allreduce(self):
+        """SUM all-reduce of the flat buffers (asynchronous launches, then the current stream waits for all of them)."""
+        if not self.active:
+            return
+        works = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for flat in self.flat]
+        for w in works:
             w.wait()
+
+    def unflatten(self):
+        """flat bucket buffers -> the .grad tensors flatten() read."""
+        if not self.active:
+            return
+        for views, grads in zip(self._views, self._grads):
             torch._foreach_copy_(grads, views)
 
     # set by the caller when the .grad tensors are known to be the same objects on every call with the same token (the

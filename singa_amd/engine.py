@@ -330,21 +330,22 @@ class TrainStep:
         # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
         with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
             self.static_loss = self._fwd_bwd(st)
+            if self.reducer is not None:
+                # the copy of this capture's gradients into the all-reduce buckets rides in the graph; between the two
+                # replays only the RCCL calls themselves are issued (GradAllReducer.flatten / allreduce / unflatten)
+                self.reducer.flatten(fresh=True)
         if hasattr(self.opt, "_grad_table"):
             self.opt._grad_table()        # the .grad tensors now live in the graph pool: publish their addresses (a
                                           # host->device copy, so it has to happen outside the capture)
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
+            if self.reducer is not None:
+                self.reducer.unflatten()
             self._update()
         self.captures += 1
-        TrainStep._serials += 1
-        self.serial = TrainStep._serials          # names this capture's fixed .grad tensors (GradAllReducer.grads_token)
-
-    _serials = 0
-    serial = None
 
     # ------------------------------------------------------------------------------------------------ capture slots
-    _SLOT_FIELDS = ("static", "static_prep", "_sig", "g_fb", "g_opt", "static_loss", "serial")
+    _SLOT_FIELDS = ("static", "static_prep", "_sig", "g_fb", "g_opt", "static_loss")
 
     def _activate(self, sig):
         """Make the capture of signature `sig` the current one (bucket mode): its static buffers, graphs and - because the
@@ -404,8 +405,7 @@ class TrainStep:
     def _replay(self):
         self.g_fb.replay()
         if self.reducer is not None:
-            self.reducer.grads_token = ("capture", self.serial)     # this capture's .grad tensors are fixed objects
-            self.reducer.reduce()
+            self.reducer.allreduce()                                # flatten / unflatten are inside the two graphs
         if hasattr(self.opt, "sync_hyper"):
             self.opt.sync_hyper()                            # scheduler-updated learning rate -> device scalar
         self.g_opt.replay()
