@@ -34,11 +34,16 @@ def _worker(rank, world, port, out):
     data = torch.randn(10, 8, generator=torch.Generator().manual_seed(1))
     tgt = torch.randn(10, 3, generator=torch.Generator().manual_seed(2))
     lo, hi = dp.shard_range(10, rank, world)
-    for _ in range(2):                                      # second step reuses the static buckets
+    for it in range(2):                                     # second step reuses the static buckets
         model.zero_grad(set_to_none=True)
         loss = ((model(data[lo:hi]) - tgt[lo:hi]) ** 2).mean()
         loss.backward()
-        red.reduce()
+        if it == 0:
+            red.reduce()
+        else:                                               # the three phases the step engine issues separately
+            red.flatten(fresh=True)
+            red.allreduce()
+            red.unflatten()
     if rank == 0:
         torch.save({"grads": {n: p.grad for n, p in model.named_parameters()}, "nb": len(red.buckets),
                     "payload": red.payload_bytes}, out)
