@@ -196,15 +196,20 @@ int singa_masked_softmax_bwd(const float* p, const float* gp, const unsigned cha
 /* k19 — dense multi-head attention core of the CProMG decoder / cross attentions (reference model/CProMG.py:107-117, 136-148:
  * scores = Q K^T / sqrt(d_k), masked_fill_(mask, -1e9), softmax, context = attn V) on the f32 MFMA, flash-style: q[BH,T,DK],
  * k[BH,S,DK], v[BH,S,DV] contiguous, mask bytes addressed as in k18, ctx[BH,T,DV], lse[BH,T,2] = (maximum, 1 / sum of
- * exponentials) of each score row (kept for the backward).  Built for DK = 32, DV = 64. */
+ * exponentials) of each score row (kept for the backward).  Built for DK = 32, DV = 64.
+ * token_major != 0: q / k / v / ctx (and the gradients of _bwd) are [B, T|S, heads, D] - the layout in which the W_Q / W_K /
+ * W_V projections produce them and `linear` consumes the context (model/CProMG.py:96-117) - instead of [B*heads, T|S, D]:
+ * the reference's `.view(B, -1, heads, d).transpose(1, 2)` copies and the `.transpose(1, 2).contiguous()` of the context
+ * disappear.  lse and dsum stay [B*heads, T]. */
 int singa_attn_fwd(const float* q, const float* k, const float* v, const unsigned char* mask, long long mask_stride_b,
-                   long long mask_stride_t, float* ctx, float* lse, int BH, int T, int S, int heads, int DK, int DV, float scale,
-                   void* stream);
+                   long long mask_stride_t, float* ctx, float* lse, int BH, int T, int S, int heads, int DK, int DV,
+                   int token_major, float scale, void* stream);
 /* gradients g_q, g_k, g_v from g_ctx: scores are recomputed from q, k and lse (nothing of size T x S is ever stored);
  * dsum[BH,T] is scratch (rowsum(g_ctx * ctx), written by the first pass and read by the second). */
 int singa_attn_bwd(const float* q, const float* k, const float* v, const unsigned char* mask, long long mask_stride_b,
                    long long mask_stride_t, const float* ctx, const float* lse, const float* g_ctx, float* g_q, float* g_k,
-                   float* g_v, float* dsum, int BH, int T, int S, int heads, int DK, int DV, float scale, void* stream);
+                   float* g_v, float* dsum, int BH, int T, int S, int heads, int DK, int DV, int token_major, float scale,
+                   void* stream);
 
 /* k6a — LayerNorm over C = 16 channels followed by SiLU: the `nn.LayerNorm`, `nn.SiLU` pair inside RadialFunction
  * (reference model/EF_layers.py:1634-1657, net.1/net.2 and net.4/net.5).  x, out, g_out, g_x: [M, C] contiguous; biased

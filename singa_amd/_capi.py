@@ -69,8 +69,8 @@ _SIGS = {
     "singa_edge_mlp_bwd": ([P] * 6 + [I32, I32, I32, P], I32),
     "singa_masked_softmax_fwd": ([P, P, I64, I64, P, I32, I32, I32, I32, F32, P], I32),
     "singa_masked_softmax_bwd": ([P, P, P, I64, I64, P, I32, I32, I32, I32, F32, P], I32),
-    "singa_attn_fwd": ([P, P, P, P, I64, I64, P, P, I32, I32, I32, I32, I32, I32, F32, P], I32),
-    "singa_attn_bwd": ([P, P, P, P, I64, I64] + [P] * 7 + [I32, I32, I32, I32, I32, I32, F32, P], I32),
+    "singa_attn_fwd": ([P, P, P, P, I64, I64, P, P, I32, I32, I32, I32, I32, I32, I32, F32, P], I32),
+    "singa_attn_bwd": ([P, P, P, P, I64, I64] + [P] * 7 + [I32, I32, I32, I32, I32, I32, I32, F32, P], I32),
     "singa_ln256_nparts": ([I64], I32),
     "singa_ln256_fwd": ([P] * 5 + [I64, I32, F32, P], I32),
     "singa_ln256_bwd": ([P] * 6 + [I64, I32, F32, P], I32),

@@ -1742,10 +1742,31 @@ __global__ void __launch_bounds__(256) masked_softmax_bwd_kernel(const float* __
 // the running maximum) and the probabilities are the B operand of ctx^T[value x query] += V^T . P^T, whose A operand
 // v[key][value channel] is read straight from global memory in the accumulator's key order.  Nothing but ctx and, per
 // query, the row maximum and the reciprocal row sum (for the backward) is written.
+// Where the rows of one (batch, head) sit.  Head-major: q[B*heads, T, 32] (k: [.., S, 32], v / ctx: [.., 64]).  Token-major
+// (tm): q[B, T, heads, 32] etc. - the layout in which the projections W_Q / W_K / W_V produce them and `linear` consumes
+// the context (CP:96-117), so no head transposes (four copies forward, five backward per attention) are needed.
+struct AttnLay {
+    long long qb, kb, vb, ob;      // float offset of row 0 in q / k / v / ctx-like tensors
+    int qs, ks, vs, os;            // floats between consecutive rows
+};
+__device__ __forceinline__ AttnLay attn_lay(int bh, int heads, int T, int S, int tm) {
+    AttnLay a;
+    if (tm) {
+        const int b = bh / heads, h = bh - b * heads;
+        a.qb = ((long long)b * T * heads + h) * 32; a.kb = ((long long)b * S * heads + h) * 32;
+        a.vb = ((long long)b * S * heads + h) * 64; a.ob = ((long long)b * T * heads + h) * 64;
+        a.qs = heads * 32; a.ks = heads * 32; a.vs = heads * 64; a.os = heads * 64;
+    } else {
+        a.qb = (long long)bh * T * 32; a.kb = (long long)bh * S * 32; a.vb = (long long)bh * S * 64; a.ob = (long long)bh * T * 64;
+        a.qs = 32; a.ks = 32; a.vs = 64; a.os = 64;
+    }
+    return a;
+}
+
 __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, const unsigned char* __restrict__ mask,
                                                        long long msb, long long mst, float* __restrict__ ctx,
-                                                       float* __restrict__ lse, int BH, int T, int S, int heads, float scale) {
+                                                       float* __restrict__ lse, int BH, int T, int S, int heads, int tm, float scale) {
     const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
     const int qtiles = (T + 31) / 32;
     // XCD b % 8 takes a contiguous eighth of the (batch x head, tile) list: the keys / values of one (batch, head) are
@@ -1754,15 +1775,16 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
     if (w >= (long long)BH * qtiles) return;
     const int bh = (int)(w / qtiles), qt = (int)(w - (long long)bh * qtiles);
     const int tq = qt * 32 + i, tqc = tq < T ? tq : T - 1;
+    const AttnLay A = attn_lay(bh, heads, T, S, tm);
     float qreg[16];
 #pragma unroll
     for (int m4 = 0; m4 < 4; ++m4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(q + ((long long)bh * T + tqc) * 32 + 16 * half + 4 * m4);
+        const float4 t4 = *reinterpret_cast<const float4*>(q + A.qb + (long long)tqc * A.qs + 16 * half + 4 * m4);
         qreg[4 * m4] = t4.x, qreg[4 * m4 + 1] = t4.y, qreg[4 * m4 + 2] = t4.z, qreg[4 * m4 + 3] = t4.w;
     }
     const unsigned char* mrow = mask + (long long)(bh / heads) * msb + (long long)tqc * mst;
-    const float* kb = k + (long long)bh * S * 32;
-    const float* vb = v + (long long)bh * S * 64;
+    const float* kb = k + A.kb;
+    const float* vb = v + A.vb;
     floatx16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = 0.f, o1[r] = 0.f;
@@ -1771,7 +1793,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
     auto fetch_k = [&](int k0) {
         const int ka = k0 + i < S ? k0 + i : S - 1;
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) knext[m4] = *reinterpret_cast<const float4*>(kb + (long long)ka * 32 + 16 * half + 4 * m4);
+        for (int m4 = 0; m4 < 4; ++m4) knext[m4] = *reinterpret_cast<const float4*>(kb + (long long)ka * A.ks + 16 * half + 4 * m4);
     };
     fetch_k(0);
     for (int k0 = 0; k0 < S; k0 += 32) {
@@ -1783,7 +1805,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int ks = k0 + 8 * (s >> 2) + 4 * half + (s & 3);
-            const float* vr = vb + (long long)(ks < S ? ks : S - 1) * 64 + i;
+            const float* vr = vb + (long long)(ks < S ? ks : S - 1) * A.vs + i;
             vreg[2 * s] = vr[0], vreg[2 * s + 1] = vr[32];
         }
         if (k0 + 32 < S) fetch_k(k0 + 32);
@@ -1822,7 +1844,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
     lrun += __shfl_xor(lrun, 32, 64);
     if (tq < T) {
         const float inv = 1.f / lrun;
-        float* dst = ctx + ((long long)bh * T + tq) * 64 + 4 * half;
+        float* dst = ctx + A.ob + (long long)tq * A.os + 4 * half;
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
             *reinterpret_cast<float4*>(dst + 8 * blk) =
@@ -1849,7 +1871,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
                                                           long long msb, long long mst, const float* __restrict__ ctx,
                                                           const float* __restrict__ lse, const float* __restrict__ go,
                                                           float* __restrict__ gq, float* __restrict__ dsum, int BH, int T, int S,
-                                                          int heads, float scale) {
+                                                          int heads, int tm, float scale) {
     const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
     const int qtiles = (T + 31) / 32;
     // XCD b % 8 takes a contiguous eighth of the (batch x head, tile) list: the keys / values of one (batch, head) are
@@ -1858,18 +1880,19 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
     if (w >= (long long)BH * qtiles) return;
     const int bh = (int)(w / qtiles), qt = (int)(w - (long long)bh * qtiles);
     const int tq = qt * 32 + i, tqc = tq < T ? tq : T - 1;
-    const long long qrow = (long long)bh * T + tqc;
+    const long long qrow = (long long)bh * T + tqc;                  // lse / dsum stay [B*heads, T]
+    const AttnLay A = attn_lay(bh, heads, T, S, tm);
     float qreg[16], goreg[32];
 #pragma unroll
     for (int m4 = 0; m4 < 4; ++m4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(q + qrow * 32 + 16 * half + 4 * m4);
+        const float4 t4 = *reinterpret_cast<const float4*>(q + A.qb + (long long)tqc * A.qs + 16 * half + 4 * m4);
         qreg[4 * m4] = t4.x, qreg[4 * m4 + 1] = t4.y, qreg[4 * m4 + 2] = t4.z, qreg[4 * m4 + 3] = t4.w;
     }
     float dpart = 0.f;
 #pragma unroll
     for (int m4 = 0; m4 < 8; ++m4) {
-        const float4 g4 = *reinterpret_cast<const float4*>(go + qrow * 64 + 32 * half + 4 * m4);
-        const float4 c4 = *reinterpret_cast<const float4*>(ctx + qrow * 64 + 32 * half + 4 * m4);
+        const float4 g4 = *reinterpret_cast<const float4*>(go + A.ob + (long long)tqc * A.os + 32 * half + 4 * m4);
+        const float4 c4 = *reinterpret_cast<const float4*>(ctx + A.ob + (long long)tqc * A.os + 32 * half + 4 * m4);
         goreg[4 * m4] = g4.x, goreg[4 * m4 + 1] = g4.y, goreg[4 * m4 + 2] = g4.z, goreg[4 * m4 + 3] = g4.w;
         dpart += (g4.x * c4.x + g4.y * c4.y) + (g4.z * c4.z + g4.w * c4.w);
     }
@@ -1877,8 +1900,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
     const float m_i = lse[qrow * 2], linv_i = lse[qrow * 2 + 1];
     if (half == 0 && tq < T) dsum[qrow] = dq_i;
     const unsigned char* mrow = mask + (long long)(bh / heads) * msb + (long long)tqc * mst;
-    const float* kb = k + (long long)bh * S * 32;
-    const float* vb = v + (long long)bh * S * 64;
+    const float* kb = k + A.kb;
+    const float* vb = v + A.vb;
     floatx16 dq;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[r] = 0.f;
@@ -1886,9 +1909,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
     auto fetch = [&](int k0) {
         const int ka = k0 + i < S ? k0 + i : S - 1;
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) kn[m4] = *reinterpret_cast<const float4*>(kb + (long long)ka * 32 + 16 * half + 4 * m4);
+        for (int m4 = 0; m4 < 4; ++m4) kn[m4] = *reinterpret_cast<const float4*>(kb + (long long)ka * A.ks + 16 * half + 4 * m4);
 #pragma unroll
-        for (int m4 = 0; m4 < 8; ++m4) vn[m4] = *reinterpret_cast<const float4*>(vb + (long long)ka * 64 + 32 * half + 4 * m4);
+        for (int m4 = 0; m4 < 8; ++m4) vn[m4] = *reinterpret_cast<const float4*>(vb + (long long)ka * A.vs + 32 * half + 4 * m4);
     };
     fetch(0);
     for (int k0 = 0; k0 < S; k0 += 32) {
@@ -1900,7 +1923,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
 #pragma unroll
         for (int s = 0; s < 16; ++s) {                  // A operands of the dQ product, issued ahead of the 48 MFMAs before it
             const int ks = k0 + 8 * (s >> 2) + 4 * half + (s & 3);
-            kd[s] = kb[(long long)(ks < S ? ks : S - 1) * 32 + i];
+            kd[s] = kb[(long long)(ks < S ? ks : S - 1) * A.ks + i];
         }
         if (k0 + 32 < S) fetch(k0 + 32);
         floatx16 sc, dp;
@@ -1923,7 +1946,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
         for (int s = 0; s < 16; ++s) dq = __builtin_amdgcn_mfma_f32_32x32x2f32(kd[s], sc[s], dq, 0, 0, 0);
     }
     if (tq < T) {
-        float* dst = gq + ((long long)bh * T + tq) * 32 + 4 * half;
+        float* dst = gq + A.qb + (long long)tq * A.qs + 4 * half;
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk)
             *reinterpret_cast<float4*>(dst + 8 * blk) = make_float4(dq[4 * blk], dq[4 * blk + 1], dq[4 * blk + 2], dq[4 * blk + 3]);
@@ -1935,7 +1958,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
                                                            long long msb, long long mst, const float* __restrict__ lse,
                                                            const float* __restrict__ dsum, const float* __restrict__ go,
                                                            float* __restrict__ gk, float* __restrict__ gv, int BH, int T, int S,
-                                                           int heads, float scale) {
+                                                           int heads, int tm, float scale) {
     const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
     const int ktiles = (S + 31) / 32;
     // XCD b % 8 takes a contiguous eighth of the (batch x head, tile) list: the keys / values of one (batch, head) are
@@ -1945,20 +1968,21 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
     const int bh = (int)(w / ktiles), kt = (int)(w - (long long)bh * ktiles);
     const int key = kt * 32 + i, keyc = key < S ? key : S - 1;
     const bool kin = key < S;
+    const AttnLay A = attn_lay(bh, heads, T, S, tm);
     float kreg[16], vreg[32];
 #pragma unroll
     for (int m4 = 0; m4 < 4; ++m4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(k + ((long long)bh * S + keyc) * 32 + 16 * half + 4 * m4);
+        const float4 t4 = *reinterpret_cast<const float4*>(k + A.kb + (long long)keyc * A.ks + 16 * half + 4 * m4);
         kreg[4 * m4] = t4.x, kreg[4 * m4 + 1] = t4.y, kreg[4 * m4 + 2] = t4.z, kreg[4 * m4 + 3] = t4.w;
     }
 #pragma unroll
     for (int m4 = 0; m4 < 8; ++m4) {
-        const float4 t4 = *reinterpret_cast<const float4*>(v + ((long long)bh * S + keyc) * 64 + 32 * half + 4 * m4);
+        const float4 t4 = *reinterpret_cast<const float4*>(v + A.vb + (long long)keyc * A.vs + 32 * half + 4 * m4);
         vreg[4 * m4] = t4.x, vreg[4 * m4 + 1] = t4.y, vreg[4 * m4 + 2] = t4.z, vreg[4 * m4 + 3] = t4.w;
     }
     const unsigned char* mb = mask + (long long)(bh / heads) * msb + keyc;
-    const float* qb = q + (long long)bh * T * 32;
-    const float* gob = go + (long long)bh * T * 64;
+    const float* qb = q + A.qb;
+    const float* gob = go + A.ob;
     floatx16 dk, dv0, dv1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dk[r] = 0.f, dv0[r] = 0.f, dv1[r] = 0.f;
@@ -1966,9 +1990,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
     auto fetch = [&](int t0) {
         const int ta = t0 + i < T ? t0 + i : T - 1;                // query row this lane supplies as A operand
 #pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) qn[m4] = *reinterpret_cast<const float4*>(qb + (long long)ta * 32 + 16 * half + 4 * m4);
+        for (int m4 = 0; m4 < 4; ++m4) qn[m4] = *reinterpret_cast<const float4*>(qb + (long long)ta * A.qs + 16 * half + 4 * m4);
 #pragma unroll
-        for (int m4 = 0; m4 < 8; ++m4) gn[m4] = *reinterpret_cast<const float4*>(gob + (long long)ta * 64 + 32 * half + 4 * m4);
+        for (int m4 = 0; m4 < 8; ++m4) gn[m4] = *reinterpret_cast<const float4*>(gob + (long long)ta * A.os + 32 * half + 4 * m4);
     };
     fetch(0);
     for (int t0 = 0; t0 < T; t0 += 32) {
@@ -1981,7 +2005,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
         for (int s = 0; s < 16; ++s) {                  // A operands of the dV / dK products, issued ahead of the 48 MFMAs before them
             const int ts = t0 + 8 * (s >> 2) + 4 * half + (s & 3);
             const long long tsc = ts < T ? ts : T - 1;
-            ad[s][0] = gob[tsc * 64 + i], ad[s][1] = gob[tsc * 64 + 32 + i], ad[s][2] = qb[tsc * 32 + i];
+            ad[s][0] = gob[tsc * A.os + i], ad[s][1] = gob[tsc * A.os + 32 + i], ad[s][2] = qb[tsc * A.qs + i];
         }
         if (t0 + 32 < T) fetch(t0 + 32);
         floatx16 sc, dp;
@@ -2012,8 +2036,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
         }
     }
     if (kin) {
-        float* dkd = gk + ((long long)bh * S + key) * 32 + 4 * half;
-        float* dvd = gv + ((long long)bh * S + key) * 64 + 4 * half;
+        float* dkd = gk + A.kb + (long long)key * A.ks + 4 * half;
+        float* dvd = gv + A.vb + (long long)key * A.vs + 4 * half;
 #pragma unroll
         for (int blk = 0; blk < 4; ++blk) {
             *reinterpret_cast<float4*>(dkd + 8 * blk) = make_float4(dk[4 * blk], dk[4 * blk + 1], dk[4 * blk + 2], dk[4 * blk + 3]);
@@ -3815,21 +3839,22 @@ int singa_masked_softmax_bwd(const float* p, const float* gp, const unsigned cha
 }
 
 int singa_attn_fwd(const float* q, const float* k, const float* v, const unsigned char* mask, long long mask_stride_b,
-                   long long mask_stride_t, float* ctx, float* lse, int BH, int T, int S, int heads, int DK, int DV, float scale,
-                   void* stream) {
+                   long long mask_stride_t, float* ctx, float* lse, int BH, int T, int S, int heads, int DK, int DV,
+                   int token_major, float scale, void* stream) {
     if (!q || !k || !v || !mask || !ctx || !lse) return fail(SINGA_E_NULL, "attn_fwd: null pointer");
     if (DK != 32 || DV != 64) return fail(SINGA_E_SHAPE, "attn: built for 32 key / 64 value channels per head");
     if (heads <= 0 || BH % heads) return fail(SINGA_E_SHAPE, "attn: BH must be batch x heads");
     if (BH <= 0 || T <= 0 || S <= 0) return SINGA_OK;
     const long long waves = (long long)BH * ((T + 31) / 32);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(((waves + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, q, k, v, mask,
-                       mask_stride_b, mask_stride_t, ctx, lse, BH, T, S, heads, scale);
+                       mask_stride_b, mask_stride_t, ctx, lse, BH, T, S, heads, token_major ? 1 : 0, scale);
     return check_launch("attn_fwd");
 }
 
 int singa_attn_bwd(const float* q, const float* k, const float* v, const unsigned char* mask, long long mask_stride_b,
                    long long mask_stride_t, const float* ctx, const float* lse, const float* g_ctx, float* g_q, float* g_k,
-                   float* g_v, float* dsum, int BH, int T, int S, int heads, int DK, int DV, float scale, void* stream) {
+                   float* g_v, float* dsum, int BH, int T, int S, int heads, int DK, int DV, int token_major, float scale,
+                   void* stream) {
     if (!q || !k || !v || !mask || !ctx || !lse || !g_ctx || !g_q || !g_k || !g_v || !dsum)
         return fail(SINGA_E_NULL, "attn_bwd: null pointer");
     if (DK != 32 || DV != 64) return fail(SINGA_E_SHAPE, "attn: built for 32 key / 64 value channels per head");
@@ -3837,9 +3862,9 @@ int singa_attn_bwd(const float* q, const float* k, const float* v, const unsigne
     if (BH <= 0 || T <= 0 || S <= 0) return SINGA_OK;
     const long long wq = (long long)BH * ((T + 31) / 32), wk = (long long)BH * ((S + 31) / 32);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((wq + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, q, k, v, mask,
-                       mask_stride_b, mask_stride_t, ctx, lse, g_ctx, g_q, dsum, BH, T, S, heads, scale);
+                       mask_stride_b, mask_stride_t, ctx, lse, g_ctx, g_q, dsum, BH, T, S, heads, token_major ? 1 : 0, scale);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(((wk + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, q, k, v, mask,
-                       mask_stride_b, mask_stride_t, lse, dsum, g_ctx, g_k, g_v, BH, T, S, heads, scale);
+                       mask_stride_b, mask_stride_t, lse, dsum, g_ctx, g_k, g_v, BH, T, S, heads, token_major ? 1 : 0, scale);
     return check_launch("attn_bwd");
 }
 

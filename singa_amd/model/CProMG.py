@@ -244,17 +244,20 @@ class MultiHeadAttention(nn.Module):
 
 def _dense_attention(module, Q, K, V, attn_mask, key_channels, hidden_channels):
     B, heads = Q.size(0), module.num_heads
-    q_s = module.W_Q(Q).view(B, -1, heads, key_channels // heads).transpose(1, 2)
-    k_s = module.W_K(K).view(B, -1, heads, key_channels // heads).transpose(1, 2)
-    v_s = module.W_V(V).view(B, -1, heads, hidden_channels // heads).transpose(1, 2)
+    dk, dv = key_channels // heads, hidden_channels // heads
+    scale = 1.0 / math.sqrt(dk)
+    if dk == 32 and dv == 64:       # the shipped head geometry: scores never leave the MFMA registers (k19), and the kernel
+        # reads q / k / v in the projections' own [B, T, heads, d] layout and writes the context in it: no head transposes
+        context = ops.attention(module.W_Q(Q).view(B, -1, heads, dk), module.W_K(K).view(B, -1, heads, dk),
+                                module.W_V(V).view(B, -1, heads, dv), attn_mask, scale, heads, token_major=True)
+        return ops.layer_norm_residual(module.linear(context.view(B, -1, hidden_channels)), Q, module.layer_norm)
+    q_s = module.W_Q(Q).view(B, -1, heads, dk).transpose(1, 2)
+    k_s = module.W_K(K).view(B, -1, heads, dk).transpose(1, 2)
+    v_s = module.W_V(V).view(B, -1, heads, dv).transpose(1, 2)
     T, S = q_s.size(2), k_s.size(2)
     flat = lambda t: t.reshape(B * heads, t.size(2), t.size(3))
-    scale = 1.0 / math.sqrt(q_s.size(-1))
-    if q_s.size(-1) == 32 and v_s.size(-1) == 64:        # the shipped head geometry: scores never leave the MFMA registers (k19)
-        context = ops.attention(flat(q_s), flat(k_s), flat(v_s), attn_mask, scale, heads).view(B, heads, T, -1)
-    else:
-        probs = ops.masked_softmax(ops.bmm_small(flat(q_s), flat(k_s).transpose(1, 2)), attn_mask, scale, heads)
-        context = ops.bmm_small(probs, flat(v_s)).view(B, heads, T, -1)
+    probs = ops.masked_softmax(ops.bmm_small(flat(q_s), flat(k_s).transpose(1, 2)), attn_mask, scale, heads)
+    context = ops.bmm_small(probs, flat(v_s)).view(B, heads, T, -1)
     context = context.transpose(1, 2).contiguous().view(B, -1, hidden_channels)
     return ops.layer_norm_residual(module.linear(context), Q, module.layer_norm)
 

@@ -659,42 +659,50 @@ def masked_softmax(s, mask, scale, heads):
 
 class _Attention(torch.autograd.Function):
     """softmax(masked_fill(q k^T * scale, mask, -1e9)) v on the MFMA (k19): scores never leave registers; the backward
-    recomputes them from q, k and the stored log-sum-exp."""
+    recomputes them from q, k and the stored log-sum-exp.  token_major: q / k / v / context are [B, T|S, heads, D] (as the
+    projections produce them) instead of [B*heads, T|S, D] - no head transposes."""
 
     @staticmethod
-    def forward(ctx, q, k, v, mask, scale, heads):
+    def forward(ctx, q, k, v, mask, scale, heads, token_major):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         _dev(q, k, v)
         assert mask.dtype == torch.bool and mask.dim() == 3 and mask.stride(2) == 1 and mask.is_cuda
-        BH, T, DK = q.shape
-        S, DV = v.shape[1], v.shape[2]
+        if token_major:
+            B, T, _, DK = q.shape
+            S, DV = v.shape[1], v.shape[3]
+            BH = B * heads
+            assert q.shape[2] == heads and k.shape == (B, S, heads, DK) and v.shape[:3] == (B, S, heads)
+            out = torch.empty(B, T, heads, DV, device=q.device, dtype=torch.float32)
+        else:
+            BH, T, DK = q.shape
+            S, DV = v.shape[1], v.shape[2]
+            out = torch.empty(BH, T, DV, device=q.device, dtype=torch.float32)
         assert mask.shape[0] * heads == BH and mask.shape[2] == S and mask.shape[1] in (1, T)
         ctx.mst = 0 if mask.shape[1] == 1 else mask.stride(1)
-        out = torch.empty(BH, T, DV, device=q.device, dtype=torch.float32)
         lse = torch.empty(BH, T, 2, device=q.device, dtype=torch.float32)       # (row maximum, 1 / row sum)
         _chk(_lib.lib().singa_attn_fwd(_p(q), _p(k), _p(v), _p(mask), mask.stride(0), ctx.mst, _p(out), _p(lse), BH, T, S, heads,
-                                       DK, DV, scale, _stream()), "singa_attn_fwd")
+                                       DK, DV, int(token_major), scale, _stream()), "singa_attn_fwd")
         ctx.save_for_backward(q, k, v, mask, out, lse)
-        ctx.scale, ctx.heads = scale, heads
+        ctx.scale, ctx.heads, ctx.tm, ctx.dims = scale, heads, bool(token_major), (BH, T, S, DK, DV)
         return out
 
     @staticmethod
     def backward(ctx, g):
         q, k, v, mask, out, lse = ctx.saved_tensors
         g = g.contiguous()
-        BH, T, DK = q.shape
-        S, DV = v.shape[1], v.shape[2]
+        BH, T, S, DK, DV = ctx.dims
         gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         dsum = torch.empty(BH, T, device=q.device, dtype=torch.float32)
         _chk(_lib.lib().singa_attn_bwd(_p(q), _p(k), _p(v), _p(mask), mask.stride(0), ctx.mst, _p(out), _p(lse), _p(g), _p(gq),
-                                       _p(gk), _p(gv), _p(dsum), BH, T, S, ctx.heads, DK, DV, ctx.scale, _stream()),
+                                       _p(gk), _p(gv), _p(dsum), BH, T, S, ctx.heads, DK, DV, int(ctx.tm), ctx.scale, _stream()),
              "singa_attn_bwd")
-        return gq, gk, gv, None, None, None
+        return gq, gk, gv, None, None, None, None
 
 
-def attention(q, k, v, mask, scale, heads):
-    """Dense attention core for q[B*heads,T,32], k[B*heads,S,32], v[B*heads,S,64] and a boolean mask [B, T|1, S] (k19)."""
-    return _Attention.apply(q, k, v, mask, scale, heads)
+def attention(q, k, v, mask, scale, heads, token_major=False):
+    """Dense attention core (k19) for q[B*heads,T,32], k[B*heads,S,32], v[B*heads,S,64] - or, token_major, q[B,T,heads,32],
+    k[B,S,heads,32], v[B,S,heads,64] -> context in the same layout - and a boolean mask [B, T|1, S]."""
+    return _Attention.apply(q, k, v, mask, scale, heads, token_major)
 
 
 class _LayerNorm256(torch.autograd.Function):

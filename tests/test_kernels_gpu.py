@@ -506,3 +506,13 @@ def test_attention_matches_torch(T, S, kind):
     assert float((got - want).abs().max()) < 1e-5 * max(1.0, float(want.abs().max()))
     for a, b in zip(got_g, want_g):
         assert float((a - b).norm()) < 2e-5 * float(b.norm())
+    # the same through the token-major layout [B, T|S, heads, D] the model uses (no head transposes): identical numbers
+    tm = lambda t: t.detach().view(B, heads, t.shape[1], t.shape[2]).transpose(1, 2).contiguous().requires_grad_(True)
+    q2, k2, v2 = tm(q), tm(k), tm(v)
+    got2 = ops.attention(q2, k2, v2, mask, scale, heads, token_major=True)
+    assert got2.shape == (B, T, heads, 64)
+    got2_g = torch.autograd.grad(got2, (q2, k2, v2), g.view(B, heads, T, 64).transpose(1, 2).contiguous())
+    back = lambda t: t.transpose(1, 2).reshape(B * heads, t.shape[1], t.shape[3])
+    assert torch.equal(back(got2), got)
+    for a, b in zip(got2_g, got_g):
+        assert torch.equal(back(a), b)
