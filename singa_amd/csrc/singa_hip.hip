@@ -53,6 +53,11 @@ int g_prof_n = 0;
 bool g_prof_on = false;
 int g_prof_edges_hint = 0;  // E of the next profiled launch (the kernel itself only needs row_ptr)
 
+// SINGA_KEEP_VGPR(x): an empty asm that pins x to its own vector register at that point (tests/emul defines it away)
+#ifndef SINGA_KEEP_VGPR
+#define SINGA_KEEP_VGPR(x) __asm__ volatile("" : "+v"(x))
+#endif
+
 // SINGA_LAUNCH(tag, E, N, kernel, grid, block, stream, args...): a plain launch, or - while profiling is enabled - the same
 // launch with a start/stop event pair attached to the dispatch and a (tag, E, N) record for singa_prof_collect_tagged.
 #define SINGA_LAUNCH(tag_, E_, N_, kern, grid, block, st, ...)                                                   \
@@ -2600,6 +2605,112 @@ __global__ void __launch_bounds__(256) s2act_sep_bwd_kernel(Segs x, const float*
     g_gate[e * C + c] = gy[0] * silu_grad_fast(gate[e * ldg + c]);
 }
 
+// ------------------------------------------------------------------------------------------------ k11s: skinny SO3 linears
+// The feed-forward block's SO3_LinearV2 pair maps 16 <-> 512 channels per coefficient row (EF:232-262, 655-671).  With a
+// 16-long contraction the MFMA tile kernel (k11) is only a vehicle for moving the [N, K, 512] tensor: 0.78 ms to WRITE it
+// (3.3 TB/s) and 0.9-1.0 ms to reduce it into a [16, 512] weight gradient (its four 128-column tiles fetch every 2 KB row in
+// four 512-byte pieces at different times).  Two VALU kernels take those two shapes: thread = one of the 512 channels, so
+// every access to the big tensor is a whole 2 KB row per node row (consecutive lanes = consecutive channels); the 16-wide
+// side of a node ([K, 16]) is loaded once per wavefront and read as lane broadcasts, fetched one node ahead.
+//   expand:  big[n, k, c]      = sum_u small[n, k, u] * W[l(k)][c][u]  (+ bias[c] on k = 0)         (forward 16 -> 512; dX 512 -> 16)
+//   reduce:  part[b][l][u][c]  = sum_{n in block b} sum_{k in l} small[n, k, u] * big[n, k, c]        (both weight gradients)
+// W is addressed with strides (w_l, w_c, w_u) so that one kernel serves weight[l][c][u] and weight[l][u][c].
+template <int L>
+__global__ void __launch_bounds__(256) so3_skinny_expand_kernel(const float* __restrict__ small, const float* __restrict__ W,
+                                                                long long w_l, long long w_c, long long w_u,
+                                                                const float* __restrict__ bias, float* __restrict__ big, int N,
+                                                                int npb) {
+    constexpr int K = (L + 1) * (L + 1), C = 512;
+    const int lane = threadIdx.x & 63;
+    const int c = (int)(blockIdx.x & 1) * 256 + threadIdx.x;
+    const int n0 = (int)(blockIdx.x >> 1) * npb;
+    const int n1 = n0 + npb < N ? n0 + npb : N;
+    if (n0 >= n1) return;
+    float w[L + 1][16];
+#pragma unroll
+    for (int l = 0; l <= L; ++l)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w[l][u] = W[l * w_l + c * w_c + u * w_u];
+    const float bc = bias ? bias[c] : 0.f;
+    // the node's [K, 16] rows: one coalesced load per wavefront (lane i holds elements i, i + 64, ..), every use is a lane
+    // broadcast into a scalar register (as the Wigner records of k4 / k10); the next node's rows are fetched a node ahead.
+    // (Scalar loads of the rows: 1.25 ms - every use waits for ALL outstanding scalar loads.  Through LDS, 100 broadcast
+    // ds_read_b128 per wavefront and node: 0.72 ms, LDS-bandwidth bound, and a barrier per node.  This form: 0.81 ms.)
+    WRows<K * 16> X, Xn;
+    Xn.load(small + (long long)n0 * K * 16, lane);
+    for (int n = n0; n < n1; ++n) {
+        X = Xn;
+        Xn.load(small + (long long)(n + 1 < n1 ? n + 1 : n) * K * 16, lane);
+        float* o = big + (long long)n * K * C + c;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            int l = 0;
+            while ((l + 1) * (l + 1) <= k) ++l;
+            float a = k == 0 ? bc : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a = fmaf(W_AT(X, k * 16 + u), w[l][u], a);
+            o[k * C] = a;
+        }
+    }
+}
+
+// out_cu: partial rows are [l][c][u] (the layout of weight[l][c][u]); otherwise [l][u][c].  bias_row: one more row [C] per
+// partial = sum over the block's nodes of big[n, 0, c] (the bias gradient of the 16 -> 512 map).  part: [blocks/2][PSZ].
+template <int L>
+__global__ void __launch_bounds__(256) so3_skinny_reduce_kernel(const float* __restrict__ small, const float* __restrict__ big,
+                                                                float* __restrict__ part, int N, int npb, int out_cu,
+                                                                int bias_row) {
+    constexpr int K = (L + 1) * (L + 1), C = 512;
+    const int lane = threadIdx.x & 63;
+    const int c = (int)(blockIdx.x & 1) * 256 + threadIdx.x;
+    const int n0 = (int)(blockIdx.x >> 1) * npb;
+    const int n1 = n0 + npb < N ? n0 + npb : N;
+    float acc[L + 1][16], accb = 0.f;
+#pragma unroll
+    for (int l = 0; l <= L; ++l)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc[l][u] = 0.f;
+    if (n0 < n1) {
+        WRows<K * 16> X, Xn;
+        float bv[K], bn[K];
+        Xn.load(small + (long long)n0 * K * 16, lane);
+#pragma unroll
+        for (int k = 0; k < K; ++k) bn[k] = big[((long long)n0 * K + k) * C + c];
+        for (int n = n0; n < n1; ++n) {
+            X = Xn;
+#pragma unroll
+            for (int k = 0; k < K; ++k) bv[k] = bn[k];
+            const int nn = n + 1 < n1 ? n + 1 : n;                   // the next node's rows travel during this node's FMAs
+            Xn.load(small + (long long)nn * K * 16, lane);
+#pragma unroll
+            for (int k = 0; k < K; ++k) bn[k] = big[((long long)nn * K + k) * C + c];
+            accb += bv[0];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                int l = 0;
+                while ((l + 1) * (l + 1) <= k) ++l;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    acc[l][u] = fmaf(W_AT(X, k * 16 + u), bv[k], acc[l][u]);
+                    // one VGPR per accumulator: without this the SLP vectoriser pairs them into v_pk_fma_f32, parks the pairs
+                    // in AGPRs and shuffles (512 registers + scratch for 80 accumulators)
+                    SINGA_KEEP_VGPR(acc[l][u]);
+                }
+            }
+        }
+    }
+    constexpr int WSZ_ = (L + 1) * 16 * C;
+    float* p = part + (long long)(blockIdx.x >> 1) * (WSZ_ + (bias_row ? C : 0));
+#pragma unroll
+    for (int l = 0; l <= L; ++l)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            if (out_cu) p[(l * C + c) * 16 + u] = acc[l][u];
+            else p[(l * 16 + u) * C + c] = acc[l][u];
+        }
+    if (bias_row) p[WSZ_ + c] = accb;
+}
+
 // ------------------------------------------------------------------------------------------------ k12: equivariant RMS norm
 __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -3533,6 +3644,69 @@ int singa_s2act_sep_bwd(const singa_seg_t* x, int nseg, const float* gate, int64
                                                   (hipStream_t)stream, s, gate, (long long)ldg, P, Q, A, g_out, gx, g_gate,
                                                   EC));
     return check_launch("s2act_sep_bwd");
+}
+
+static inline int so3_skinny_npb(int N, int target_blocks) {
+    int npb = (N + target_blocks - 1) / target_blocks;
+    return npb < 8 ? 8 : npb;
+}
+
+// workgroup pairs (two 256-channel halves) of the reduction: as many as run concurrently in ONE round (every workgroup walks
+// its nodes sequentially, so a partly filled second round would cost a full round's time)
+static int so3_skinny_reduce_pairs(int lmax) {
+    static int cached[8] = {0};
+    if (lmax < 0 || lmax > 7) return 512;
+    if (cached[lmax]) return cached[lmax];
+    int per_cu = 0, cus = 256;
+    hipError_t e = hipErrorInvalidValue;
+    if (lmax == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, so3_skinny_reduce_kernel<2>, 256, 0);
+    if (lmax == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, so3_skinny_reduce_kernel<4>, 256, 0);
+    if (lmax == 6) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, so3_skinny_reduce_kernel<6>, 256, 0);
+    if (e != hipSuccess || per_cu < 1) per_cu = 2;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    cached[lmax] = per_cu * cus / 2;
+    return cached[lmax];
+}
+
+int singa_so3_skinny_nparts(int N, int lmax) {
+    if (N <= 0) return 0;
+    const int npb = so3_skinny_npb(N, so3_skinny_reduce_pairs(lmax));
+    return (N + npb - 1) / npb;
+}
+
+int singa_so3_skinny_expand(const float* small, const float* W, long long w_l, long long w_c, long long w_u, const float* bias,
+                            float* big, int N, int lmax, void* stream) {
+    if (!small || !W || !big) return fail(SINGA_E_NULL, "so3_skinny_expand: null pointer");
+    if (N <= 0) return SINGA_OK;
+    const int npb = so3_skinny_npb(N, 1536);
+    const dim3 grid(2u * (unsigned)((N + npb - 1) / npb)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (lmax) {
+        case 2: hipLaunchKernelGGL((so3_skinny_expand_kernel<2>), grid, block, 0, st, small, W, w_l, w_c, w_u, bias, big, N, npb); break;
+        case 4: hipLaunchKernelGGL((so3_skinny_expand_kernel<4>), grid, block, 0, st, small, W, w_l, w_c, w_u, bias, big, N, npb); break;
+        case 6: hipLaunchKernelGGL((so3_skinny_expand_kernel<6>), grid, block, 0, st, small, W, w_l, w_c, w_u, bias, big, N, npb); break;
+        default: return fail(SINGA_E_LMAX, "so3_skinny: lmax must be 2, 4 or 6");
+    }
+    return check_launch("so3_skinny_expand");
+}
+
+int singa_so3_skinny_reduce(const float* small, const float* big, float* part, int N, int lmax, int out_cu, int bias_row,
+                            void* stream) {
+    if (!small || !big || !part) return fail(SINGA_E_NULL, "so3_skinny_reduce: null pointer");
+    if (N <= 0) return SINGA_OK;
+    const int npb = so3_skinny_npb(N, so3_skinny_reduce_pairs(lmax));
+    const dim3 grid(2u * (unsigned)((N + npb - 1) / npb)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    switch (lmax) {
+        case 2: hipLaunchKernelGGL((so3_skinny_reduce_kernel<2>), grid, block, 0, st, small, big, part, N, npb, out_cu, bias_row); break;
+        case 4: hipLaunchKernelGGL((so3_skinny_reduce_kernel<4>), grid, block, 0, st, small, big, part, N, npb, out_cu, bias_row); break;
+        case 6: hipLaunchKernelGGL((so3_skinny_reduce_kernel<6>), grid, block, 0, st, small, big, part, N, npb, out_cu, bias_row); break;
+        default: return fail(SINGA_E_LMAX, "so3_skinny: lmax must be 2, 4 or 6");
+    }
+    return check_launch("so3_skinny_reduce");
 }
 
 int singa_adam_step(float* const* p, const float* const* g, float* const* m, float* const* v, const long long* sizes,

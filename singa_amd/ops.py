@@ -1092,6 +1092,7 @@ class _Linear(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------- k7 / k11: own f32 MFMA GEMM
 USE_OWN_GEMM = _os.environ.get("SINGA_GEMM", "own") == "own"      # "lib": the library GEMMs (kept as the tests' cross-check)
 USE_OWN_SO3 = _os.environ.get("SINGA_SO3_GEMM", "own") == "own"
+USE_SKINNY_SO3 = _os.environ.get("SINGA_SO3_SKINNY", "1") == "1"      # k11s for the 16 <-> 512 channel SO3 linears
 _GEMM_SPLIT_ROWS = int(_os.environ.get("SINGA_GEMM_SPLIT_ROWS", "2048"))
 
 
@@ -1245,15 +1246,20 @@ class _SO3Linear(torch.autograd.Function):
         N, K, cin = x.shape
         cout = weight.shape[1]
         out = torch.empty(N, K, cout, device=x.device, dtype=torch.float32)
-        items = []
-        for l in range(L + 1):
-            n = 2 * l + 1
-            items.append(dict(a=x.data_ptr() + 4 * l * l * cin, lda=cin, a_group=n, a_group_ld=K * cin,
-                              b=weight.data_ptr() + 4 * l * cout * cin, ldb=cin,
-                              c=out.data_ptr() + 4 * l * l * cout, ldc=cout, c_group=n, c_group_ld=K * cout,
-                              bias=bias.data_ptr() if l == 0 else None, I=N * n, J=cout, R=cin))
-        if N > 0:
-            _gemm(items, True, True)
+        if USE_SKINNY_SO3 and cin == 16 and cout == 512:
+            # k11s: a 16-long contraction - VALU kernel, thread = output channel, whole 2 KB rows per store
+            _chk(_lib.lib().singa_so3_skinny_expand(_p(x), _p(weight), cout * cin, cin, 1, _p(bias), _p(out), N, L, _stream()),
+                 "singa_so3_skinny_expand")
+        else:
+            items = []
+            for l in range(L + 1):
+                n = 2 * l + 1
+                items.append(dict(a=x.data_ptr() + 4 * l * l * cin, lda=cin, a_group=n, a_group_ld=K * cin,
+                                  b=weight.data_ptr() + 4 * l * cout * cin, ldb=cin,
+                                  c=out.data_ptr() + 4 * l * l * cout, ldc=cout, c_group=n, c_group_ld=K * cout,
+                                  bias=bias.data_ptr() if l == 0 else None, I=N * n, J=cout, R=cin))
+            if N > 0:
+                _gemm(items, True, True)
         ctx.save_for_backward(x, weight)
         ctx.L = L
         return out
@@ -1265,18 +1271,41 @@ class _SO3Linear(torch.autograd.Function):
         g = g.contiguous()
         N, K, cin = x.shape
         cout = weight.shape[1]
+        lib = _lib.lib()
+        skinny = USE_SKINNY_SO3 and N > 0 and ((cin == 16 and cout == 512) or (cin == 512 and cout == 16))
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
-            items = []
-            for l in range(L + 1):
-                n = 2 * l + 1
-                items.append(dict(a=g.data_ptr() + 4 * l * l * cout, lda=cout, a_group=n, a_group_ld=K * cout,
-                                  b=weight.data_ptr() + 4 * l * cout * cin, ldb=cin,
-                                  c=gx.data_ptr() + 4 * l * l * cin, ldc=cin, c_group=n, c_group_ld=K * cin,
-                                  I=N * n, J=cin, R=cout))
-            if N > 0:
-                _gemm(items, True, False)
+            if skinny and cout == 16:
+                # k11s: d x = g expanded through weight[l][u][c] - again a 16-long contraction
+                _chk(lib.singa_so3_skinny_expand(_p(g), _p(weight), cout * cin, 1, cin, None, _p(gx), N, L, _stream()),
+                     "singa_so3_skinny_expand(dx)")
+            else:
+                items = []
+                for l in range(L + 1):
+                    n = 2 * l + 1
+                    items.append(dict(a=g.data_ptr() + 4 * l * l * cout, lda=cout, a_group=n, a_group_ld=K * cout,
+                                      b=weight.data_ptr() + 4 * l * cout * cin, ldb=cin,
+                                      c=gx.data_ptr() + 4 * l * l * cin, ldc=cin, c_group=n, c_group_ld=K * cin,
+                                      I=N * n, J=cin, R=cout))
+                if N > 0:
+                    _gemm(items, True, False)
+        if skinny:
+            # k11s: the weight gradient as a VALU reduction over whole 2 KB rows of the 512-channel tensor (16 -> 512:
+            # small = x, big = g, rows [l][c][u] + the bias gradient; 512 -> 16: small = g, big = x, rows [l][u][c])
+            wide_out = cout == 512
+            wsz = (L + 1) * 16 * 512
+            part = torch.empty(lib.singa_so3_skinny_nparts(N, L), wsz + (512 if wide_out else 0), device=x.device,
+                               dtype=torch.float32)
+            small, big = (x, g) if wide_out else (g, x)
+            _chk(lib.singa_so3_skinny_reduce(_p(small), _p(big), _p(part), N, L, int(wide_out), int(wide_out), _stream()),
+                 "singa_so3_skinny_reduce")
+            if wide_out:
+                gw, gb = param_colsum(part, [(0, wsz, ctx.params[0]), (wsz, 512, ctx.params[1])])
+            else:
+                gw = param_colsum(part, [(0, wsz, ctx.params[0])])[0]
+                gb = param_colsum(g[:, 0, :], [(0, cout, ctx.params[1])])[0]
+            return gx, (gw.view(L + 1, cout, cin) if gw is not None else None), gb, None
         # dW_l = sum over the (node, row) pairs of degree l of g_row^T x_row
         sz = cout * cin
         S = _splits_for(N * (2 * L + 1))

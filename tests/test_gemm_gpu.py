@@ -114,10 +114,12 @@ def test_so2_convolution_matches_oracle(L, cin, cout, extra):
             ops.USE_OWN_GEMM, ops._GEMM_SPLIT_ROWS = True, 2048
 
 
-@pytest.mark.parametrize("L,cin,cout", [(2, 16, 512), (4, 512, 16), (4, 112, 16), (6, 16, 512), (6, 512, 16)])
+@pytest.mark.parametrize("L,cin,cout", [(2, 16, 512), (2, 512, 16), (4, 16, 512), (4, 512, 16), (4, 112, 16), (6, 16, 512),
+                                        (6, 512, 16)])
 def test_so3_linear_matches_oracle(L, cin, cout):
-    """ops.so3_linear (k11: one grouped-row problem per degree) vs oracle.so3_linear (EF:655-671): output, d input,
-    d weight per degree, d bias; N = 333 nodes (ragged tiles, several reduction splits)."""
+    """ops.so3_linear vs oracle.so3_linear (EF:655-671): output, d input, d weight per degree, d bias; N = 333 nodes (ragged
+    tiles, several reduction splits / partial rows).  Three evaluations: the VALU kernels k11s for the 16 <-> 512 shapes,
+    the MFMA kernel k11 (one grouped-row problem per degree), the BLAS libraries."""
     from singa_amd import ops
     N, K = 333, (L + 1) ** 2
     g = torch.Generator().manual_seed(L + cin)
@@ -128,8 +130,8 @@ def test_so3_linear_matches_oracle(L, cin, cout):
     want = O.so3_linear(sdo, "p", xo, L)
     gy = torch.randn(want.shape, generator=g)
     (want * gy).sum().backward()
-    for own in (True, False):
-        ops.USE_OWN_GEMM, ops._GEMM_SPLIT_ROWS = own, 500
+    for own, skinny in ((True, True), (True, False), (False, False)):
+        ops.USE_OWN_GEMM, ops._GEMM_SPLIT_ROWS, ops.USE_SKINNY_SO3 = own, 500, skinny
         try:
             xd = x.to(DEV).requires_grad_(True)
             w, b = sd["p.weight"].to(DEV).requires_grad_(True), sd["p.bias"].to(DEV).requires_grad_(True)
@@ -140,7 +142,7 @@ def test_so3_linear_matches_oracle(L, cin, cout):
             assert rel_err(w.grad.cpu(), sdo["p.weight"].grad) < 1e-5
             assert rel_err(b.grad.cpu(), sdo["p.bias"].grad) < 1e-5
         finally:
-            ops.USE_OWN_GEMM, ops._GEMM_SPLIT_ROWS = True, 2048
+            ops.USE_OWN_GEMM, ops._GEMM_SPLIT_ROWS, ops.USE_SKINNY_SO3 = True, 2048, True
 
 
 def test_so2_and_so3_linear_on_empty_inputs():
