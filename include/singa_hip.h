@@ -304,17 +304,18 @@ int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_con
 /* resident workgroups per CU of one kernel variant (cfg 0: 128x128, 1: 128x32, 2: 32x128 tiles), for the lab probes */
 int singa_gemm_occupancy(int a_r_contig, int b_r_contig, int cfg);
 
-/* k11s - SO3_LinearV2 (model/EF_layers.py:655-671) between 16 and 512 channels (the feed-forward block, EF:232-262), where
+/* k11s - SO3_LinearV2 (model/EF_layers.py:655-671) between 16 and C = 512 channels (the feed-forward block, EF:232-262) or
+ * C = 112 (the attention's output projection, EF:1201-1204; there only the backward maps 16 -> 112 channels), where
  * the contraction is only 16 long: VALU kernels, thread = one of the 512 channels, whole 2 KB rows of the big tensor per access.
  * _expand: big[N, K, 512] = sum_u small[N, K, 16][.., u] * W[l(k)][c][u] (+ bias[c] on the l = 0 row; bias may be NULL), W
  * addressed as W[l * w_l + c * w_c + u * w_u] (weight[l][c][u]: w_c = 16, w_u = 1; weight[l][u][c]: w_c = 1, w_u = 512).
- * _reduce: partial weight gradients part[singa_so3_skinny_nparts(N, lmax)][(L+1) * 16 * 512 (+ 512 if bias_row)], each row
+ * _reduce: partial weight gradients part[singa_so3_skinny_nparts(N, lmax, C)][(L+1) * 16 * C (+ C if bias_row)], each row
  * [l][c][u] (out_cu != 0) or [l][u][c], = sum over the part's nodes and the rows k of degree l of small[n, k, u] * big[n, k, c];
  * the bias row is sum_n big[n, 0, c].  The caller adds the parts up (singa_colsum / singa_colsum_multi). */
-int singa_so3_skinny_nparts(int N, int lmax);
+int singa_so3_skinny_nparts(int N, int lmax, int C);
 int singa_so3_skinny_expand(const float* small, const float* W, long long w_l, long long w_c, long long w_u, const float* bias,
-                            float* big, int N, int lmax, void* stream);
-int singa_so3_skinny_reduce(const float* small, const float* big, float* part, int N, int lmax, int out_cu, int bias_row,
+                            float* big, int N, int C, int lmax, void* stream);
+int singa_so3_skinny_reduce(const float* small, const float* big, float* part, int N, int C, int lmax, int out_cu, int bias_row,
                             void* stream);
 
 /* Total 2-norm of all gradients over the same (tensor, chunk) table as singa_adam_step: torch.nn.utils.clip_grad_norm_'s

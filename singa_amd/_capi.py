@@ -79,9 +79,9 @@ _SIGS = {
     "singa_ln_silu_bwd": ([P] * 6 + [I64, I32, F32, P], I32),
     "singa_colsum_work": ([C.c_longlong, I32], C.c_longlong),
     "singa_colsum": ([P, C.c_longlong, C.c_longlong, I32, P, P, P], I32),
-    "singa_so3_skinny_nparts": ([I32, I32], I32),
-    "singa_so3_skinny_expand": ([P, P, I64, I64, I64, P, P, I32, I32, P], I32),
-    "singa_so3_skinny_reduce": ([P, P, P, I32, I32, I32, I32, P], I32),
+    "singa_so3_skinny_nparts": ([I32, I32, I32], I32),
+    "singa_so3_skinny_expand": ([P, P, I64, I64, I64, P, P, I32, I32, I32, P], I32),
+    "singa_so3_skinny_reduce": ([P, P, P, I32, I32, I32, I32, I32, P], I32),
     "singa_colsum_multi_work": ([C.c_longlong, I32], C.c_longlong),
     "singa_colsum_multi": ([I32, P, P, P, P, P, I32, P, P, P, C.c_longlong, P], I32),
     "singa_adam_step": ([P, P, P, P, P, P, P, I32, I32, P, P, F32, F32, F32, P], I32),

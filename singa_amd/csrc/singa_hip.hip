@@ -2615,15 +2615,25 @@ __global__ void __launch_bounds__(256) s2act_sep_bwd_kernel(Segs x, const float*
 //   expand:  big[n, k, c]      = sum_u small[n, k, u] * W[l(k)][c][u]  (+ bias[c] on k = 0)         (forward 16 -> 512; dX 512 -> 16)
 //   reduce:  part[b][l][u][c]  = sum_{n in block b} sum_{k in l} small[n, k, u] * big[n, k, c]        (both weight gradients)
 // W is addressed with strides (w_l, w_c, w_u) so that one kernel serves weight[l][c][u] and weight[l][u][c].
-template <int L>
-__global__ void __launch_bounds__(256) so3_skinny_expand_kernel(const float* __restrict__ small, const float* __restrict__ W,
+// C = 512: two workgroups of 256 threads per run of nodes (blockIdx & 1 = channel half); C = 112 (the attention's output
+// projection, EF:1201-1204): one workgroup of 128 threads, 112 of them active.
+template <int C>
+struct SkinnyCfg {
+    static constexpr int HALVES = C > 256 ? 2 : 1;
+    static constexpr int BLOCK = (C / HALVES + 63) / 64 * 64;
+};
+
+template <int L, int C>
+__global__ void __launch_bounds__(SkinnyCfg<C>::BLOCK) so3_skinny_expand_kernel(const float* __restrict__ small, const float* __restrict__ W,
                                                                 long long w_l, long long w_c, long long w_u,
                                                                 const float* __restrict__ bias, float* __restrict__ big, int N,
                                                                 int npb) {
-    constexpr int K = (L + 1) * (L + 1), C = 512;
+    constexpr int K = (L + 1) * (L + 1), HV = SkinnyCfg<C>::HALVES, BL = SkinnyCfg<C>::BLOCK;
     const int lane = threadIdx.x & 63;
-    const int c = (int)(blockIdx.x & 1) * 256 + threadIdx.x;
-    const int n0 = (int)(blockIdx.x >> 1) * npb;
+    const int ct = (int)(blockIdx.x % HV) * BL + threadIdx.x;
+    const bool act = ct < C;
+    const int c = act ? ct : C - 1;                      // surplus lanes shadow the last channel (loads only, no stores)
+    const int n0 = (int)(blockIdx.x / HV) * npb;
     const int n1 = n0 + npb < N ? n0 + npb : N;
     if (n0 >= n1) return;
     float w[L + 1][16];
@@ -2649,21 +2659,23 @@ __global__ void __launch_bounds__(256) so3_skinny_expand_kernel(const float* __r
             float a = k == 0 ? bc : 0.f;
 #pragma unroll
             for (int u = 0; u < 16; ++u) a = fmaf(W_AT(X, k * 16 + u), w[l][u], a);
-            o[k * C] = a;
+            if (act) o[k * C] = a;
         }
     }
 }
 
 // out_cu: partial rows are [l][c][u] (the layout of weight[l][c][u]); otherwise [l][u][c].  bias_row: one more row [C] per
 // partial = sum over the block's nodes of big[n, 0, c] (the bias gradient of the 16 -> 512 map).  part: [blocks/2][PSZ].
-template <int L>
-__global__ void __launch_bounds__(256) so3_skinny_reduce_kernel(const float* __restrict__ small, const float* __restrict__ big,
+template <int L, int C>
+__global__ void __launch_bounds__(SkinnyCfg<C>::BLOCK) so3_skinny_reduce_kernel(const float* __restrict__ small, const float* __restrict__ big,
                                                                 float* __restrict__ part, int N, int npb, int out_cu,
                                                                 int bias_row) {
-    constexpr int K = (L + 1) * (L + 1), C = 512;
+    constexpr int K = (L + 1) * (L + 1), HV = SkinnyCfg<C>::HALVES, BL = SkinnyCfg<C>::BLOCK;
     const int lane = threadIdx.x & 63;
-    const int c = (int)(blockIdx.x & 1) * 256 + threadIdx.x;
-    const int n0 = (int)(blockIdx.x >> 1) * npb;
+    const int ct = (int)(blockIdx.x % HV) * BL + threadIdx.x;
+    const bool act = ct < C;
+    const int c = act ? ct : C - 1;
+    const int n0 = (int)(blockIdx.x / HV) * npb;
     const int n1 = n0 + npb < N ? n0 + npb : N;
     float acc[L + 1][16], accb = 0.f;
 #pragma unroll
@@ -2700,7 +2712,8 @@ __global__ void __launch_bounds__(256) so3_skinny_reduce_kernel(const float* __r
         }
     }
     constexpr int WSZ_ = (L + 1) * 16 * C;
-    float* p = part + (long long)(blockIdx.x >> 1) * (WSZ_ + (bias_row ? C : 0));
+    float* p = part + (long long)(blockIdx.x / HV) * (WSZ_ + (bias_row ? C : 0));
+    if (!act) return;
 #pragma unroll
     for (int l = 0; l <= L; ++l)
 #pragma unroll
@@ -2710,6 +2723,34 @@ __global__ void __launch_bounds__(256) so3_skinny_reduce_kernel(const float* __r
         }
     if (bias_row) p[WSZ_ + c] = accb;
 }
+
+static inline int so3_skinny_npb(int N, int target_blocks) {
+    int npb = (N + target_blocks - 1) / target_blocks;
+    return npb < 8 ? 8 : npb;
+}
+
+// node runs of the reduction: as many as run concurrently in ONE round (every workgroup walks its nodes sequentially, so
+// a partly filled second round would cost a full round's time)
+template <int C>
+static int so3_skinny_reduce_runs(int lmax) {
+    static int cached[8] = {0};
+    if (lmax < 0 || lmax > 7) return 512;
+    if (cached[lmax]) return cached[lmax];
+    int per_cu = 0, cus = 256;
+    hipError_t e = hipErrorInvalidValue;
+    constexpr int BL = SkinnyCfg<C>::BLOCK;
+    if (lmax == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, so3_skinny_reduce_kernel<2, C>, BL, 0);
+    if (lmax == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, so3_skinny_reduce_kernel<4, C>, BL, 0);
+    if (lmax == 6) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, so3_skinny_reduce_kernel<6, C>, BL, 0);
+    if (e != hipSuccess || per_cu < 1) per_cu = 2;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+    cached[lmax] = per_cu * cus / SkinnyCfg<C>::HALVES;
+    return cached[lmax];
+}
+static inline bool so3_skinny_channels_ok(int C) { return C == 512 || C == 112; }
 
 // ------------------------------------------------------------------------------------------------ k12: equivariant RMS norm
 __device__ __forceinline__ float wave_sum(float v) {
@@ -3646,66 +3687,59 @@ int singa_s2act_sep_bwd(const singa_seg_t* x, int nseg, const float* gate, int64
     return check_launch("s2act_sep_bwd");
 }
 
-static inline int so3_skinny_npb(int N, int target_blocks) {
-    int npb = (N + target_blocks - 1) / target_blocks;
-    return npb < 8 ? 8 : npb;
-}
 
-// workgroup pairs (two 256-channel halves) of the reduction: as many as run concurrently in ONE round (every workgroup walks
-// its nodes sequentially, so a partly filled second round would cost a full round's time)
-static int so3_skinny_reduce_pairs(int lmax) {
-    static int cached[8] = {0};
-    if (lmax < 0 || lmax > 7) return 512;
-    if (cached[lmax]) return cached[lmax];
-    int per_cu = 0, cus = 256;
-    hipError_t e = hipErrorInvalidValue;
-    if (lmax == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, so3_skinny_reduce_kernel<2>, 256, 0);
-    if (lmax == 4) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, so3_skinny_reduce_kernel<4>, 256, 0);
-    if (lmax == 6) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, so3_skinny_reduce_kernel<6>, 256, 0);
-    if (e != hipSuccess || per_cu < 1) per_cu = 2;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-        cus = prop.multiProcessorCount;
-    cached[lmax] = per_cu * cus / 2;
-    return cached[lmax];
-}
-
-int singa_so3_skinny_nparts(int N, int lmax) {
-    if (N <= 0) return 0;
-    const int npb = so3_skinny_npb(N, so3_skinny_reduce_pairs(lmax));
+int singa_so3_skinny_nparts(int N, int lmax, int C) {
+    if (N <= 0 || !so3_skinny_channels_ok(C)) return 0;
+    const int runs = C == 512 ? so3_skinny_reduce_runs<512>(lmax) : so3_skinny_reduce_runs<112>(lmax);
+    const int npb = so3_skinny_npb(N, runs);
     return (N + npb - 1) / npb;
 }
 
+#define SINGA_SKINNY_LC(lmax, C, ...)                                                      \
+    do {                                                                                   \
+        if ((C) == 512) {                                                                  \
+            constexpr int C_ = 512;                                                        \
+            switch (lmax) {                                                                \
+                case 2: { constexpr int L_ = 2; __VA_ARGS__; } break;                      \
+                case 4: { constexpr int L_ = 4; __VA_ARGS__; } break;                      \
+                case 6: { constexpr int L_ = 6; __VA_ARGS__; } break;                      \
+                default: return fail(SINGA_E_LMAX, "so3_skinny: lmax must be 2, 4 or 6");  \
+            }                                                                              \
+        } else {                                                                           \
+            constexpr int C_ = 112;                                                        \
+            switch (lmax) {                                                                \
+                case 2: { constexpr int L_ = 2; __VA_ARGS__; } break;                      \
+                case 4: { constexpr int L_ = 4; __VA_ARGS__; } break;                      \
+                case 6: { constexpr int L_ = 6; __VA_ARGS__; } break;                      \
+                default: return fail(SINGA_E_LMAX, "so3_skinny: lmax must be 2, 4 or 6");  \
+            }                                                                              \
+        }                                                                                  \
+    } while (0)
+
 int singa_so3_skinny_expand(const float* small, const float* W, long long w_l, long long w_c, long long w_u, const float* bias,
-                            float* big, int N, int lmax, void* stream) {
+                            float* big, int N, int C, int lmax, void* stream) {
     if (!small || !W || !big) return fail(SINGA_E_NULL, "so3_skinny_expand: null pointer");
+    if (!so3_skinny_channels_ok(C)) return fail(SINGA_E_SHAPE, "so3_skinny: built for 512 and 112 wide channels");
     if (N <= 0) return SINGA_OK;
     const int npb = so3_skinny_npb(N, 1536);
-    const dim3 grid(2u * (unsigned)((N + npb - 1) / npb)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    switch (lmax) {
-        case 2: hipLaunchKernelGGL((so3_skinny_expand_kernel<2>), grid, block, 0, st, small, W, w_l, w_c, w_u, bias, big, N, npb); break;
-        case 4: hipLaunchKernelGGL((so3_skinny_expand_kernel<4>), grid, block, 0, st, small, W, w_l, w_c, w_u, bias, big, N, npb); break;
-        case 6: hipLaunchKernelGGL((so3_skinny_expand_kernel<6>), grid, block, 0, st, small, W, w_l, w_c, w_u, bias, big, N, npb); break;
-        default: return fail(SINGA_E_LMAX, "so3_skinny: lmax must be 2, 4 or 6");
-    }
+    SINGA_SKINNY_LC(lmax, C, hipLaunchKernelGGL((so3_skinny_expand_kernel<L_, C_>),
+                                                dim3((unsigned)(SkinnyCfg<C_>::HALVES * ((N + npb - 1) / npb))),
+                                                dim3(SkinnyCfg<C_>::BLOCK), 0, st, small, W, w_l, w_c, w_u, bias, big, N, npb));
     return check_launch("so3_skinny_expand");
 }
 
-int singa_so3_skinny_reduce(const float* small, const float* big, float* part, int N, int lmax, int out_cu, int bias_row,
+int singa_so3_skinny_reduce(const float* small, const float* big, float* part, int N, int C, int lmax, int out_cu, int bias_row,
                             void* stream) {
     if (!small || !big || !part) return fail(SINGA_E_NULL, "so3_skinny_reduce: null pointer");
+    if (!so3_skinny_channels_ok(C)) return fail(SINGA_E_SHAPE, "so3_skinny: built for 512 and 112 wide channels");
     if (N <= 0) return SINGA_OK;
-    const int npb = so3_skinny_npb(N, so3_skinny_reduce_pairs(lmax));
-    const dim3 grid(2u * (unsigned)((N + npb - 1) / npb)), block(256);
+    const int runs = C == 512 ? so3_skinny_reduce_runs<512>(lmax) : so3_skinny_reduce_runs<112>(lmax);
+    const int npb = so3_skinny_npb(N, runs);
     hipStream_t st = (hipStream_t)stream;
-    switch (lmax) {
-        case 2: hipLaunchKernelGGL((so3_skinny_reduce_kernel<2>), grid, block, 0, st, small, big, part, N, npb, out_cu, bias_row); break;
-        case 4: hipLaunchKernelGGL((so3_skinny_reduce_kernel<4>), grid, block, 0, st, small, big, part, N, npb, out_cu, bias_row); break;
-        case 6: hipLaunchKernelGGL((so3_skinny_reduce_kernel<6>), grid, block, 0, st, small, big, part, N, npb, out_cu, bias_row); break;
-        default: return fail(SINGA_E_LMAX, "so3_skinny: lmax must be 2, 4 or 6");
-    }
+    SINGA_SKINNY_LC(lmax, C, hipLaunchKernelGGL((so3_skinny_reduce_kernel<L_, C_>),
+                                                dim3((unsigned)(SkinnyCfg<C_>::HALVES * ((N + npb - 1) / npb))),
+                                                dim3(SkinnyCfg<C_>::BLOCK), 0, st, small, big, part, N, npb, out_cu, bias_row));
     return check_launch("so3_skinny_reduce");
 }
 

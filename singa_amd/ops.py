@@ -1248,8 +1248,8 @@ class _SO3Linear(torch.autograd.Function):
         out = torch.empty(N, K, cout, device=x.device, dtype=torch.float32)
         if USE_SKINNY_SO3 and cin == 16 and cout == 512:
             # k11s: a 16-long contraction - VALU kernel, thread = output channel, whole 2 KB rows per store
-            _chk(_lib.lib().singa_so3_skinny_expand(_p(x), _p(weight), cout * cin, cin, 1, _p(bias), _p(out), N, L, _stream()),
-                 "singa_so3_skinny_expand")
+            _chk(_lib.lib().singa_so3_skinny_expand(_p(x), _p(weight), cout * cin, cin, 1, _p(bias), _p(out), N, cout, L,
+                                                    _stream()), "singa_so3_skinny_expand")
         else:
             items = []
             for l in range(L + 1):
@@ -1272,13 +1272,15 @@ class _SO3Linear(torch.autograd.Function):
         N, K, cin = x.shape
         cout = weight.shape[1]
         lib = _lib.lib()
-        skinny = USE_SKINNY_SO3 and N > 0 and ((cin == 16 and cout == 512) or (cin == 512 and cout == 16))
+        # (wide, 16) pairs the VALU kernels are built for: the feed-forward block's 512 and the output projection's 112
+        skinny = USE_SKINNY_SO3 and N > 0 and ((cin == 16 and cout == 512) or (cin in (512, 112) and cout == 16))
+        wide = max(cin, cout)
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty_like(x)
             if skinny and cout == 16:
                 # k11s: d x = g expanded through weight[l][u][c] - again a 16-long contraction
-                _chk(lib.singa_so3_skinny_expand(_p(g), _p(weight), cout * cin, 1, cin, None, _p(gx), N, L, _stream()),
+                _chk(lib.singa_so3_skinny_expand(_p(g), _p(weight), cout * cin, 1, cin, None, _p(gx), N, wide, L, _stream()),
                      "singa_so3_skinny_expand(dx)")
             else:
                 items = []
@@ -1293,15 +1295,15 @@ class _SO3Linear(torch.autograd.Function):
         if skinny:
             # k11s: the weight gradient as a VALU reduction over whole 2 KB rows of the 512-channel tensor (16 -> 512:
             # small = x, big = g, rows [l][c][u] + the bias gradient; 512 -> 16: small = g, big = x, rows [l][u][c])
-            wide_out = cout == 512
-            wsz = (L + 1) * 16 * 512
-            part = torch.empty(lib.singa_so3_skinny_nparts(N, L), wsz + (512 if wide_out else 0), device=x.device,
+            wide_out = cout == wide
+            wsz = (L + 1) * 16 * wide
+            part = torch.empty(lib.singa_so3_skinny_nparts(N, L, wide), wsz + (wide if wide_out else 0), device=x.device,
                                dtype=torch.float32)
             small, big = (x, g) if wide_out else (g, x)
-            _chk(lib.singa_so3_skinny_reduce(_p(small), _p(big), _p(part), N, L, int(wide_out), int(wide_out), _stream()),
+            _chk(lib.singa_so3_skinny_reduce(_p(small), _p(big), _p(part), N, wide, L, int(wide_out), int(wide_out), _stream()),
                  "singa_so3_skinny_reduce")
             if wide_out:
-                gw, gb = param_colsum(part, [(0, wsz, ctx.params[0]), (wsz, 512, ctx.params[1])])
+                gw, gb = param_colsum(part, [(0, wsz, ctx.params[0]), (wsz, wide, ctx.params[1])])
             else:
                 gw = param_colsum(part, [(0, wsz, ctx.params[0])])[0]
                 gb = param_colsum(g[:, 0, :], [(0, cout, ctx.params[1])])[0]

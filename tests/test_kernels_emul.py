@@ -341,40 +341,41 @@ def test_s2act_separable(emul, L, edge):
     assert np.abs(gg - want_g.numpy()).max() < 1e-5
 
 
-@pytest.mark.parametrize("L", [2, 4, 6])
-def test_so3_skinny_kernels(emul, L):
+@pytest.mark.parametrize("L,C", [(2, 512), (4, 512), (6, 512), (4, 112), (6, 112)])
+def test_so3_skinny_kernels(emul, L, C):
     """k11s: the 16 <-> 512 channel SO3 linears as VALU kernels - expand (forward 16 -> 512 with bias, and d x of 512 -> 16
     through weight[l][u][c]) and reduce (both weight gradients + the bias row) against einsum in float64."""
     rs = np.random.RandomState(40 + L)
-    N, K, C = 13, (L + 1) ** 2, 512
+    N, K = 13, (L + 1) ** 2
     deg = np.asarray(so3.layout(L, L).degree)
     small = rs.randn(N, K, 16).astype(np.float32)
     w_cu = (rs.randn(L + 1, C, 16) * 0.25).astype(np.float32)           # weight[l][c][u] of a 16 -> 512 map
     w_uc = (rs.randn(L + 1, 16, C) * 0.25).astype(np.float32)           # weight[l][u][c] of a 512 -> 16 map
     bias = rs.randn(C).astype(np.float32)
     big = np.full((N, K, C), np.nan, np.float32)
-    assert emul.singa_so3_skinny_expand(ptr(small), ptr(w_cu), C * 16, 16, 1, ptr(bias), ptr(big), N, L, None) == 0
+    assert emul.singa_so3_skinny_expand(ptr(small), ptr(w_cu), C * 16, 16, 1, ptr(bias), ptr(big), N, C, L, None) == 0
     want = np.einsum("nku,kcu->nkc", small.astype(np.float64), w_cu[deg].astype(np.float64))
     want[:, 0] += bias
     assert np.abs(big - want).max() < 1e-4
     big2 = np.full((N, K, C), np.nan, np.float32)
-    assert emul.singa_so3_skinny_expand(ptr(small), ptr(w_uc), 16 * C, 1, C, None, ptr(big2), N, L, None) == 0
+    assert emul.singa_so3_skinny_expand(ptr(small), ptr(w_uc), 16 * C, 1, C, None, ptr(big2), N, C, L, None) == 0
     assert np.abs(big2 - np.einsum("nku,kuc->nkc", small.astype(np.float64), w_uc[deg].astype(np.float64))).max() < 1e-4
     # reductions
     g = rs.randn(N, K, C).astype(np.float32)
     onehot = np.eye(L + 1)[deg]                                           # [K, L+1]
     ref_uc = np.einsum("kl,nku,nkc->luc", onehot, small.astype(np.float64), g.astype(np.float64))
-    nparts = emul.singa_so3_skinny_nparts(N, L)
+    nparts = emul.singa_so3_skinny_nparts(N, L, C)
     wsz = (L + 1) * 16 * C
     for out_cu, bias_row in ((1, 1), (0, 0)):
         part = np.full((nparts, wsz + (C if bias_row else 0)), np.nan, np.float32)
-        assert emul.singa_so3_skinny_reduce(ptr(small), ptr(g), ptr(part), N, L, out_cu, bias_row, None) == 0
+        assert emul.singa_so3_skinny_reduce(ptr(small), ptr(g), ptr(part), N, C, L, out_cu, bias_row, None) == 0
         tot = part.astype(np.float64).sum(0)
         got = tot[:wsz].reshape(L + 1, C, 16).transpose(0, 2, 1) if out_cu else tot[:wsz].reshape(L + 1, 16, C)
         assert np.abs(got - ref_uc).max() < 1e-3 * max(1.0, np.abs(ref_uc).max())
         if bias_row:
             assert np.abs(tot[wsz:] - g[:, 0].astype(np.float64).sum(0)).max() < 1e-4
-    assert emul.singa_so3_skinny_expand(ptr(small), ptr(w_cu), C * 16, 16, 1, None, ptr(big), N, 5, None) == -2
+    assert emul.singa_so3_skinny_expand(ptr(small), ptr(w_cu), C * 16, 16, 1, None, ptr(big), N, C, 5, None) == -2
+    assert emul.singa_so3_skinny_expand(ptr(small), ptr(w_cu), C * 16, 16, 1, None, ptr(big), N, 100, L, None) == -3
 
 
 def test_ln_silu(emul):
