@@ -39,7 +39,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg3_b128_l4")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="N > 1 only.  Default strong = BASELINE.json configs[3] (the SAME batch split over the ranks); the "
+                         "weak figure (every rank its own full batch) is then measured too and reported under 'weak'")
+    ap.add_argument("--proxy-workload", default="cfg4_shard_r0of8",
+                    help="N = 1, default workload only: also time the shard one rank of the 8-GPU strong split owns")
+    ap.add_argument("--proxy-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-prefetch", action="store_true",
@@ -50,6 +55,7 @@ def parse():
     ap.add_argument("--growth", type=float, default=1.04, help="width of a size class of the bucketed replay")
     ap.add_argument("--roofline-steps", type=int, default=2, help="instrumented eager steps after the timed region")
     ap.add_argument("--cpu-graphs", type=int, default=8, help="graphs in the bounded CPU-oracle sample")
+    ap.add_argument("--cpu-graphs-1t", type=int, default=2, help="graphs of the one-thread CPU-oracle figure (0 = skip)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-state", type=str, default=None, help=argparse.SUPPRESS)
@@ -160,52 +166,81 @@ def host_cores():
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline (oracle)
-def cpu_baseline_worker(workload, n_graphs, threads, state=None):
-    """Runs in a child process that never touches the GPU: times the CPU oracle (kind 'port':
-    oracle/singa_oracle.py, pinned to the reference by tests/golden) on a bounded sample of the same workload -
-    forward + CrossEntropy + backward of the first `n_graphs` synthetic graphs - and prints one JSON object."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline_worker(workload, n_graphs, threads, state=None, n_graphs_1t=2):
+    """Runs in a child process that never touches the GPU: times the CPU oracle (kind 'port': oracle/singa_oracle.py,
+    pinned to the reference by tests/golden) on a bounded sample of the same workload - the whole step of train.py:113-133
+    (zero_grad, forward, CrossEntropy, backward, gradient norm, Adam) on the first `n_graphs` synthetic graphs with all
+    host threads, then on the first `n_graphs_1t` graphs with ONE thread - and prints one JSON object."""
     torch.set_num_threads(threads)
     from oracle import singa_oracle as O
     from singa_amd import graph as G
     from singa_amd.config import load_config
     from singa_amd.model.GAN import SINGA
-    wl = dict(G.WORKLOADS[workload])
-    L = wl["lmax"]
-    kw = {k: v for k, v in wl.items() if k not in ("n_graphs", "lmax")}
+    L, kw, ids, _ = G.resolve_workload(workload)
     cfg = load_config(lmax=L)
     torch.manual_seed(cfg.train.seed)
     model = SINGA(cfg, device="cpu")          # parameter container only; the product forward is never called here
     if state:                                 # the GPU run's initial parameters (drawn with the device generator there)
         model.load_state_dict(torch.load(state, map_location="cpu"))
-    graphs = [G.synthetic_graph(i, **G.graph_sizes(i, **kw)) for i in range(n_graphs)]
-    b, rots, lap_p, lap_l = O.batch_from_graphs(graphs)
+    graphs = [G.synthetic_graph(i, **G.graph_sizes(i, **kw)) for i in ids[:n_graphs]]
     sd = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
-    times = []
-    for it in range(2):   # first pass warms the table caches; the second is reported
-        for v in sd.values():
-            v.grad = None
+    leaves = [v for v in sd.values() if v.requires_grad]
+    adam = torch.optim.Adam(leaves, lr=cfg.train.optimizer.lr, betas=(cfg.train.optimizer.beta1, cfg.train.optimizer.beta2))
+
+    def step(inputs, update):
+        b, rots, lap_p, lap_l = inputs
+        adam.zero_grad(set_to_none=True)
         t0 = time.perf_counter()
         loss = O.train_step_loss(sd, b, rots, L, lap_p, lap_l)
         loss.backward()
-        times.append(time.perf_counter() - t0)
-        print(f"[cpu-baseline] pass {it}: {times[-1]:.2f} s", file=sys.stderr, flush=True)
-    print(json.dumps({"loss": float(loss.detach()),
-                      "value": round(n_graphs / times[-1], 4), "unit": "graphs/s", "cores": threads, "kind": "port",
-                      "sample": f"first {n_graphs} graphs of {workload}: oracle forward+CE+backward (no Adam), "
-                                f"{threads} torch threads, {times[-1]:.1f} s"}), flush=True)
+        gn = torch.sqrt(sum((v.grad.double() ** 2).sum() for v in leaves if v.grad is not None))
+        if update:
+            adam.step()
+        return time.perf_counter() - t0, float(loss.detach()), float(gn)
+
+    full = O.batch_from_graphs(graphs)
+    # first pass warms the table caches and reports loss / gradient norm at the INITIAL parameters (no update); the second,
+    # complete with its Adam update, is the timed one
+    t_warm, loss0, gn0 = step(full, update=False)
+    print(f"[cpu-baseline] warm pass: {t_warm:.2f} s", file=sys.stderr, flush=True)
+    t_full, _, _ = step(full, update=True)
+    print(f"[cpu-baseline] timed pass, {threads} threads: {t_full:.2f} s", file=sys.stderr, flush=True)
+    out = {"loss": loss0, "grad_norm": gn0, "value": round(n_graphs / t_full, 4), "unit": "graphs/s", "cores": threads,
+           "kind": "port", "cpu": cpu_model(),
+           "sample": f"first {n_graphs} graphs of {workload}: oracle zero_grad+forward+CE+backward+grad-norm+Adam, "
+                     f"{threads} torch threads, {t_full:.1f} s"}
+    if n_graphs_1t > 0:
+        torch.set_num_threads(1)
+        small = O.batch_from_graphs(graphs[:n_graphs_1t])
+        t_1, _, _ = step(small, update=True)
+        print(f"[cpu-baseline] timed pass, 1 thread: {t_1:.2f} s", file=sys.stderr, flush=True)
+        out["one_thread"] = {"value": round(n_graphs_1t / t_1, 4), "unit": "graphs/s", "cores": 1,
+                             "sample": f"first {n_graphs_1t} graphs, same step, torch.set_num_threads(1), {t_1:.1f} s"}
+    print(json.dumps(out), flush=True)
 
 
-def cpu_baseline(workload, n_graphs, limit_s=300, state=None):
+def cpu_baseline(workload, n_graphs, limit_s=400, state=None, n_graphs_1t=2):
     threads = host_cores()
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="", OMP_NUM_THREADS=str(threads),
                MKL_NUM_THREADS=str(threads))
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--workload", workload, "--cpu-graphs",
-           str(n_graphs), "--cpu-threads", str(threads)] + (["--cpu-state", state] if state else [])
+           str(n_graphs), "--cpu-graphs-1t", str(n_graphs_1t), "--cpu-threads", str(threads)] + (["--cpu-state", state] if state else [])
     try:
         r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=limit_s, check=True)
         return json.loads(r.stdout.decode().strip().splitlines()[-1])
     except Exception as e:  # a baseline that cannot be timed must not take the GPU measurement down with it
-        return {"value": None, "unit": "graphs/s", "cores": threads, "kind": "port",
+        return {"value": None, "unit": "graphs/s", "cores": threads, "kind": "port", "cpu": cpu_model(),
                 "sample": f"not measured: {type(e).__name__}"}
 
 
@@ -224,10 +259,85 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def rocprof_in_graph_us(prof, kernel_substr, grid):
+    """Average duration of a kernel (by name + grid) in the committed rocprofv3 kernel trace of this command
+    (profiles/<tag>/singa_kernels_by_grid.csv: the replayed steps of the timed region dominate its launches)."""
+    import csv
+    if prof is None:
+        return None
+    f = os.path.join(prof[0], "singa_kernels_by_grid.csv")
+    if not os.path.exists(f):
+        return None
+    for r in csv.DictReader(open(f)):
+        if kernel_substr in r["kernel"] and int(r["grid_x"]) == grid:
+            return float(r["avg_us"])
+    return None
+
+
+def copy_ceiling_gbs(dev, n=64 * 1024 * 1024, reps=10):
+    """Measured device-copy bandwidth (read + write bytes / time) of the library's own float4 copy kernel
+    (singa_calib_copy) on 256 MB operands: the practical HBM ceiling next to the 8 TB/s spec peak."""
+    import ctypes
+    from singa_amd import _lib
+    a = torch.randn(n, device=dev)
+    b = torch.empty_like(a)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    fn = _lib.lib().singa_calib_copy
+    for _ in range(2):
+        fn(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n, st)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n, st)
+    e1.record()
+    torch.cuda.synchronize()
+    return round(2.0 * 4 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+
+def timed_region(engine, batches, steps, multi, dev, prefetch=True):
+    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides -> (elapsed seconds = MAX over ranks, per-step
+    milliseconds from events on the compute stream, MAX over ranks per step, last loss)."""
+    nb = len(batches)
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    nxt = batches[0]
+    loss = None
+    for i in range(steps):
+        loss = engine.step(nxt)
+        marks[i + 1].record()
+        nxt = batches[(i + 1) % nb]
+        if prefetch:
+            nxt = engine.prefetch(nxt)          # (bucket mode: returns the padded batch the next step replays)
+    torch.cuda.synchronize()
+    if multi:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    per = torch.tensor([marks[i].elapsed_time(marks[i + 1]) for i in range(steps)], device=dev, dtype=torch.float64)
+    if multi:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(per, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    return elapsed, per.tolist(), loss
+
+
+def median(xs):
+    xs = sorted(xs)
+    n = len(xs)
+    return 0.5 * (xs[(n - 1) // 2] + xs[n // 2]) if n else None
+
+
 def main():
     args = parse()
     if args.cpu_baseline_worker:
-        return cpu_baseline_worker(args.workload, args.cpu_graphs, args.cpu_threads or host_cores(), args.cpu_state)
+        return cpu_baseline_worker(args.workload, args.cpu_graphs, args.cpu_threads or host_cores(), args.cpu_state,
+                                   args.cpu_graphs_1t)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -263,6 +373,8 @@ def main():
     assert world == args.gpus or world == 1, f"launched with WORLD_SIZE={world} but --gpus {args.gpus}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # N > 1 defaults to BASELINE.json configs[3]: the SAME batch split over the ranks (strong scaling)
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
 
     import __graft_entry__
     if rank == 0:
@@ -274,9 +386,8 @@ def main():
     from singa_amd.model import EF_layers
     from singa_amd.model.GAN import SINGA
 
-    wl = dict(G.WORKLOADS[args.workload])
-    n_graphs, L = wl["n_graphs"], wl["lmax"]
-    kw = {k: v for k, v in wl.items() if k not in ("n_graphs", "lmax")}
+    L, kw, base_ids, n_parent = G.resolve_workload(args.workload)
+    n_graphs = len(base_ids)
     cfg = load_config(lmax=L)
     torch.manual_seed(cfg.train.seed)                     # same-seed init on every rank (no broadcast)
     model = SINGA(cfg, device=dev)
@@ -292,84 +403,66 @@ def main():
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
+    D = max(1, args.distinct_batches)
+
+    def make_batches(ids, stride, count):
+        """`count` different batches of the graphs `ids` (batch k: ids + k * stride), resident in HBM."""
+        return [G.synthetic_batch(len(ids), ids=[i + k * stride for i in ids], **kw).to(dev) for k in range(count)]
+
     # ---- this rank's graphs (resident in HBM before the timed region starts)
-    if args.scaling == "strong" and world > 1:
-        costs = [G.graph_cost(G.graph_sizes(i, **kw)) for i in range(n_graphs)]
+    if scaling == "strong" and world > 1:
+        costs = [G.graph_cost(G.graph_sizes(i, **kw)) for i in base_ids]
         lo, hi = dp.shard_ranges_by_cost(costs, world)[rank]
-        ids = list(range(lo, hi))
+        ids = base_ids[lo:hi]
         reducer.set_shard_weight(len(ids), n_graphs)
         graphs_per_step = n_graphs
+        stride = n_parent
     else:
-        ids = list(range(rank * n_graphs, (rank + 1) * n_graphs))
+        ids = [i + rank * n_parent for i in base_ids]
         graphs_per_step = n_graphs * world
+        stride = n_parent * world
     t_gen = time.perf_counter()
     # D different batches of this rank's graphs, resident in HBM, cycled through the steps.  Their atom / edge counts differ
     # (config 3 is ragged), so the replayed step pads each batch to its size class (TrainStep bucket mode).  D = 1: the
     # same batch every step (two resident copies, so that batch i+1 can be prepared while step i computes).
     import copy
-    D = max(1, args.distinct_batches)
-    stride = n_graphs * world if args.scaling != "strong" else n_graphs
-    batches = [G.synthetic_batch(len(ids), ids=[i + k * stride for i in ids], **kw).to(dev) for k in range(D)]
+    batches = make_batches(ids, stride, D)
     batch = batches[0]
     if D == 1 and not args.no_prefetch:
         batches.append(copy.deepcopy(batch))
     from singa_amd.engine import TrainStep
     bucket = use_graph and D > 1
     engine = TrainStep(model, opt, reducer if multi else None, use_graph=use_graph,
-                       max_grad_norm=float(cfg.train.max_grad_norm), bucket=bucket, growth=args.growth, max_cached=4)
-    # the HIP path's loss on the CPU-baseline sample (the first graphs of the workload, initial parameters, dropout off):
-    # compared below with the loss the oracle computes on the same graphs while it is being timed
-    hip_sample_loss = state_file = None
+                       max_grad_norm=float(cfg.train.max_grad_norm), bucket=bucket, growth=args.growth, max_cached=6)
+    # the run's initial parameters, for the CPU oracle (and for the HIP path's own loss / gradient norm on the CPU sample,
+    # computed at the very end of the run)
+    hip_sample = state_file = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import tempfile
         state_file = os.path.join(tempfile.mkdtemp(prefix="singa_bench_"), "init_state.pt")
         torch.save({k: v.cpu() for k, v in model.state_dict().items()}, state_file)
-        sample = G.synthetic_batch(args.cpu_graphs, ids=list(range(args.cpu_graphs)), **kw).to(dev)
-        model.eval()
-        with torch.no_grad():
-            EF_layers._edge_cache.clear()
-            model.prepare(sample)
-            lg = model(sample)
-            hip_sample_loss = float(torch.nn.functional.cross_entropy(lg, sample["ligand_data"]["smiIndices_tgt"].reshape(-1)))
-        model.train()
-        del sample, lg
     n_nodes = batch[G.PA]["x"].shape[0] + batch[G.LA]["x"].shape[0]
     n_edges = sum(int(batch[et]["edge_index"].shape[1]) for et in (G.E_PP, G.E_LL, G.E_LP, G.E_PL))
     log(f"workload {args.workload}: {len(ids)} graphs on this GPU ({n_nodes} atoms, {n_edges} edges), L={L}, generated in "
         f"{time.perf_counter() - t_gen:.1f} s; {'HIP-graph replay' if use_graph else 'eager'} step")
-    nb = len(batches)
-    for i in range(max(args.warmup, nb if bucket else 0)):      # (bucket mode: every batch once, so that all captures exist)
-        t_w = time.perf_counter()
-        loss = engine.step(batches[i % nb])
-        torch.cuda.synchronize()
-        log(f"warmup step {i}: {time.perf_counter() - t_w:.3f} s")
+
+    def warm(bs, n):
+        for i in range(max(n, len(bs) if bucket else 0)):      # (bucket mode: every batch once, so that all captures exist)
+            t_w = time.perf_counter()
+            engine.step(bs[i % len(bs)])
+            torch.cuda.synchronize()
+            log(f"warmup step {i}: {time.perf_counter() - t_w:.3f} s")
+
+    warm(batches, args.warmup)
     captures_before = engine.captures
     # ---- timed region: exactly K steps, barrier + synchronize on both sides, MAX over ranks.  Every step handles its
     # batch as newly arrived: the graph structure (edge sorting, kNN graphs, dense maps) is rebuilt K times inside the
     # region - by default on a second stream while the previous step computes (TrainStep.prefetch), the way a loader
     # thread would; with --no-prefetch at the start of the step itself.
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    nxt = batches[0]
-    for i in range(args.steps):
-        loss = engine.step(nxt)
-        nxt = batches[(i + 1) % nb]
-        if not args.no_prefetch:
-            nxt = engine.prefetch(nxt)          # (bucket mode: returns the padded batch the next step replays)
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if multi:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t)
+    elapsed, per_step, loss = timed_region(engine, batches, args.steps, multi, dev, not args.no_prefetch)
     final_loss = float(loss.detach())
-    log(f"timed {args.steps} steps in {elapsed:.3f} s ({engine.captures} graph capture(s) so far)")
+    captures_timed = engine.captures - captures_before
+    log(f"timed {args.steps} steps in {elapsed:.3f} s, median step {median(per_step):.3f} ms ({engine.captures} graph capture(s) so far)")
     # how much of a step is per-batch graph preparation (edge sorting, kNN graphs, dense maps; SURVEY §8f n1) - measured
     # separately, it is already inside every timed step
     torch.cuda.synchronize()
@@ -380,6 +473,46 @@ def main():
         model.prepare(batch)
     torch.cuda.synchronize()
     prepare_ms = (time.perf_counter() - t_p) / 3 * 1e3
+    # the Laplacian positional encoding of one batch (reference: dgl.lap_pe inside forward, GAN:71,77): the
+    # bench batches carry it (made by the same routine at generation time), so it is timed here on its own
+    torch.cuda.synchronize()
+    t_p = time.perf_counter()
+    for _ in range(3):
+        for nt, et in ((G.PA, G.E_PP), (G.LA, G.E_LL)):
+            G.laplacian_pe_batched(batch[et]["edge_index"], batch[nt]["batch"], batch.num_graphs, cfg.model.encoder.lap_dim)
+    torch.cuda.synchronize()
+    lap_pe_ms = (time.perf_counter() - t_p) / 3 * 1e3
+
+    # ---- N > 1, strong split: the weak figure too (every rank its own full batch), same engine, its own captures
+    weak = None
+    if world > 1 and scaling == "strong" and args.scaling is None:
+        reducer.weight = None
+        w_ids = [i + rank * n_parent for i in base_ids]
+        w_batches = make_batches(w_ids, n_parent * world, 2)
+        warm(w_batches, 2)
+        w_steps = max(4, args.steps // 2)
+        w_el, w_per, _ = timed_region(engine, w_batches, w_steps, multi, dev, not args.no_prefetch)
+        weak = {"value": round(n_graphs * world * w_steps / w_el, 3), "unit": "graphs/s", "global_batch": n_graphs * world,
+                "steps": w_steps, "ms_per_step": round(1e3 * w_el / w_steps, 3), "ms_per_step_median": round(median(w_per), 3),
+                "scaling": "weak"}
+        del w_batches
+
+    # ---- N = 1, default workload: the shard ONE rank of the 8-GPU strong split (config 4) would own, timed on this GPU
+    proxy = None
+    if world == 1 and not multi and use_graph and args.proxy_steps > 0 and args.proxy_workload in G.WORKLOADS \
+            and G.WORKLOADS[args.proxy_workload].get("parent") == args.workload:
+        _, _, p_ids, _ = G.resolve_workload(args.proxy_workload)
+        p_batches = make_batches(p_ids, n_parent, D)
+        warm(p_batches, 3)
+        p_el, p_per, _ = timed_region(engine, p_batches, args.proxy_steps, False, dev, not args.no_prefetch)
+        pw = G.WORKLOADS[args.proxy_workload]["shard"][1]
+        proxy = {"workload": args.proxy_workload, "graphs": len(p_ids), "ranks_of_split": pw, "steps": args.proxy_steps,
+                 "ms_per_step": round(1e3 * p_el / args.proxy_steps, 3), "ms_per_step_median": round(median(p_per), 3),
+                 "implied_speedup_at_8": round(median(per_step) / median(p_per), 2),
+                 "note": "1-GPU step time of rank 0's cost-balanced shard of the same batch (no all-reduce: add the RCCL "
+                         "ring of grad_allreduce_bytes, ~1.2 ms over xGMI)"}
+        log(f"strong proxy: {len(p_ids)} graphs, median step {proxy['ms_per_step_median']} ms")
+        del p_batches
 
     # ---- instrumented pass for the roofline: the same step run eagerly with start/stop events attached to every
     # k4 / k10 dispatch (graph replays cannot carry per-dispatch events); not part of `value`.
@@ -404,6 +537,7 @@ def main():
                 _lib.lib().singa_calib_copy(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n,
                                             ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
             torch.cuda.synchronize()
+            del a, b
         prof = committed_profile(args.workload)
         per = {}
         if recs:
@@ -434,32 +568,47 @@ def main():
         if "k10_fwd" in per:
             k = per["k10_fwd"]
             tr = pmc_traffic(prof, f"rotate_back_scatter_kernel<{L}, 2, false", n_union * 128)
+            in_graph = rocprof_in_graph_us(prof, f"rotate_back_scatter_kernel<{L}, 2, false", n_union * 128)
             sha = lib_source_sha()
+            same = prof is not None and prof[1].get("lib_sha") == sha
+            src = (f"{os.path.relpath(prof[0], ROOT)} (library source sha {prof[1].get('lib_sha')}; "
+                   f"{'same as' if same else 'OLDER than'} this build {sha})") if prof else None
             roof = {"bound": "hbm", "kernel": "rotate_back_scatter_kernel (k10 fwd, 'scatter-TP', on the bonded edges: "
                                               "protein-protein U ligand-ligand pass)",
                     "achieved": k["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["frac"],
+                    "frac_uses": "avg_launch_us (events around each dispatch, measured in this process)",
                     "traffic": tr,
-                    "traffic_source": (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command: "
-                                       f"{os.path.relpath(prof[0], ROOT)} (library source sha {prof[1].get('lib_sha')}; "
-                                       f"{'same as' if prof[1].get('lib_sha') == sha else 'OLDER than'} this build {sha})"
-                                       if tr else None),
+                    "traffic_source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command: {src}" if tr else None,
                     "bytes_per_launch": k["bytes_per_launch"], "avg_launch_us": k["avg_launch_us"], "launches": k["launches"],
+                    "avg_launch_us_in_graph": in_graph,
+                    "in_graph_source": f"rocprofv3 --kernel-trace of this command (replayed steps): {src}" if in_graph else None,
+                    "hbm_copy_ceiling": copy_ceiling_gbs(dev),
+                    "hbm_copy_ceiling_note": "GB/s, read + write bytes of the library's float4 copy kernel on 256 MB operands, "
+                                             "measured in this process",
                     "edges": big, "dst_nodes": n_union,
                     "timing": f"start/stop events attached to each dispatch, {args.roofline_steps} instrumented eager steps "
                               "right after the timed region (same process, same batch)",
                     "other_kernels": {t: v for t, v in per.items() if t != "k10_fwd"}}
+            for t, sub, gmul in (("k10_bwd", f"rotate_back_scatter_bwd_kernel<{L}, 2, false", 128),):
+                ig = rocprof_in_graph_us(prof, sub, n_union * gmul)
+                if ig and t in roof["other_kernels"]:
+                    roof["other_kernels"][t]["avg_launch_us_in_graph"] = ig
             if prof and prof[1].get("mfma"):
                 roof["mfma"] = dict(prof[1]["mfma"], source=os.path.relpath(prof[0], ROOT), peak_tflops=MFMA_F32_PEAK_TFLOPS)
 
     if rank == 0:
         sizes = [G.graph_sizes(i, **kw) for i in ids]
         mean = lambda k: round(sum(s[k] for s in sizes) / len(sizes), 1)
+        med = median(per_step)
         out = {"metric": baseline_metric(),
                "value": round(graphs_per_step * args.steps / elapsed, 3), "unit": "graphs/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-               "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
+               "ms_per_step_median": round(med, 3), "value_at_median": round(graphs_per_step / (med * 1e-3), 3),
+               "higher_is_better": True, "scaling": scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
-               "config": {"workload": args.workload, "global_batch": graphs_per_step, "graphs_per_gpu": len(ids), "lmax": L,
+               "config": {"workload": args.workload + (" split over the ranks (BASELINE.json configs[3])"
+                                                       if world > 1 and scaling == "strong" else ""),
+                          "global_batch": graphs_per_step, "graphs_per_gpu": len(ids), "lmax": L,
                           "mmax": 2, "ragged": "ragged" in kw,
                           "atoms_on_this_gpu": n_nodes, "edges_on_this_gpu": n_edges,
                           "mean_protein_atoms": mean("n_protein"), "mean_ligand_atoms": mean("n_ligand"),
@@ -467,26 +616,54 @@ def main():
                           "parallelism": f"dp{world}" + (" (RCCL self-test: the collectives run on a 1-rank communicator)" if selftest else ""),
                           "step": "prepare+zero_grad+fwd+CE+bwd+allreduce+clip+Adam of the generator (the reference has no discriminator)",
                           "launch": "hipGraph replay" if use_graph else "eager",
+                          "value_is": "graphs of all ranks x steps / wall time of the timed region (barrier + synchronize on both "
+                                      "sides, MAX over ranks); ms_per_step_median = median of the per-step event times",
                           "batches": (f"{D} different resident batches per GPU cycled through the steps, each padded to its "
                                       f"size class (x{args.growth} per class) and its graph structure rebuilt every step"
                                       if bucket else "one resident batch per GPU, its graph structure rebuilt every step"),
-                          "captures_in_timed_region": engine.captures - captures_before,
+                          "captures_in_timed_region": captures_timed,
                           "prepare": "in step" if args.no_prefetch else "prefetched on a second stream during the previous step",
-                          "prepare_ms_of_step": round(prepare_ms, 2), "graph_captures": engine.captures,
+                          "prepare_ms_of_step": round(prepare_ms, 2), "lap_pe_ms": round(lap_pe_ms, 2),
+                          "lap_pe": "Laplacian PE of one batch (both node types) by graph.laplacian_pe_batched, timed on its own; "
+                                    "the bench batches carry theirs from generation time",
+                          "graph_captures": engine.captures,
                           "grad_allreduce_bytes": reducer.payload_bytes},
                "final_loss": round(final_loss, 5), "roofline": roof}
+        if weak is not None:
+            out["weak"] = weak
+        if proxy is not None:
+            out["strong_proxy"] = proxy
+            out["strong_proxy_ms"] = proxy["ms_per_step_median"]
         if not args.no_cpu_baseline and world == 1:
+            # the HIP path's loss and total gradient norm on the CPU-baseline sample (the first graphs of the workload,
+            # the run's INITIAL parameters, dropout off): compared with what the oracle computes while it is being timed
+            if use_graph:
+                engine.release()
+            model.load_state_dict(torch.load(state_file, map_location=dev))
+            sample = G.synthetic_batch(args.cpu_graphs, ids=base_ids[:args.cpu_graphs], **kw).to(dev)
+            model.eval()
+            EF_layers._edge_cache.clear()
+            model.prepare(sample)
+            model.zero_grad(set_to_none=True)
+            ls = torch.nn.functional.cross_entropy(model(sample), sample["ligand_data"]["smiIndices_tgt"].reshape(-1))
+            ls.backward()
+            gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
+            hip_sample = (float(ls.detach()), float(gn))
+            del sample, ls
             log("timing the CPU oracle on the bounded sample ...")
-            cb = cpu_baseline(args.workload, args.cpu_graphs, state=state_file)
+            cb = cpu_baseline(args.workload, args.cpu_graphs, state=state_file, n_graphs_1t=args.cpu_graphs_1t)
             if state_file:
                 import shutil
                 shutil.rmtree(os.path.dirname(state_file), ignore_errors=True)
-            lo = cb.pop("loss", None)
+            lo, gno = cb.pop("loss", None), cb.pop("grad_norm", None)
             out["cpu_baseline"] = cb
-            if lo is not None and hip_sample_loss is not None:
-                out["oracle_check"] = {"what": f"CrossEntropy of the first {args.cpu_graphs} graphs at the initial parameters, "
-                                               "dropout off: HIP path vs CPU oracle", "loss_hip": round(hip_sample_loss, 6),
-                                       "loss_oracle": round(lo, 6), "rel_diff": abs(hip_sample_loss - lo) / abs(lo)}
+            if lo is not None and hip_sample is not None:
+                out["oracle_check"] = {"what": f"CrossEntropy and total gradient 2-norm of the first {args.cpu_graphs} graphs at the "
+                                               "initial parameters, dropout off: HIP path vs CPU oracle",
+                                       "loss_hip": round(hip_sample[0], 6), "loss_oracle": round(lo, 6),
+                                       "rel_diff": abs(hip_sample[0] - lo) / abs(lo),
+                                       "grad_norm_hip": round(hip_sample[1], 6), "grad_norm_oracle": round(gno, 6),
+                                       "grad_norm_rel_diff": abs(hip_sample[1] - gno) / abs(gno)}
         print(json.dumps(out), file=json_out, flush=True)
     if multi:
         dist.barrier()

@@ -58,6 +58,13 @@ int singa_init(const double* jd_flat, int lmax_max);
 /* Sizes the host needs to allocate buffers: KR, WSZ, RAD_ROWS for (lmax, mmax). */
 int singa_dims(int lmax, int mmax, int* kr, int* wsz, int* rad_rows);
 
+/* k1 - init_edge_rot_mat (EF:2286-2351): vec[E,3] edge vectors, rnd[E,3] the uniform [0,1) draws the reference takes
+ * from torch.rand_like (Q6) -> rot[E,3,3] edge frames (rows z, x, -y; R x_hat = +y).  The reference's two guards
+ * (EF:2292-2297 shortest edge, EF:2329 helper vector aligned with an edge) are reported through stats[2]:
+ * stats[0] = min(stats[0], min |vec|), stats[1] = max(stats[1], max |cos(edge, helper)|) with a NaN propagated; the
+ * caller initialises (+inf, 0) and judges the values (warning / error) after a read-back. */
+int singa_edge_frames(const float* vec, const float* rnd, float* rot, float* stats, int E, void* stream);
+
 /* k2 — SO3_Rotation.set_wigner / RotationToWignerDMatrix / wigner_D (EF:485-528, 2207-2229):
  * rot[E,3,3] edge frames -> Wr[E,WSZ] reduced Wigner rows. */
 int singa_wigner_rows(const float* rot, float* wr, int E, int lmax, int mmax, void* stream);

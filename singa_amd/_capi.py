@@ -35,6 +35,7 @@ _SIGS = {
     "singa_last_error_string": ([], C.c_char_p),
     "singa_init": ([P, I32], I32),
     "singa_dims": ([I32, I32, C.POINTER(I32), C.POINTER(I32), C.POINTER(I32)], I32),
+    "singa_edge_frames": ([P, P, P, P, I32, P], I32),
     "singa_wigner_rows": ([P, P, I32, I32, I32, P], I32),
     "singa_gather_rotate_fwd": ([P, P, P, P, P, P, P, I32, I32, I32, I32, P], I32),
     "singa_gather_rotate_bwd": ([P] * 13 + [I32] * 6 + [P], I32),

@@ -135,6 +135,68 @@ struct WRows {
 };
 #define W_AT(w, idx) SINGA_LANE_BCAST((w).v[(idx) / 64], (idx) % 64, (w).p, (idx))
 
+// ------------------------------------------------------------------------------------------------ k1: edge frames
+// init_edge_rot_mat (EF:2286-2351), one thread per edge, the reference's operations in the reference's order (including
+// the second normalisation of z): x = v / |v|; helper r = (rand - 0.5) / |rand - 0.5|, replaced by one of its two
+// 90-degree copies (-r1, r0, r2) / (r0, -r2, r1) when it is the more parallel one; z = x X r, y = x X z; rows of the frame
+// = (z, x, -y).  The reference's two guards need min |v| and max |x . r| over the edges: both are order-independent, so
+// they are folded with wave butterflies + one integer atomic per wave on the float bit patterns (non-negative floats order
+// like their bits; a NaN has the largest pattern, so it survives the max exactly as torch.max propagates it).
+// stats[0] = min(stats[0], min |v|), stats[1] = max(stats[1], max |cos|): the caller initialises (inf, 0).
+#ifndef SINGA_WAVE_MIN_MAX  // tests/emul: every (sequential) thread is its own wave
+#define SINGA_WAVE_MIN_MAX(lo, hi)                             \
+    _Pragma("unroll") for (int o_ = 32; o_ > 0; o_ >>= 1) {    \
+        int a_ = __shfl_xor((lo), o_, 64), b_ = __shfl_xor((hi), o_, 64); \
+        (lo) = a_ < (lo) ? a_ : (lo);                          \
+        (hi) = b_ > (hi) ? b_ : (hi);                          \
+    }
+#define SINGA_WAVE_LEADER ((threadIdx.x & 63) == 0)
+#endif
+__device__ __forceinline__ float3 cross3(float3 a, float3 b) {
+    return make_float3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float norm3(float3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+__device__ __forceinline__ float absdot3(float3 a, float3 b) { return fabsf(a.x * b.x + a.y * b.y + a.z * b.z); }
+
+__global__ void __launch_bounds__(256) edge_frames_kernel(const float* __restrict__ vec, const float* __restrict__ rnd,
+                                                          float* __restrict__ rot, int* __restrict__ stats, int E) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    int dbits = 0x7f800000, cbits = 0;  // +inf, 0
+    if (e < E) {
+        float3 v = make_float3(vec[3 * (long long)e], vec[3 * (long long)e + 1], vec[3 * (long long)e + 2]);
+        float d = norm3(v);
+        float3 x = make_float3(v.x / d, v.y / d, v.z / d);
+        float3 r = make_float3(rnd[3 * (long long)e] - 0.5f, rnd[3 * (long long)e + 1] - 0.5f, rnd[3 * (long long)e + 2] - 0.5f);
+        float rn = norm3(r);
+        r = make_float3(r.x / rn, r.y / rn, r.z / rn);
+        float3 rb = make_float3(-r.y, r.x, r.z), rc = make_float3(r.x, -r.z, r.y);
+        float db = absdot3(rb, x), dc = absdot3(rc, x), d0 = absdot3(r, x);
+        if (d0 > db) r = rb;
+        d0 = absdot3(r, x);
+        if (d0 > dc) r = rc;
+        d0 = absdot3(r, x);
+        float3 z = cross3(x, r);
+        float zn = norm3(z);
+        z = make_float3(z.x / zn, z.y / zn, z.z / zn);
+        zn = norm3(z);
+        z = make_float3(z.x / zn, z.y / zn, z.z / zn);
+        float3 y = cross3(x, z);
+        float yn = norm3(y);
+        y = make_float3(y.x / yn, y.y / yn, y.z / yn);
+        float* R = rot + 9 * (long long)e;
+        R[0] = z.x, R[1] = z.y, R[2] = z.z;
+        R[3] = x.x, R[4] = x.y, R[5] = x.z;
+        R[6] = -y.x, R[7] = -y.y, R[8] = -y.z;
+        dbits = __builtin_bit_cast(int, d) & 0x7fffffff;   // (a NaN length never wins the min; the NaN dot below reports it)
+        cbits = __builtin_bit_cast(int, d0) & 0x7fffffff;
+    }
+    SINGA_WAVE_MIN_MAX(dbits, cbits);
+    if (SINGA_WAVE_LEADER) {
+        atomicMin(stats, dbits);
+        atomicMax(stats + 1, cbits);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ k2: Wigner rows
 // One thread per (edge, reduced row).  D_l = Za J Zb J Zc with Z(t) = diag cos(f t) + antidiag sin(f t),
 // f = l, l-1, .., -l (EF:2207-2229); angles from the 3x3 frame as e3nn's xyz_to_angles / angles_to_matrix do
@@ -3346,6 +3408,14 @@ int singa_dims(int lmax, int mmax, int* kr, int* wsz, int* rad_rows) {
         if (rad_rows) *rad_rows = I::RAD_ROWS;
     });
     return SINGA_OK;
+}
+
+int singa_edge_frames(const float* vec, const float* rnd, float* rot, float* stats, int E, void* stream) {
+    if (!vec || !rnd || !rot || !stats) return fail(SINGA_E_NULL, "edge_frames: null pointer");
+    if (E <= 0) return SINGA_OK;
+    hipLaunchKernelGGL(edge_frames_kernel, dim3((E + 255) / 256), dim3(256), 0, (hipStream_t)stream, vec, rnd, rot,
+                       (int*)stats, E);
+    return check_launch("edge_frames");
 }
 
 int singa_wigner_rows(const float* rot, float* wr, int E, int lmax, int mmax, void* stream) {

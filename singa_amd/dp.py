@@ -43,18 +43,29 @@ class GradAllReducer:
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
         assert float(hi - lo) == 0.0, "ranks were not initialised with identical parameters"
 
+    def _side_group(self):
+        """A gloo group for the small host-side agreements (no device synchronisation involved)."""
+        if getattr(self, "_cpu_group", None) is None:
+            self._cpu_group = (self.group if dist.get_backend(self.group) == "gloo" else dist.new_group(backend="gloo"))
+        return self._cpu_group
+
     def any_rank(self, flag):
         """True on every rank if `flag` is true on any (host-side decision that all ranks must take together, e.g.
-        re-capturing the step: its warm-up issues collectives).  Exchanged over a gloo group so that no device
-        synchronisation is involved."""
+        re-capturing the step: its warm-up issues collectives)."""
         if not self.active:
             return bool(flag)
-        if getattr(self, "_cpu_group", None) is None:
-            self._cpu_group = (self.group if dist.get_backend(self.group) == "gloo"
-                               else dist.new_group(backend="gloo"))
         t = torch.tensor([1 if flag else 0], dtype=torch.int32)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._cpu_group)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._side_group())
         return bool(int(t))
+
+    def max_ints(self, values):
+        """Element-wise MAX of a short list of integers over the ranks (host-side agreement: the sizes a padded batch is
+        staged with, see TrainStep._stage).  Every rank must call it the same number of times."""
+        if not self.active:
+            return [int(v) for v in values]
+        t = torch.tensor([int(v) for v in values], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self._side_group())
+        return t.tolist()
 
     def set_shard_weight(self, n_local, n_global):
         """Shards of different sizes (batch % world != 0, or `shard_ranges_by_cost`): every rank's CrossEntropy is a mean

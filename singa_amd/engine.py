@@ -104,6 +104,8 @@ class TrainStep:
         self._active = None
         self.direct_grads = direct_grads   # see _fwd_bwd
         self._sink_params = None           # parameters whose gradients are accumulated in place (found in the first step)
+        self._opt_gen = None               # optimizer.generation the current captures were made with
+        self._pinned_table = None
 
     # ------------------------------------------------------------------------------------------------ size classes
     def _class_caps(self, sizes):
@@ -127,9 +129,15 @@ class TrainStep:
             if "lap_pe" not in batch[nt]:
                 batch[nt]["lap_pe"] = G.laplacian_pe_batched(batch[et]["edge_index"], batch[nt]["batch"], B,
                                                              self.model.config.model.encoder.lap_dim)
-        c, caps = self._class_caps(G.batch_sizes(batch))
+        # Several ranks: sizes, layout widths and kNN edge counts are agreed with a MAX over the ranks (a few integers over
+        # the gloo side group), so every rank derives the SAME size class, capacities and signature from them and the
+        # ranks capture / replay in lockstep (ragged shards otherwise land in different classes on different ranks, and
+        # every new signature anywhere forces a collective re-capture everywhere).
+        agree = self.reducer.max_ints if (self.reducer is not None and self.reducer.active) else (lambda v: list(v))
         widths = torch.stack([(batch[nt]["ptr"][1:] - batch[nt]["ptr"][:-1]).max() for nt in (PA, LA)]).tolist()
-        for nt, w in zip((PA, LA), widths):
+        agreed = agree(list(G.batch_sizes(batch)) + [int(w) for w in widths])
+        c, caps = self._class_caps(tuple(agreed[:5]))
+        for nt, w in zip((PA, LA), agreed[5:]):
             self._mx[nt] = max(self._mx[nt], -(-int(w) // 16) * 16)
         pb = G.pad_batch(batch, *caps)
         EF_layers._edge_cache.clear()
@@ -138,16 +146,21 @@ class TrainStep:
             pb.extras["pad"].update(mx_p=self._mx[PA], mx_l=self._mx[LA], knn_p=kp, knn_l=kl)
             pb.extras.pop("prepared", None)
             try:
-                prep = self.model.prepare(pb)
+                prep, over = self.model.prepare(pb), 0
             except OverflowError:                       # a denser batch than the class has seen: forget, measure again
+                prep, over = None, 1
+            over, e_p, e_l = agree([over] + [prep[k]["edges"].n_edges if prep is not None else 0 for k in ("p", "l")])
+            if over:
                 self._knn_cap.pop((c, PA), None)
                 self._knn_cap.pop((c, LA), None)
                 continue
             if kp is not None and kl is not None:
                 break
             # first batch of this class: its edge counts (+4 %) become the class capacities, then prepare with them
-            for nt, key in ((PA, "p"), (LA, "l")):
-                self._knn_cap[(c, nt)] = -(-int(prep[key]["edges"].n_edges * 1.04) // 1024) * 1024
+            for nt, e in ((PA, e_p), (LA, e_l)):
+                self._knn_cap[(c, nt)] = -(-int(e * 1.04) // 1024) * 1024
+        else:
+            raise RuntimeError("TrainStep._stage: the kNN edge capacities of a size class did not settle in 3 attempts")
         pb.extras["pad"]["sig"] = (c, self._mx[PA], self._mx[LA], self._knn_cap[(c, PA)], self._knn_cap[(c, LA)])
         return pb
 
@@ -335,14 +348,18 @@ class TrainStep:
                 # replays only the RCCL calls themselves are issued (GradAllReducer.flatten / allreduce / unflatten)
                 self.reducer.flatten(fresh=True)
         if hasattr(self.opt, "_grad_table"):
-            self.opt._grad_table()        # the .grad tensors now live in the graph pool: publish their addresses (a
-                                          # host->device copy, so it has to happen outside the capture)
+            # the .grad tensors now live in the graph pool: publish their addresses in a table of this capture's own (a
+            # host->device copy, so it has to happen outside the capture; pinned until the capture is dropped)
+            if not self.bucket and getattr(self, "_pinned_table", None) is not None:
+                self.opt.unpin(self._pinned_table)
+            self._pinned_table = self.opt._grad_table(pin=True)
         self.g_opt = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
             if self.reducer is not None:
                 self.reducer.unflatten()
             self._update()
         self.captures += 1
+        self._opt_gen = getattr(self.opt, "generation", 0)     # (the warm-up may have built the optimizer)
 
     # ------------------------------------------------------------------------------------------------ capture slots
     _SLOT_FIELDS = ("static", "static_prep", "_sig", "g_fb", "g_opt", "static_loss")
@@ -363,12 +380,17 @@ class TrainStep:
     def _store(self, sig):
         slot = {f: getattr(self, f) for f in self._SLOT_FIELDS}
         slot["grads"] = [p.grad for p in self.model.parameters()]
-        slot["g_ptr"] = getattr(self.opt, "g_ptr", None)   # the address table the optimizer graph reads: keep it alive
+        slot["g_ptr"] = getattr(self.opt, "g_ptr", None)   # the address table the optimizer graph reads (pinned in the optimizer)
+        old_slot = self._slots.pop(sig, None)
+        if old_slot is not None and hasattr(self.opt, "unpin"):
+            self.opt.unpin(old_slot["g_ptr"])
         self._slots[sig] = slot
         self._active = sig
         while len(self._slots) > self.max_cached:
             old = next(iter(self._slots))
-            self._slots.pop(old)                           # its graphs and pool are freed with the last reference
+            gone = self._slots.pop(old)                    # its graphs and pool are freed with the last reference
+            if hasattr(self.opt, "unpin"):
+                self.opt.unpin(gone["g_ptr"])
             torch.cuda.synchronize()
             torch.cuda.empty_cache()
 
@@ -376,6 +398,9 @@ class TrainStep:
         """Drop the captured graphs and their private memory pool (e.g. before running large eager steps)."""
         self._slots.clear()
         self._active = None
+        if hasattr(self.opt, "unpin") and getattr(self.opt, "_built", False):
+            self.opt.unpin()
+        self._pinned_table = None
         self.g_fb = self.g_opt = self.static = self.static_prep = self.static_loss = None
         EF_layers._edge_pinned.clear()
         self.opt.zero_grad(set_to_none=True)
@@ -390,6 +415,13 @@ class TrainStep:
     def step(self, batch):
         if not self.use_graph:
             return self.eager_step(batch)
+        gen = getattr(self.opt, "generation", 0)
+        if gen != self._opt_gen:
+            # the optimizer re-created its moment buffers (load_state_dict / first build): captures made before still
+            # point at the old ones
+            if self._opt_gen is not None and (self.static is not None or self._slots):
+                self.release()
+            self._opt_gen = gen
         if self.bucket:
             return self._bucket_step(batch)
         need = self.static is None or not self._load(batch)

@@ -161,13 +161,19 @@ def synthetic_graph(graph_id, n_protein=200, n_ligand=30, e_pp=1700, e_ll=64, e_
     side = (n_protein / 0.05) ** (1.0 / 3.0)
 
     def place(n, draw, others):
-        pts = []
-        while len(pts) < n:
+        # accepted points live in one preallocated array (same draws, same acceptance test as a list rebuilt per draw,
+        # without the per-draw list -> array conversion that made a 470-atom graph cost 0.1 s)
+        ref = np.empty((n + len(others), 3), np.float64)
+        m = len(others)
+        if m:
+            ref[:m] = np.asarray(others)
+        k = 0
+        while k < n:
             cand = draw()
-            ref = pts + others
-            if not ref or np.min(np.linalg.norm(np.asarray(ref) - cand, axis=1)) >= 1.0:
-                pts.append(cand)
-        return pts
+            if m + k == 0 or np.min(np.linalg.norm(ref[:m + k] - cand, axis=1)) >= 1.0:
+                ref[m + k] = cand
+                k += 1
+        return [ref[m + i].copy() for i in range(n)]
 
     def lig_draw():
         while True:
@@ -228,7 +234,24 @@ WORKLOADS = {
     "cfg3_fixed_b128_l4": dict(n_graphs=128, lmax=4, n_protein=350, n_ligand=30, e_pp=700, e_ll=66, e_x=80),
     "cfg5_l6": dict(n_graphs=64, lmax=6, n_protein=800, n_ligand=40, e_pp=7600, e_ll=88, e_x=156),
     "cfg5_l6_b8": dict(n_graphs=8, lmax=6, n_protein=800, n_ligand=40, e_pp=7600, e_ll=88, e_x=156),
+    # BASELINE.json configs[3] seen from ONE rank: the cost-balanced shard rank 0 of 8 owns of the
+    # config-3 batch (dp.shard_ranges_by_cost over graphs 0..127) - what a one-GPU box can time of the 8-GPU strong split
+    "cfg4_shard_r0of8": dict(parent="cfg3_b128_l4", shard=(0, 8)),
 }
+
+
+def resolve_workload(name):
+    """-> (lmax, generator kwargs, graph ids of one batch, graphs of the parent batch).  A `shard` workload names the
+    graphs one rank of a strong split of its parent owns."""
+    wl = dict(WORKLOADS[name])
+    if "parent" in wl:
+        from .dp import shard_ranges_by_cost
+        rank, world = wl["shard"]
+        L, kw, ids, n = resolve_workload(wl["parent"])
+        lo, hi = shard_ranges_by_cost([graph_cost(graph_sizes(i, **kw)) for i in ids], world)[rank]
+        return L, kw, list(ids[lo:hi]), n
+    n, L = wl.pop("n_graphs"), wl.pop("lmax")
+    return L, wl, list(range(n)), n
 
 
 def graph_sizes(graph_id, ragged=None, **kw):

@@ -228,19 +228,24 @@ def get_normalization_layer(norm_type, lmax, num_channels, eps: float = 1e-5, af
 
 # ----------------------------------------------------------------------------------------------- SO(2) convolution
 _pass_token = [0, False]
+_bw_cache: Dict[int, Tensor] = {}          # id(SO2_m_Convolution) -> its block weight, alive for ONE forward pass only
 
 
 class forward_pass:
     """`with forward_pass():` brackets one EquivariantEmbedding.forward.  Inside it, parameter-derived tensors (the SO(2)
-    block weights) are built once and shared by the homogeneous and heterogeneous passes; outside it nothing is cached
-    (the cached tensors carry the autograd history of the pass that built them)."""
+    block weights) are built once and shared by the homogeneous and heterogeneous passes; the cache is emptied when the
+    pass ends: the cached tensors carry the autograd history of the pass that built them, and a history kept alive past its
+    pass pins that pass's AccumulateGrad nodes (and their stream) - an eager backward followed by a graph capture on
+    another stream then crashed inside the capture."""
 
     def __enter__(self):
         _pass_token[0] += 1
         _pass_token[1] = True
+        _bw_cache.clear()
 
     def __exit__(self, *a):
         _pass_token[1] = False
+        _bw_cache.clear()
         return False
 
 
@@ -257,16 +262,17 @@ class SO2_m_Convolution(nn.Module):
         self.fc.weight.data.mul_(1 / math.sqrt(2))
 
     def block_weight(self) -> Tensor:
-        """Built once per forward pass of the model (`new_forward_pass`): the blocks are shared by the homogeneous and the
+        """Built once per forward pass of the model (`forward_pass`): the blocks are shared by the homogeneous and the
         two heterogeneous passes, which would otherwise each rebuild (and back-propagate through) the same four cats."""
-        hit = getattr(self, "_bw", None)
-        if _pass_token[1] and hit is not None and hit[0] == _pass_token[0] and hit[2] == torch.is_grad_enabled():
-            return hit[1]
+        hit = _bw_cache.get(id(self)) if _pass_token[1] else None
+        if hit is not None and hit[1] == torch.is_grad_enabled():
+            return hit[0]
         w = self.fc.weight
         h = w.shape[0] // 2
         wr, wi = w[:h], w[h:]
         bw = torch.cat([torch.cat([wr, -wi], 1), torch.cat([wi, wr], 1)], 0)
-        object.__setattr__(self, "_bw", (_pass_token[0], bw, torch.is_grad_enabled()) if _pass_token[1] else None)
+        if _pass_token[1]:
+            _bw_cache[id(self)] = (bw, torch.is_grad_enabled())
         return bw
 
 
@@ -525,31 +531,19 @@ def check_edge_frames(device=None, reset: bool = True) -> None:
 
 
 def init_edge_rot_mat(edge_distance_vec: Tensor, device: str = "cuda", rand: Optional[Tensor] = None) -> Tensor:
-    """Edge frames (EF:2286-2351).  `rand` is the uniform [0,1) draw the reference takes from torch.rand_like (Q6);
-    pass it explicitly for reproducible parity, otherwise it is drawn on the tensor's device.  Both guards of the
-    reference are kept (`_judge_frames`): evaluated at once in eager mode, accumulated on the device under graph capture
-    (`check_edge_frames`)."""
+    """Edge frames (EF:2286-2351) by the k1 kernel (ops.edge_frames): one launch builds the frames and folds the two
+    statistics the reference's guards need.  `rand` is the uniform [0,1) draw the reference takes from torch.rand_like
+    (Q6); pass it explicitly for reproducible parity, otherwise it is drawn on the tensor's device.  Both guards of the
+    reference are kept (`_judge_frames`): evaluated at once in eager mode (one read-back), accumulated on the device
+    under graph capture (`check_edge_frames`)."""
     v = edge_distance_vec
     if v.shape[0] == 0:
         return v.new_zeros(0, 3, 3)
-    d = v.norm(dim=1, keepdim=True)
-    nx = v / d
-    r = (torch.rand_like(v) if rand is None else rand) - 0.5
-    r = r / r.norm(dim=1, keepdim=True)
-    rb = torch.stack([-r[:, 1], r[:, 0], r[:, 2]], 1)
-    rc = torch.stack([r[:, 0], -r[:, 2], r[:, 1]], 1)
-    dot = lambda a: (a * nx).sum(1, keepdim=True).abs()
-    r = torch.where(dot(r) > dot(rb), rb, r)
-    r = torch.where(dot(r) > dot(rc), rc, r)
-    # max over |cos| with NaN propagated (torch.max propagates NaN: a zero-length edge must trip the guard)
-    stats = torch.stack([d.min(), dot(r).max()])
-    if v.is_cuda and torch.cuda.is_current_stream_capturing():
-        fl = _frame_flag_tensor(v.device)
-        fl.copy_(torch.stack([torch.minimum(fl[0], stats[0]), torch.maximum(fl[1], stats[1])]))
-    else:
+    if rand is None:
+        rand = torch.rand_like(v)
+    capturing = v.is_cuda and torch.cuda.is_current_stream_capturing()
+    stats = _frame_flag_tensor(v.device) if capturing else torch.tensor([float("inf"), 0.0], device=v.device)
+    rot = ops.edge_frames(v, rand, stats)
+    if not capturing:
         _judge_frames(*stats.tolist())
-    nz = torch.linalg.cross(nx, r, dim=1)
-    nz = nz / nz.norm(dim=1, keepdim=True)
-    ny = torch.linalg.cross(nx, nz, dim=1)
-    ny = ny / ny.norm(dim=1, keepdim=True)
-    return torch.stack([nz, nx, -ny], dim=2).transpose(1, 2).contiguous().detach()
+    return rot

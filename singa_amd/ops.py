@@ -90,6 +90,19 @@ class EdgeSet:
         return [self.order, self.src64, self.dst64, self.src, self.dst, self.row_ptr, self.eperm, self.col_ptr]
 
 
+def edge_frames(vec, rand, stats):
+    """k1: edge vectors [E,3] + the uniform draws [E,3] of the reference's torch.rand_like (Q6) -> edge frames [E,3,3]
+    (no gradient, EF:2286-2351, `.detach()` at EF:2351).  stats: float32 [2] on the same device, updated in place to
+    (min(stats[0], shortest edge), max(stats[1], largest |cos(edge, helper)|)) - the reference's two guards."""
+    vec, rand = vec.detach().contiguous().float(), rand.detach().contiguous().float()
+    _dev(vec, rand, stats)
+    E = vec.shape[0]
+    assert vec.shape == (E, 3) and rand.shape == (E, 3) and stats.shape == (2,) and stats.is_contiguous()
+    rot = torch.empty(E, 3, 3, device=vec.device, dtype=torch.float32)
+    _chk(_lib.lib().singa_edge_frames(_p(vec), _p(rand), _p(rot), _p(stats), E, _stream()), "singa_edge_frames")
+    return rot
+
+
 def wigner_rows(rot, L, M=2):
     """k2: rot [E,3,3] -> reduced Wigner rows [E, WSZ] (no gradient, EF:485-528)."""
     rot = rot.detach().contiguous().float()

@@ -47,20 +47,44 @@ class Adam(torch.optim.Optimizer):
         self.chunk_off = i64(co)
         self.g_ptr = None
         self._grad_ids = None
+        self._pinned = {}                  # grad-address tuple -> device table baked into a captured optimizer graph
+        self._scratch_table = None         # the eager steps' table (overwritten in place)
+        self._norm_partial = None
         self._built = True
+        self.generation = getattr(self, "generation", 0) + 1     # the step engine drops its captures when this changes
 
-    def _grad_table(self):
-        """Device table of the CURRENT .grad addresses (they change when grads are re-created; static under replay)."""
+    def _grad_table(self, pin=False):
+        """Device table of the CURRENT .grad addresses (they change when grads are re-created; static under replay).
+        pin=True (the step engine, right before it captures the optimizer graph): the table gets its own tensor that stays
+        alive until `unpin` - a captured launch has the address of the table it was captured with baked in.  Otherwise
+        (eager steps: gradients are re-created every step and the allocator may hand back new addresses each time) ONE
+        scratch table is overwritten in stream order, so nothing accumulates over a long run."""
         ids = tuple(p.grad.data_ptr() for p in self.active)
         if ids != self._grad_ids:
-            # tables stay alive: a captured optimizer graph has the address of the table it was captured with baked in
-            if not hasattr(self, "_tables"):
-                self._tables = {}
-            if ids not in self._tables:
-                self._tables[ids] = torch.tensor(ids, dtype=torch.int64, device=self.p_ptr.device)
-            self.g_ptr = self._tables[ids]
+            hit = self._pinned.get(ids)
+            if hit is None:
+                host = torch.tensor(ids, dtype=torch.int64)
+                if pin:
+                    hit = self._pinned[ids] = host.to(self.p_ptr.device)
+                else:
+                    if self._scratch_table is None:
+                        self._scratch_table = torch.empty(len(ids), dtype=torch.int64, device=self.p_ptr.device)
+                    self._scratch_table.copy_(host)
+                    hit = self._scratch_table
+            self.g_ptr = hit
             self._grad_ids = ids
+        elif pin and ids not in self._pinned:       # the current table is the scratch one: give the capture its own
+            self._pinned[ids] = self.g_ptr = torch.tensor(ids, dtype=torch.int64, device=self.p_ptr.device)
         return self.g_ptr
+
+    def unpin(self, table=None):
+        """Forget a pinned address table (the capture that used it is gone); None = all of them."""
+        if table is None:
+            self._pinned.clear()
+        else:
+            for k in [k for k, v in self._pinned.items() if v is table]:
+                del self._pinned[k]
+        self._grad_ids = None
 
     def sync_hyper(self):
         """Push the (possibly scheduler-modified) learning rate to the device scalar the kernel reads."""
@@ -89,7 +113,7 @@ class Adam(torch.optim.Optimizer):
         if not self._built:
             self._build()
         g_ptr = self._grad_table()
-        if getattr(self, "_norm_partial", None) is None:
+        if self._norm_partial is None:
             self._norm_partial = torch.empty(self.chunk_tensor.numel(), device=self.p_ptr.device, dtype=torch.float32)
             self._norm_out = torch.zeros(1, device=self.p_ptr.device, dtype=torch.float32)
         vp = lambda t: ctypes.c_void_p(t.data_ptr())
@@ -157,17 +181,24 @@ class Adam(torch.optim.Optimizer):
         state = {int(i): st for i, st in sd["state"].items()}
         if not state:
             self._built = False
+            self.generation = getattr(self, "generation", 0) + 1
             return
         steps = {float(st["step"]) for st in state.values()}
         if len(steps) != 1:
             raise ValueError("Adam.load_state_dict: parameters with different step counts are not supported")
-        for i in state:                                        # these parameters take part from now on
-            if self.params[i].grad is None:
-                self.params[i].grad = torch.zeros_like(self.params[i])
-        for i, p in enumerate(self.params):
-            if i not in state and p.grad is not None:
-                p.grad = None
-        self._build()
+        same = self._built and {id(p) for p in self.active} == {id(self.params[i]) for i in state}
+        if not same:
+            # (re)build over exactly the parameters the checkpoint has a state for; the step engine notices the new
+            # `generation` and drops captures that still point at the old moment buffers.  NB torch.optim.Adam would create
+            # the state of a parameter lazily when it first receives a gradient; here the participating set is fixed by
+            # the checkpoint (the 90 gradient-free tensors never change within a run)
+            for i in state:
+                if self.params[i].grad is None:
+                    self.params[i].grad = torch.zeros_like(self.params[i])
+            for i, p in enumerate(self.params):
+                if i not in state and p.grad is not None:
+                    p.grad = None
+            self._build()
         self.step_t.fill_(steps.pop())
         idx = {id(p): i for i, p in enumerate(self.params)}
         with torch.no_grad():

@@ -23,6 +23,15 @@ struct float4 {
     float x, y, z, w;
 };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct float3 {
+    float x, y, z;
+};
+static inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
+// sequential threads: an atomic is a plain update, and every thread is the leader of its own one-lane wave
+static inline int atomicMin(int* p, int v) { int o = *p; if (v < o) *p = v; return o; }
+static inline int atomicMax(int* p, int v) { int o = *p; if (v > o) *p = v; return o; }
+#define SINGA_WAVE_MIN_MAX(lo, hi) ((void)0)
+#define SINGA_WAVE_LEADER true
 
 struct dim3 {
     unsigned x, y, z;

@@ -220,3 +220,40 @@ def test_shard_ranges_by_cost():
     assert shard_ranges_by_cost([1, 1, 1, 1], 1) == [(0, 4)]
     one_heavy = shard_ranges_by_cost([100, 1, 1, 1], 4)
     assert one_heavy == [(0, 1), (1, 2), (2, 3), (3, 4)]
+
+
+def _worker_agree(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    from singa_amd import dp
+    from singa_amd.engine import TrainStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    red = dp.GradAllReducer(Toy())
+    # ragged shards: every rank proposes its own sizes; all derive ONE size class / capacity set from the element-wise MAX
+    sizes = [(5000, 400, 10000, 900, 1300), (5300, 380, 10600, 860, 1400)][rank]
+    agreed = red.max_ints(sizes)
+    eng = TrainStep.__new__(TrainStep)
+    eng._base, eng.growth = None, 1.04
+    c0, caps0 = eng._class_caps(tuple(agreed))
+    later = red.max_ints([(5100, 410, 10100, 905, 1290), (4900, 395, 10900, 880, 1310)][rank])
+    c1, caps1 = eng._class_caps(tuple(later))
+    torch.save({"agreed": agreed, "class": (c0, caps0, c1, caps1), "flag": red.any_rank(rank == 1)}, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_padded_sizes(tmp_path):
+    """TrainStep._stage under data parallelism: the size class and capacities a batch is padded to come from the MAX of
+    the ranks' sizes, so ragged shards replay the same capture signature on every rank (no lone re-captures)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "a")
+    mp.spawn(_worker_agree, args=(2, port, out), nprocs=2, join=True)
+    a, b = torch.load(out + ".0"), torch.load(out + ".1")
+    assert a["agreed"] == b["agreed"] == [5300, 400, 10600, 900, 1400]
+    assert a["class"] == b["class"] and a["flag"] is True and b["flag"] is True
+    c0, caps0, c1, caps1 = a["class"]
+    assert c0 == 0 and all(cap >= v for cap, v in zip(caps0, a["agreed"]))
+    assert all(cap >= v for cap, v in zip(caps1, (5100, 410, 10900, 905, 1310)))

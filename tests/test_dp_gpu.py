@@ -74,6 +74,73 @@ def test_two_ranks_equal_one_process_on_the_union_batch(tmp_path, use_graph):
         assert abs(0.5 * (a + b) - r) < 2e-4 * abs(r), (l0, l1, ref_l)
 
 
+# ---- BASELINE.json configs[3] in miniature: ONE ragged config-3 batch (the bench's generator, L = 4) split over two ranks by
+# edge cost (unequal shards), token-weighted combination, bucketed HIP-graph replay with sizes agreed over the ranks - the
+# path `bench.py --gpus N` takes by default
+CFG3_IDS = [0, 1, 2, 3, 4]
+CFG3_STRIDE = 128
+
+
+def _cfg3_kw():
+    from singa_amd import graph as G
+    return G.resolve_workload("cfg3_b128_l4")[1]
+
+
+def _train_cfg3(rank, world, use_graph):
+    sys.path.insert(0, ROOT)
+    from singa_amd import dp, graph as G
+    from singa_amd.config import load_config
+    from singa_amd.engine import TrainStep
+    from singa_amd.model.GAN import SINGA
+    from singa_amd.optim import Adam
+    kw = _cfg3_kw()
+    torch.manual_seed(11)
+    model = SINGA(load_config(lmax=4), device="cuda").eval()
+    reducer = dp.GradAllReducer(model) if world > 1 else None
+    ids = CFG3_IDS
+    if reducer:
+        reducer.check_same_init()
+        lo, hi = dp.shard_ranges_by_cost([G.graph_cost(G.graph_sizes(i, **kw)) for i in CFG3_IDS], world)[rank]
+        ids = CFG3_IDS[lo:hi]
+        reducer.set_shard_weight(len(ids), len(CFG3_IDS))
+    eng = TrainStep(model, Adam(model.parameters(), lr=1e-4), reducer, use_graph=use_graph, bucket=use_graph, growth=1.04)
+    batches = [G.synthetic_batch(len(ids), ids=[i + k * CFG3_STRIDE for i in ids], **kw).to("cuda") for k in range(2)]
+    losses = [float(eng.step(batches[k % 2]).detach()) for k in range(4)]
+    probe = {n: p.detach().cpu().clone() for n, p in model.named_parameters()
+             if n in ("model.projection.weight", "embedding.blocks.0.ga.alpha_dot", "embedding.blocks.2.ffn.so3_linear_2.weight",
+                      "model.encoder.layers.0.pos_ffn.conv1.weight")}
+    return losses, probe, len(ids), eng.captures
+
+
+def _worker_cfg3(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    torch.save(_train_cfg3(rank, world, True), f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_strong_split_of_a_config3_batch_equals_the_union(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "s")
+    mp.spawn(_worker_cfg3, args=(2, port, out), nprocs=2, join=True)
+    (l0, p0, n0, c0), (l1, p1, n1, c1) = torch.load(out + ".0"), torch.load(out + ".1")
+    assert n0 + n1 == len(CFG3_IDS) and n0 != n1                     # unequal shards
+    assert c0 == c1                                                   # the ranks captured in lockstep
+    ref_l, ref_p, _, _ = _train_cfg3(0, 1, False)                     # one process, eager, on the whole batch
+    for n in ref_p:
+        assert torch.equal(p0[n], p1[n]), n
+        d = (p0[n] - ref_p[n]).norm() / (ref_p[n].norm() + 1e-12)
+        assert float(d) < 2e-4, (n, float(d))
+    # the whole batch's loss is the token-weighted mean of the shard losses
+    for a, b, r in zip(l0, l1, ref_l):
+        assert abs((n0 * a + n1 * b) / (n0 + n1) - r) < 2e-4 * abs(r), (l0, l1, ref_l)
+
+
 def test_rccl_selftest_one_rank_bench():
     """The N-rank code path of bench.py on a ONE-rank RCCL communicator (SINGA_RCCL_SELFTEST=1): process group on `nccl`,
     same-init check, collective capture decision over the side gloo group, barriers, the bucketed all-reduce between the

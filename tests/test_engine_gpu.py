@@ -190,3 +190,101 @@ def test_prefetched_steps_equal_plain_steps():
     a, b = run(False), run(True)
     # not bit-equal even without prefetch: torch's index_add_ (atomics) orders its sums differently from run to run
     assert all(abs(x - y) < 2e-5 * abs(x) for x, y in zip(a, b)), (a, b)
+
+
+def test_eager_steps_keep_no_gradient_address_tables():
+    """ADVICE r2: in eager mode the gradients are re-created every step (new addresses whenever the allocator says so);
+    the optimizer must not keep one address table per distinct address tuple.  Ragged batches + blocks held between the
+    steps force new addresses; only captures pin tables."""
+    from singa_amd import graph as G
+    from singa_amd.config import load_config
+    from singa_amd.engine import TrainStep
+    from singa_amd.model.GAN import SINGA
+    from singa_amd.optim import Adam
+    torch.manual_seed(3)
+    model = SINGA(load_config(lmax=2), device="cuda").eval()
+    opt = Adam(model.parameters(), lr=1e-4)
+    eng = TrainStep(model, opt, None, use_graph=False)
+    seen, hold = set(), []
+    for i in range(6):
+        b = G.synthetic_batch(2, first_id=60 + 2 * i, n_protein=40 + 5 * i, n_ligand=12, e_pp=200 + 16 * i, e_ll=24, e_x=30).to("cuda")
+        eng.step(b)
+        seen.add(opt._grad_ids)
+        hold.append(torch.empty(1 << 18, device="cuda"))      # perturb the allocator between the steps
+    assert len(opt._pinned) == 0 and opt._scratch_table is not None
+    assert len(seen) > 1, "the test did not manage to move the gradients"
+    # a graph engine on the same optimizer pins exactly one table per capture and releases it again
+    eng2 = TrainStep(model, opt, None, use_graph=True)
+    eng2.step(b)
+    eng2.step(b)
+    assert len(opt._pinned) == 1
+    eng2.release()
+    assert len(opt._pinned) == 0
+
+
+def test_load_state_dict_drops_stale_captures():
+    """loading an optimizer state into a running engine must not leave captured optimizer graphs that update
+    moment buffers the optimizer no longer owns: after load_state_dict the replayed trajectory equals the eager one."""
+    from singa_amd.config import load_config
+    from singa_amd.engine import TrainStep
+    from singa_amd.model.GAN import SINGA
+    from singa_amd.optim import Adam
+    z = golden("singa_L2_B3.npz")
+    batch = product_batch(NAMES, z)
+
+    def run(use_graph):
+        model = SINGA(load_config(lmax=2), device="cuda")
+        model.load_state_dict(state_from_spec("singa_L2"), strict=False)
+        model.eval()
+        opt = Adam(model.parameters(), lr=1e-4, betas=(0.99, 0.999))
+        eng = TrainStep(model, opt, None, use_graph=use_graph)
+        out = [float(eng.step(batch).detach()) for _ in range(2)]
+        sd = copy.deepcopy(opt.state_dict())
+        params = [p.detach().clone() for p in model.parameters()]
+        out += [float(eng.step(batch).detach()) for _ in range(2)]
+        # back to the state after step 2: same moments (copied into the existing buffers) ...
+        opt.load_state_dict(sd)
+        with torch.no_grad():
+            for p, q in zip(model.parameters(), params):
+                p.copy_(q)
+        out += [float(eng.step(batch).detach()) for _ in range(2)]
+        # ... and once more through a REBUILT optimizer state (first entry dropped: another active set)
+        first = min(sd["state"])
+        sd2 = {"state": {k: v for k, v in sd["state"].items() if k != first}, "param_groups": sd["param_groups"]}
+        gen = opt.generation
+        opt.load_state_dict(sd2)
+        assert opt.generation == gen + 1
+        with torch.no_grad():
+            for p, q in zip(model.parameters(), params):
+                p.copy_(q)
+        out += [float(eng.step(batch).detach()) for _ in range(2)]
+        return out, eng
+
+    eager, _ = run(False)
+    graph, eng = run(True)
+    assert all(abs(a - b) < 2e-4 * abs(b) for a, b in zip(graph, eager)), (graph, eager)
+    assert abs(eager[4] - eager[2]) < 2e-4 * abs(eager[2]) and abs(eager[5] - eager[3]) < 2e-4 * abs(eager[3])
+    assert eng.captures == 2                                # the rebuilt optimizer forced exactly one re-capture
+
+
+def test_eager_backward_before_capture():
+    """An eager forward + backward (autograd history on the current stream) followed by a graph capture: the SO(2) block
+    weights cached for ONE forward pass must not keep that pass's autograd graph alive (this crashed inside the capture
+    when the cache outlived the pass)."""
+    from singa_amd.config import load_config
+    from singa_amd.engine import TrainStep
+    from singa_amd.model.GAN import SINGA
+    from singa_amd.model import EF_layers
+    from singa_amd.optim import Adam
+    z = golden("singa_L2_B3.npz")
+    batch = product_batch(NAMES, z)
+    model = SINGA(load_config(lmax=2), device="cuda")
+    model.load_state_dict(state_from_spec("singa_L2"), strict=False)
+    model.eval()
+    logits = model(batch)
+    torch.nn.functional.cross_entropy(logits, batch["ligand_data"]["smiIndices_tgt"].reshape(-1)).backward()
+    assert not EF_layers._bw_cache
+    model.zero_grad(set_to_none=True)
+    eng = TrainStep(model, Adam(model.parameters(), lr=1e-4, betas=(0.99, 0.999)), None, use_graph=True)
+    first = float(eng.step(batch).detach())
+    assert abs(first - float(z["loss"])) < 1e-4 * float(z["loss"])

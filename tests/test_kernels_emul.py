@@ -73,6 +73,45 @@ def rad_row_index(lay):
     return np.concatenate(idx)
 
 
+@pytest.mark.parametrize("name", ["3wi2_4tpp", "4agq_5a7b", "5cp5_4nue"])
+def test_edge_frames_match_reference_draws(emul, name):
+    """k1 (the kernel source, run sequentially): on the reference's own torch.rand_like draws the frames equal the ones the
+    reference built (EF:2286-2351; goldens recorded by oracle/make_golden.py), and the two guard statistics are the
+    shortest edge and the largest |cos(edge, helper)| of the oracle's restatement."""
+    from tests.test_oracle_conventions import reference_frame_cases
+    for vec, rand, want in reference_frame_cases(name):
+        vec, rand = vec.float().numpy().copy(), rand.float().numpy().copy()
+        E = vec.shape[0]
+        rot = np.full((E, 3, 3), np.nan, np.float32)
+        stats = np.array([np.inf, 0.0], np.float32)
+        assert emul.singa_edge_frames(ptr(vec), ptr(rand), ptr(rot), ptr(stats), E, None) == 0
+        assert np.abs(rot - want.numpy()).max() < 1e-6
+        assert abs(stats[0] - np.linalg.norm(vec, axis=1).min()) < 1e-6
+        assert 0.0 <= stats[1] < 0.99
+
+
+def test_edge_frame_guard_statistics(emul):
+    """A short edge lowers stats[0] below the reference's 1e-4 threshold (EF:2292-2297); a zero-length edge makes the
+    |cos| statistic NaN, which the product turns into the RuntimeError that stands for the reference's assert (EF:2329)."""
+    rs = np.random.RandomState(3)
+    vec, rand = rs.randn(16, 3).astype(np.float32), rs.rand(16, 3).astype(np.float32)
+    vec[3] = [5e-5, 0.0, 0.0]
+    rot = np.zeros((16, 3, 3), np.float32)
+    stats = np.array([np.inf, 0.0], np.float32)
+    assert emul.singa_edge_frames(ptr(vec), ptr(rand), ptr(rot), ptr(stats), 16, None) == 0
+    assert abs(stats[0] - 5e-5) < 1e-9 and stats[1] < 0.99
+    vec[3] = 0.0
+    stats = np.array([np.inf, 0.0], np.float32)
+    assert emul.singa_edge_frames(ptr(vec), ptr(rand), ptr(rot), ptr(stats), 16, None) == 0
+    assert stats[0] == 0.0 and np.isnan(stats[1])
+    # statistics accumulate across launches (what the captured graphs rely on)
+    stats = np.array([0.25, 0.5], np.float32)
+    v2 = np.tile(np.array([[1.0, 0.0, 0.0]], np.float32), (4, 1))
+    r2 = np.tile(np.array([[0.5, 0.9, 0.5]], np.float32), (4, 1))
+    assert emul.singa_edge_frames(ptr(v2), ptr(r2), ptr(rot), ptr(stats), 4, None) == 0
+    assert stats[0] == 0.25 and stats[1] == 0.5
+
+
 @pytest.mark.parametrize("L", [2, 4, 6])
 def test_wigner_rows(emul, L):
     rs = np.random.RandomState(L)

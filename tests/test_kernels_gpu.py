@@ -55,6 +55,62 @@ def test_library_loaded_and_no_cpu_path():
         ops.so3_rmsnorm(torch.zeros(2, 9, 16), torch.ones(3, 16), torch.zeros(16), 2)
 
 
+@pytest.mark.parametrize("name", ["3wi2_4tpp", "4agq_5a7b", "5cp5_4nue"])
+def test_edge_frames_match_reference_draws(name):
+    """k1 on the GPU through the product's init_edge_rot_mat: the frames the REFERENCE built from its own torch.rand_like
+    draws (EF:2286-2351; tests/golden/rot_rand_*.npz + rot_* of embed_L2_*.npz), 1e-6 absolute."""
+    from singa_amd.model.EF_layers import init_edge_rot_mat
+    from tests.test_oracle_conventions import reference_frame_cases
+    for vec, rand, want in reference_frame_cases(name):
+        got = init_edge_rot_mat(vec.float().to(DEV), rand=rand.float().to(DEV))
+        assert got.shape == want.shape and float((got.cpu() - want).abs().max()) < 1e-6
+
+
+def test_edge_frame_guards():
+    """EF:2292-2297 (short edge: report only) and EF:2329 (aligned helper / NaN: abort) in the product, on the GPU."""
+    from singa_amd.model.EF_layers import init_edge_rot_mat
+    rs = np.random.RandomState(2)
+    vec = torch.tensor(rs.randn(16, 3), dtype=torch.float32, device=DEV)
+    rand = torch.tensor(rs.rand(16, 3), dtype=torch.float32, device=DEV)
+    v = vec.clone()
+    v[3] = torch.tensor([5e-5, 0.0, 0.0], device=DEV)
+    with pytest.warns(RuntimeWarning, match="edge_vec_0_distance"):
+        init_edge_rot_mat(v, rand=rand)
+    v[3] = 0.0
+    with pytest.warns(RuntimeWarning), pytest.raises(RuntimeError, match="aligned"):
+        init_edge_rot_mat(v, rand=rand)
+    assert init_edge_rot_mat(vec[:0], rand=rand[:0]).shape == (0, 3, 3)
+
+
+def test_edge_frame_statistics_replay_at_bench_size():
+    """the guards' statistics must come out of a replayed HIP graph exactly as out of an eager launch at the
+    edge counts of the bench (120 k - 500 k edges: many workgroups).  They are integer min / max atomics on float bit
+    patterns, so the values are order-independent and exact."""
+    ops = _ops()
+    for E in (120_001, 500_000):
+        g = torch.Generator(device="cpu").manual_seed(E)
+        vec = (torch.randn(E, 3, generator=g) * 2.0).to(DEV)
+        rand = torch.rand(E, 3, generator=g).to(DEV)
+        eager = torch.tensor([float("inf"), 0.0], device=DEV)
+        rot_e = ops.edge_frames(vec, rand, eager)
+        want_min = float(vec.norm(dim=1).min())
+        assert abs(float(eager[0]) - want_min) <= 1e-6 * want_min and 0.0 < float(eager[1]) < 0.99
+        stat = torch.tensor([float("inf"), 0.0], device=DEV)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ops.edge_frames(vec, rand, stat)
+        torch.cuda.current_stream().wait_stream(side)
+        stat.copy_(torch.tensor([float("inf"), 0.0]))
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            rot_g = ops.edge_frames(vec, rand, stat)
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(stat, eager) and torch.equal(rot_g, rot_e)
+
+
 @pytest.mark.parametrize("L", [2, 4, 6])
 def test_wigner_rows(L):
     ops = _ops()

@@ -44,6 +44,16 @@ def real_sh(L, xyz):
     return np.stack(cols, 1)
 
 
+def reference_frame_cases(name):
+    """(edge vectors, the reference's uniform draws, the frames the reference built) for the three edge types of a
+    bundled graph."""
+    z, rr = golden(f"embed_L2_{name}.npz"), golden(f"rot_rand_{name}.npz")
+    g = O.load_graph_npz(os.path.join(GOLDEN, f"graph_{name}.npz"))
+    for k, (ei, ps, pd) in {"pp": ("ei_pp", "pos_p", "pos_p"), "ll": ("ei_ll", "pos_l", "pos_l"),
+                            "lp": ("ei_lp", "pos_l", "pos_p")}.items():
+        yield g[ps][g[ei][0]] - g[pd][g[ei][1]], torch.as_tensor(rr[k]), torch.as_tensor(z[f"rot_{k}"])
+
+
 def _frames(n, seed):
     rng = np.random.default_rng(seed)
     vec = torch.tensor(rng.normal(size=(n, 3)), dtype=torch.float64)
@@ -64,34 +74,12 @@ def test_edge_frame_is_a_rotation_taking_the_edge_to_plus_y():
 
 @pytest.mark.parametrize("name", NAMES)
 def test_edge_frames_match_reference_draws(name):
-    """oracle.edge_rot_mat AND the product's init_edge_rot_mat on the reference's own torch.rand_like draws
-    (tests/golden/rot_rand_*.npz, recorded by oracle/make_golden.py) reproduce the frames the reference built
-    (rot_pp / rot_ll / rot_lp of embed_L2_*.npz; reference model/EF_layers.py:2286-2351)."""
-    from singa_amd.model.EF_layers import init_edge_rot_mat
-    z, rr = golden(f"embed_L2_{name}.npz"), golden(f"rot_rand_{name}.npz")
-    g = O.load_graph_npz(os.path.join(GOLDEN, f"graph_{name}.npz"))
-    for k, (ei, ps, pd) in {"pp": ("ei_pp", "pos_p", "pos_p"), "ll": ("ei_ll", "pos_l", "pos_l"),
-                            "lp": ("ei_lp", "pos_l", "pos_p")}.items():
-        vec = g[ps][g[ei][0]] - g[pd][g[ei][1]]
-        want = torch.as_tensor(z[f"rot_{k}"])
-        rand = torch.as_tensor(rr[k])
+    """oracle.edge_rot_mat on the reference's own torch.rand_like draws (tests/golden/rot_rand_*.npz, recorded by
+    oracle/make_golden.py) reproduces the frames the reference built (rot_pp / rot_ll / rot_lp of embed_L2_*.npz;
+    reference model/EF_layers.py:2286-2351).  The product's k1 kernel is held to the same frames in
+    tests/test_kernels_emul.py (the kernel source on the CPU) and tests/test_kernels_gpu.py (-m gpu)."""
+    for vec, rand, want in reference_frame_cases(name):
         assert float((O.edge_rot_mat(vec, rand) - want).abs().max()) < 1e-6
-        assert float((init_edge_rot_mat(vec, rand=rand) - want).abs().max()) < 1e-6
-
-
-def test_edge_frame_guards():
-    """EF:2292-2297 (short edge: report only) and EF:2329 (aligned helper / NaN: abort) in the product."""
-    from singa_amd.model.EF_layers import init_edge_rot_mat
-    vec, rand, _ = _frames(16, 2)
-    vec, rand = vec.float(), rand.float()
-    v = vec.clone()
-    v[3] = torch.tensor([5e-5, 0.0, 0.0])
-    with pytest.warns(RuntimeWarning, match="edge_vec_0_distance"):
-        init_edge_rot_mat(v, rand=rand)
-    v[3] = 0.0
-    with pytest.warns(RuntimeWarning), pytest.raises(RuntimeError, match="aligned"):
-        init_edge_rot_mat(v, rand=rand)
-    assert init_edge_rot_mat(vec[:0], rand=rand[:0]).shape == (0, 3, 3)
 
 
 # ------------------------------------------------------------------------------------------------ Wigner matrices

@@ -20,9 +20,7 @@ def test_workload_step_matches_oracle(workload):
     from singa_amd import graph as G
     from singa_amd.config import load_config
     from singa_amd.model.GAN import SINGA
-    wl = dict(G.WORKLOADS[workload])
-    L = wl["lmax"]
-    kw = {k: v for k, v in wl.items() if k not in ("n_graphs", "lmax")}
+    L, kw, _, _ = G.resolve_workload(workload)
     ids = [3, 4]
     graphs = [G.synthetic_graph(i, **G.graph_sizes(i, **kw)) for i in ids]
     cfg = load_config(lmax=L)
@@ -64,6 +62,31 @@ def test_workload_step_matches_oracle(workload):
             bad.append((name, err, float(go.norm())))
     assert n_checked == 634, n_checked                    # 634 of the 724 tensors carry gradients
     assert not bad, bad[:8]
+
+
+def test_cfg5_l6_b8_loss_matches_oracle():
+    """BASELINE.json configs[4] at full PER-GRAPH size (800 protein + 40 ligand atoms, ~8 k edges per graph, l_max = 6) on an
+    8-graph batch: the HIP path's logits and CrossEntropy against the CPU oracle's (forward only: the oracle needs ~20 s
+    for it; gradients at this size are covered by the 2-graph case above)."""
+    from singa_amd import graph as G
+    from singa_amd.config import load_config
+    from singa_amd.model.GAN import SINGA
+    L, kw, ids, _ = G.resolve_workload("cfg5_l6_b8")
+    graphs = [G.synthetic_graph(i, **G.graph_sizes(i, **kw)) for i in ids]
+    torch.manual_seed(7)
+    model = SINGA(load_config(lmax=L), device=DEV).eval()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    b, rots, lap_p, lap_l = O.batch_from_graphs(graphs)
+    with torch.no_grad():
+        bp = torch.repeat_interleave(torch.arange(len(ids)), b["ptr_p"][1:] - b["ptr_p"][:-1])
+        bl = torch.repeat_interleave(torch.arange(len(ids)), b["ptr_l"][1:] - b["ptr_l"][:-1])
+        ref = O.singa_forward(sd, b, rots, L, O.knn_graph(b["pos_p"], 48, bp), O.knn_graph(b["pos_l"], 30, bl), lap_p, lap_l)
+        loss_o = torch.nn.functional.cross_entropy(ref, b["tok_tgt"].reshape(-1))
+        batch = G.collate(graphs).to(DEV)
+        logits = model(batch)
+        loss = torch.nn.functional.cross_entropy(logits, batch["ligand_data"]["smiIndices_tgt"].reshape(-1))
+    assert rel_err(logits.cpu(), ref) < 1e-4
+    assert abs(float(loss) - float(loss_o)) < 1e-4 * abs(float(loss_o)), (float(loss), float(loss_o))
 
 
 def test_laplacian_pe_batched_on_gpu_against_oracle_spectrum():

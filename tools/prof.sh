@@ -11,9 +11,11 @@ wl=${2:-cfg3_b128_l4}
 out=gpurun_out/prof_${tag}
 raw=/tmp/prof_raw_${tag}
 mkdir -p $out $raw
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/trace -- python3 bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline > $out/trace.log 2>&1 || echo "trace run failed"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $raw/trace -- python3 bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --proxy-steps 0 > $out/trace.log 2>&1 || echo "trace run failed"
 grep "^{\"metric" $out/trace.log > $out/bench_under_rocprof.json
 echo "trace done" > $out/progress.txt
+if [ ! -s $out/bench_under_rocprof.json ]; then echo "the profiled bench run printed no result line:"; tail -30 $out/trace.log; exit 1; fi
+if [ "$TRACE_ONLY" = "1" ]; then python3 tools/prof_summarize.py $raw $out $wl; ls -la $out; exit 0; fi
 for c in FETCH_SIZE WRITE_SIZE; do
   SINGA_CALIB=1 timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $raw/pmc_$c -- python3 bench.py --workload $wl --eager --steps 2 --warmup 1 --roofline-steps 1 --no-cpu-baseline > $out/pmc_$c.log 2>&1 || echo "pmc $c run failed"
   echo "pmc $c done" >> $out/progress.txt

@@ -62,6 +62,9 @@ def main():
                     help="capture the step into HIP graphs and replay it; batches of different sizes are padded to size "
                          "classes, one capture per class")
     ap.add_argument("--resume", type=str, default=None, help="checkpoint to load (model, optimizer, scheduler, iteration)")
+    ap.add_argument("--no-dropout", action="store_true",
+                    help="switch the decoder's positional-encoding dropout (reference CProMG.py:198, p = 0.1: the only stochastic "
+                         "op of the step besides the edge-frame draws) off - reproducible runs for parity checks")
     args = ap.parse_args()
     assert args.device.startswith("cuda"), "the hot path is the HIP path: there is no CPU fallback"
 
@@ -107,6 +110,8 @@ def main():
         return G.collate(gs).to(dev)
 
     model = SINGA(cfg, device=dev)
+    if args.no_dropout:
+        model.model.decoder.pos_emb.dropout.p = 0.0
     o = cfg.train.optimizer
     from singa_amd.optim import Adam
     assert o.type == "adam" and o.weight_decay == 0
