@@ -207,16 +207,18 @@ int singa_masked_softmax_bwd(const float* p, const float* gp, const unsigned cha
  * token_major != 0: q / k / v / ctx (and the gradients of _bwd) are [B, T|S, heads, D] - the layout in which the W_Q / W_K /
  * W_V projections produce them and `linear` consumes the context (model/CProMG.py:96-117) - instead of [B*heads, T|S, D]:
  * the reference's `.view(B, -1, heads, d).transpose(1, 2)` copies and the `.transpose(1, 2).contiguous()` of the context
- * disappear.  lse and dsum stay [B*heads, T]. */
+ * disappear.  lse and dsum stay [B*heads, T].  ld_q / ld_k / ld_v (token_major only; 0 = dense): floats between consecutive
+ * tokens of q / k / v - and of g_q / g_k / g_v in _bwd - when they are column blocks of ONE fused projection output
+ * [B, T, 128 + 128 + 256] (W_Q | W_K | W_V evaluated as one GEMM) instead of three dense tensors; ctx / g_ctx stay dense. */
 int singa_attn_fwd(const float* q, const float* k, const float* v, const unsigned char* mask, long long mask_stride_b,
                    long long mask_stride_t, float* ctx, float* lse, int BH, int T, int S, int heads, int DK, int DV,
-                   int token_major, float scale, void* stream);
+                   int token_major, long long ld_q, long long ld_k, long long ld_v, float scale, void* stream);
 /* gradients g_q, g_k, g_v from g_ctx: scores are recomputed from q, k and lse (nothing of size T x S is ever stored);
  * dsum[BH,T] is scratch (rowsum(g_ctx * ctx), written by the first pass and read by the second). */
 int singa_attn_bwd(const float* q, const float* k, const float* v, const unsigned char* mask, long long mask_stride_b,
                    long long mask_stride_t, const float* ctx, const float* lse, const float* g_ctx, float* g_q, float* g_k,
-                   float* g_v, float* dsum, int BH, int T, int S, int heads, int DK, int DV, int token_major, float scale,
-                   void* stream);
+                   float* g_v, float* dsum, int BH, int T, int S, int heads, int DK, int DV, int token_major, long long ld_q,
+                   long long ld_k, long long ld_v, float scale, void* stream);
 
 /* k6a — LayerNorm over C = 16 channels followed by SiLU: the `nn.LayerNorm`, `nn.SiLU` pair inside RadialFunction
  * (reference model/EF_layers.py:1634-1657, net.1/net.2 and net.4/net.5).  x, out, g_out, g_x: [M, C] contiguous; biased
@@ -292,7 +294,8 @@ int singa_adam_step(float* const* p, const float* const* g, float* const* m, flo
  *   Built combinations: (1,1) y = x W^T; (1,0) dx = dy W; (0,0) dW = dy^T x.
  *   splits > 1: the reduction range is cut into `splits` chunks; chunk s writes a dense [I, J] slab (ldc = J, no bias, no
  *   grouping) at c + s * c_split_stride, which the caller adds up (singa_colsum).
- *   All problems of a launch use 128 x 128 output tiles, 128 x 32 when every J <= 32, or 32 x 128 when every I <= 32.
+ *   All problems of a launch use 128 x 128 output tiles, 128 x 32 when every J <= 32, 32 x 128 when every I <= 32, or
+ *   64 x 64 when the launch has fewer than 384 tiles of 128 x 128.
  * Contiguous axes (of A, B and of the result: J, ldc) must be multiples of 4 floats and 16-byte aligned.  Enqueue-only
  * on `stream`. */
 #define SINGA_GEMM_MAX 8
@@ -306,9 +309,16 @@ typedef struct {
     int32_t a_group, b_group, c_group;           /* rows per group (0 = plain rows) */
     int64_t a_group_ld, b_group_ld, c_group_ld;
     int64_t c_split_stride;                       /* floats between the partial slabs of consecutive splits */
+    const float* mask;        /* NULL, or a tensor with c's (plain-row) layout: c is zeroed where mask <= 0 (ReLU gradient) */
+    const float* addend;      /* NULL, or a tensor with c's (plain-row) layout that is added to the product (a sum of two Linears'
+                                 outputs, CP:77,400: `centroid_lin(x) + aggr_msg`) */
+    int32_t relu;             /* != 0: c = max(c, 0) after bias and addend (nn.ReLU behind a Linear, CP:171,188) */
 } singa_gemm_t;
 int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_contig, int splits, void* stream);
-/* resident workgroups per CU of one kernel variant (cfg 0: 128x128, 1: 128x32, 2: 32x128 tiles), for the lab probes */
+/* tests only: force the 128 x 128 (0) or the 64 x 64 (3) tile shape wherever the automatic choice is between those two;
+ * -1 = automatic. */
+int singa_gemm_force_cfg(int cfg);
+/* resident workgroups per CU of one kernel variant (cfg 0: 128x128, 1: 128x32, 2: 32x128, 3: 64x64 tiles), for the lab probes */
 int singa_gemm_occupancy(int a_r_contig, int b_r_contig, int cfg);
 
 /* k11s - SO3_LinearV2 (model/EF_layers.py:655-671) between 16 and C = 512 channels (the feed-forward block, EF:232-262) or
@@ -320,10 +330,22 @@ int singa_gemm_occupancy(int a_r_contig, int b_r_contig, int cfg);
  * [l][c][u] (out_cu != 0) or [l][u][c], = sum over the part's nodes and the rows k of degree l of small[n, k, u] * big[n, k, c];
  * the bias row is sum_n big[n, 0, c].  The caller adds the parts up (singa_colsum / singa_colsum_multi). */
 int singa_so3_skinny_nparts(int N, int lmax, int C);
+/* tests / lab only: 1 selects the VALU (lane-broadcast) form of the two kernels below, 0 (default) the matrix-core form */
+int singa_so3_skinny_variant(int valu);
 int singa_so3_skinny_expand(const float* small, const float* W, long long w_l, long long w_c, long long w_u, const float* bias,
                             float* big, int N, int C, int lmax, void* stream);
 int singa_so3_skinny_reduce(const float* small, const float* big, float* part, int N, int C, int lmax, int out_cu, int bias_row,
                             void* stream);
+
+/* n2 - Laplacian positional encoding (reference model/CProMG.py:562-571 `lap_pe` -> dgl.lap_pe(g, k), called inside forward
+ * at model/GAN.py:71,77): for each of B graphs the kout (<= 8) eigenvectors after the smallest of its dense symmetric
+ * matrix A[b] (fp64, [ld, ld] row-major, only the leading nnodes[b] x nnodes[b] block is used and DESTROYED), entry of
+ * largest magnitude made positive, written as fp32 rows out[first[b] + i, 0..kout-1]; graphs with fewer than kout + 1
+ * nodes get zero columns.  work: singa_lap_eig_work(B, ld) doubles.  ld <= 1016.  One workgroup per graph: Householder
+ * tridiagonalisation, Sturm multi-section, inverse iteration, back-transformation. */
+int singa_lap_eig_work(int B, int ld);
+int singa_lap_eig(double* A, const int32_t* nnodes, const int32_t* first, double* work, float* out, int B, int ld, int kout,
+                  void* stream);
 
 /* Total 2-norm of all gradients over the same (tensor, chunk) table as singa_adam_step: torch.nn.utils.clip_grad_norm_'s
  * norm (reference train.py:126), deterministic and HIP-graph replayable.  partial: nchunks floats of scratch; out: 1 float. */

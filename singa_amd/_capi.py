@@ -19,7 +19,8 @@ class Gemm(C.Structure):
     """singa_gemm_t of include/singa_hip.h"""
     _fields_ = [("a", P), ("b", P), ("c", P), ("bias", P), ("lda", I64), ("ldb", I64), ("ldc", I64), ("I", C.c_int32),
                 ("J", C.c_int32), ("R", C.c_int32), ("a_group", C.c_int32), ("b_group", C.c_int32), ("c_group", C.c_int32),
-                ("a_group_ld", I64), ("b_group_ld", I64), ("c_group_ld", I64), ("c_split_stride", I64)]
+                ("a_group_ld", I64), ("b_group_ld", I64), ("c_group_ld", I64), ("c_split_stride", I64), ("mask", P),
+                ("addend", P), ("relu", C.c_int32)]
 
 
 def gemm_probs(items):
@@ -70,8 +71,8 @@ _SIGS = {
     "singa_edge_mlp_bwd": ([P] * 6 + [I32, I32, I32, P], I32),
     "singa_masked_softmax_fwd": ([P, P, I64, I64, P, I32, I32, I32, I32, F32, P], I32),
     "singa_masked_softmax_bwd": ([P, P, P, I64, I64, P, I32, I32, I32, I32, F32, P], I32),
-    "singa_attn_fwd": ([P, P, P, P, I64, I64, P, P, I32, I32, I32, I32, I32, I32, I32, F32, P], I32),
-    "singa_attn_bwd": ([P, P, P, P, I64, I64] + [P] * 7 + [I32, I32, I32, I32, I32, I32, I32, F32, P], I32),
+    "singa_attn_fwd": ([P, P, P, P, I64, I64, P, P, I32, I32, I32, I32, I32, I32, I32, I64, I64, I64, F32, P], I32),
+    "singa_attn_bwd": ([P, P, P, P, I64, I64] + [P] * 7 + [I32, I32, I32, I32, I32, I32, I32, I64, I64, I64, F32, P], I32),
     "singa_ln256_nparts": ([I64], I32),
     "singa_ln256_fwd": ([P] * 5 + [I64, I32, F32, P], I32),
     "singa_ln256_bwd": ([P] * 6 + [I64, I32, F32, P], I32),
@@ -81,14 +82,18 @@ _SIGS = {
     "singa_colsum_work": ([C.c_longlong, I32], C.c_longlong),
     "singa_colsum": ([P, C.c_longlong, C.c_longlong, I32, P, P, P], I32),
     "singa_so3_skinny_nparts": ([I32, I32, I32], I32),
+    "singa_so3_skinny_variant": ([I32], I32),
     "singa_so3_skinny_expand": ([P, P, I64, I64, I64, P, P, I32, I32, I32, P], I32),
     "singa_so3_skinny_reduce": ([P, P, P, I32, I32, I32, I32, I32, P], I32),
     "singa_colsum_multi_work": ([C.c_longlong, I32], C.c_longlong),
     "singa_colsum_multi": ([I32, P, P, P, P, P, I32, P, P, P, C.c_longlong, P], I32),
+    "singa_lap_eig_work": ([I32, I32], I32),
+    "singa_lap_eig": ([P, P, P, P, P, I32, I32, I32, P], I32),
     "singa_adam_step": ([P, P, P, P, P, P, P, I32, I32, P, P, F32, F32, F32, P], I32),
     "singa_grad_norm": ([P, P, P, P, I32, I32, P, P, P], I32),
     "singa_gemm_f32": ([C.POINTER(Gemm), I32, I32, I32, I32, P], I32),
     "singa_gemm_occupancy": ([I32, I32, I32], I32),
+    "singa_gemm_force_cfg": ([I32], I32),
     "singa_prof_enable": ([I32], I32),
     "singa_prof_hint_edges": ([I32], I32),
     "singa_prof_collect": ([P, P, P, I32], I32),

@@ -1816,13 +1816,16 @@ struct AttnLay {
     long long qb, kb, vb, ob;      // float offset of row 0 in q / k / v / ctx-like tensors
     int qs, ks, vs, os;            // floats between consecutive rows
 };
-__device__ __forceinline__ AttnLay attn_lay(int bh, int heads, int T, int S, int tm) {
+struct AttnPitch {
+    int q, k, v;                   // token-major only: floats between consecutive tokens of q / k / v (and of their gradients);
+};                                 // heads * D when dense, larger when they are column blocks of one fused projection output
+__device__ __forceinline__ AttnLay attn_lay(int bh, int heads, int T, int S, int tm, AttnPitch ld) {
     AttnLay a;
     if (tm) {
         const int b = bh / heads, h = bh - b * heads;
-        a.qb = ((long long)b * T * heads + h) * 32; a.kb = ((long long)b * S * heads + h) * 32;
-        a.vb = ((long long)b * S * heads + h) * 64; a.ob = ((long long)b * T * heads + h) * 64;
-        a.qs = heads * 32; a.ks = heads * 32; a.vs = heads * 64; a.os = heads * 64;
+        a.qb = (long long)b * T * ld.q + h * 32; a.kb = (long long)b * S * ld.k + h * 32;
+        a.vb = (long long)b * S * ld.v + h * 64; a.ob = ((long long)b * T * heads + h) * 64;
+        a.qs = ld.q; a.ks = ld.k; a.vs = ld.v; a.os = heads * 64;
     } else {
         a.qb = (long long)bh * T * 32; a.kb = (long long)bh * S * 32; a.vb = (long long)bh * S * 64; a.ob = (long long)bh * T * 64;
         a.qs = 32; a.ks = 32; a.vs = 64; a.os = 64;
@@ -1833,7 +1836,7 @@ __device__ __forceinline__ AttnLay attn_lay(int bh, int heads, int T, int S, int
 __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, const unsigned char* __restrict__ mask,
                                                        long long msb, long long mst, float* __restrict__ ctx,
-                                                       float* __restrict__ lse, int BH, int T, int S, int heads, int tm, float scale) {
+                                                       float* __restrict__ lse, int BH, int T, int S, int heads, int tm, float scale, AttnPitch ld) {
     const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
     const int qtiles = (T + 31) / 32;
     // XCD b % 8 takes a contiguous eighth of the (batch x head, tile) list: the keys / values of one (batch, head) are
@@ -1842,7 +1845,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
     if (w >= (long long)BH * qtiles) return;
     const int bh = (int)(w / qtiles), qt = (int)(w - (long long)bh * qtiles);
     const int tq = qt * 32 + i, tqc = tq < T ? tq : T - 1;
-    const AttnLay A = attn_lay(bh, heads, T, S, tm);
+    const AttnLay A = attn_lay(bh, heads, T, S, tm, ld);
     float qreg[16];
 #pragma unroll
     for (int m4 = 0; m4 < 4; ++m4) {
@@ -1938,7 +1941,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
                                                           long long msb, long long mst, const float* __restrict__ ctx,
                                                           const float* __restrict__ lse, const float* __restrict__ go,
                                                           float* __restrict__ gq, float* __restrict__ dsum, int BH, int T, int S,
-                                                          int heads, int tm, float scale) {
+                                                          int heads, int tm, float scale, AttnPitch ld) {
     const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
     const int qtiles = (T + 31) / 32;
     // XCD b % 8 takes a contiguous eighth of the (batch x head, tile) list: the keys / values of one (batch, head) are
@@ -1948,7 +1951,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
     const int bh = (int)(w / qtiles), qt = (int)(w - (long long)bh * qtiles);
     const int tq = qt * 32 + i, tqc = tq < T ? tq : T - 1;
     const long long qrow = (long long)bh * T + tqc;                  // lse / dsum stay [B*heads, T]
-    const AttnLay A = attn_lay(bh, heads, T, S, tm);
+    const AttnLay A = attn_lay(bh, heads, T, S, tm, ld);
     float qreg[16], goreg[32];
 #pragma unroll
     for (int m4 = 0; m4 < 4; ++m4) {
@@ -2025,7 +2028,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
                                                            long long msb, long long mst, const float* __restrict__ lse,
                                                            const float* __restrict__ dsum, const float* __restrict__ go,
                                                            float* __restrict__ gk, float* __restrict__ gv, int BH, int T, int S,
-                                                           int heads, int tm, float scale) {
+                                                           int heads, int tm, float scale, AttnPitch ld) {
     const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
     const int ktiles = (S + 31) / 32;
     // XCD b % 8 takes a contiguous eighth of the (batch x head, tile) list: the keys / values of one (batch, head) are
@@ -2035,7 +2038,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
     const int bh = (int)(w / ktiles), kt = (int)(w - (long long)bh * ktiles);
     const int key = kt * 32 + i, keyc = key < S ? key : S - 1;
     const bool kin = key < S;
-    const AttnLay A = attn_lay(bh, heads, T, S, tm);
+    const AttnLay A = attn_lay(bh, heads, T, S, tm, ld);
     float kreg[16], vreg[32];
 #pragma unroll
     for (int m4 = 0; m4 < 4; ++m4) {
@@ -2786,6 +2789,165 @@ __global__ void __launch_bounds__(SkinnyCfg<C>::BLOCK) so3_skinny_reduce_kernel(
     if (bias_row) p[WSZ_ + c] = accb;
 }
 
+// ---- k11s on the matrix cores.  The VALU kernels above spend one v_readlane per FMA (the 16-wide operand is a lane
+// broadcast), i.e. ~800 vector instructions per thread and node for 100 bytes of the big tensor: 0.73 / 0.86 ms per launch at
+// config 3 against 0.48 ms for moving the 2.5 GB.  v_mfma_f32_16x16x4_f32 does the same 16-long contraction with the big
+// tensor's channels on the lanes and needs 32 cycles per KB of it per SIMD - a quarter of what HBM can feed - so both kernels
+// become plain streaming kernels.  Channel slab of a wavefront: 64 channels c0 + 4 i + t (i = lane & 15 = MFMA column, t = 0..3
+// = one of four accumulator tiles): the four tiles of a lane are four CONSECUTIVE channels, so every access to the big tensor
+// is a float4 per lane and 256 contiguous bytes per row and 16-lane group.
+//   expand: tile rows = 16 consecutive nodes at one coefficient k, contraction u = 4 g + j (g = lane >> 4, j = MFMA step):
+//           A = small[node i][k][4 g .. 4 g + 3] (one float4 load), B = W[l(k)][channel][u] (registers, per degree).
+//   reduce: tile rows = the 16 values of u, contraction = 4 consecutive nodes at one coefficient k:
+//           A = small[node g][k][u = i], B = big[node g][k][4 channels] (one float4 load), accumulators per degree.
+#ifndef SINGA_FLOATX4
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+#else
+typedef SINGA_FLOATX4 floatx4;
+#endif
+
+template <int L, int C>
+__global__ void __launch_bounds__(SkinnyCfg<C>::BLOCK) so3_skinny_expand_mfma_kernel(const float* __restrict__ small, const float* __restrict__ W,
+                                                                     long long w_l, long long w_c, long long w_u,
+                                                                     const float* __restrict__ bias, float* __restrict__ big, int N,
+                                                                     int npb) {
+    constexpr int K = (L + 1) * (L + 1), HV = SkinnyCfg<C>::HALVES, BL = SkinnyCfg<C>::BLOCK;
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int c0 = ((int)(blockIdx.x % HV) * (BL / 64) + (int)(threadIdx.x >> 6)) * 64 + 4 * i;   // this lane's four channels
+    const bool act = c0 + 3 < C;                                   // (C is a multiple of 4: a lane's float4 is inside or outside)
+    const int cc = act ? c0 : C - 4;
+    const int n0 = (int)(blockIdx.x / HV) * npb;
+    const int n1 = n0 + npb < N ? n0 + npb : N;
+    if (n0 >= n1) return;
+    float w[L + 1][4][4];                                          // [degree][tile t = channel cc + t][step j: u = 4 g + j]
+#pragma unroll
+    for (int l = 0; l <= L; ++l)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[l][t][j] = W[l * w_l + (cc + t) * w_c + (4 * g + j) * w_u];
+    float4 bc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) bc = *reinterpret_cast<const float4*>(bias + cc);
+    for (int nb = n0; nb < n1; nb += 16) {
+        const int na = nb + i < n1 ? nb + i : n1 - 1;              // the node whose rows this lane feeds as A
+        const float* arow = small + (long long)na * K * 16 + 4 * g;
+        float4 a = *reinterpret_cast<const float4*>(arow);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float4 an = a;
+            if (k + 1 < K) an = *reinterpret_cast<const float4*>(arow + (k + 1) * 16);
+            int l = 0;
+            while ((l + 1) * (l + 1) <= k) ++l;
+            const float av[4] = {a.x, a.y, a.z, a.w};
+            floatx4 acc[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float b0 = k == 0 ? (t == 0 ? bc.x : (t == 1 ? bc.y : (t == 2 ? bc.z : bc.w))) : 0.f;
+                acc[t] = floatx4{b0, b0, b0, b0};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], w[l][t][j], acc[t], 0, 0, 0);
+            // accumulator register r = tile row 4 g + r = node nb + 4 g + r, column i = channels cc .. cc + 3 over the tiles
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = nb + 4 * g + r;
+                if (act && n < n1)
+                    *reinterpret_cast<float4*>(big + ((long long)n * K + k) * C + cc) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+            }
+            a = an;
+        }
+    }
+}
+
+template <int L>
+struct SkinnyChunk {
+    static constexpr int K = (L + 1) * (L + 1);
+    static constexpr int D = L == 2 ? 3 : (L == 4 ? 5 : 7);        // coefficient rows per prefetch chunk (K = D * D)
+};
+
+template <int L, int C>
+__global__ void __launch_bounds__(SkinnyCfg<C>::BLOCK) so3_skinny_reduce_mfma_kernel(const float* __restrict__ small, const float* __restrict__ big,
+                                                                     float* __restrict__ part, int N, int npb, int out_cu,
+                                                                     int bias_row) {
+    constexpr int K = (L + 1) * (L + 1), HV = SkinnyCfg<C>::HALVES, BL = SkinnyCfg<C>::BLOCK, D = SkinnyChunk<L>::D, NCH = K / D;
+    static_assert(NCH * D == K, "chunking");
+    const int lane = threadIdx.x & 63, i = lane & 15, g = lane >> 4;
+    const int c0 = ((int)(blockIdx.x % HV) * (BL / 64) + (int)(threadIdx.x >> 6)) * 64 + 4 * i;
+    const bool act = c0 + 3 < C;
+    const int cc = act ? c0 : C - 4;
+    const int n0 = (int)(blockIdx.x / HV) * npb;
+    const int n1 = n0 + npb < N ? n0 + npb : N;
+    floatx4 acc[L + 1][4];
+#pragma unroll
+    for (int l = 0; l <= L; ++l)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[l][t] = floatx4{0.f, 0.f, 0.f, 0.f};
+    float4 accb = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n0 < n1) {
+        float4 bcur[D], bnxt[D];
+        float acur[D], anxt[D];
+        // chunk (q, ch): coefficients ch * D .. ch * D + D - 1 of the node quad q (nodes q + g); rows past the run are fed as
+        // zeros on the A side (their B rows are read from the last valid node: finite values times zero)
+        auto load = [&](float4* b, float* a, int q, int ch) {
+            const int n = q + g;
+            const bool ok = n < n1;
+            const long long nn = ok ? n : n1 - 1;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int k = ch * D + d;
+                b[d] = *reinterpret_cast<const float4*>(big + (nn * K + k) * C + cc);
+                const float v = small[(nn * K + k) * 16 + i];
+                a[d] = ok ? v : 0.f;
+            }
+        };
+        load(bnxt, anxt, n0, 0);
+        for (int q = n0; q < n1; q += 4) {
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) bcur[d] = bnxt[d], acur[d] = anxt[d];
+                if (ch + 1 < NCH) load(bnxt, anxt, q, ch + 1);
+                else load(bnxt, anxt, q + 4 < n1 ? q + 4 : q, 0);
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int k = ch * D + d;
+                    int l = 0;
+                    while ((l + 1) * (l + 1) <= k) ++l;
+                    const float bv[4] = {bcur[d].x, bcur[d].y, bcur[d].z, bcur[d].w};
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) acc[l][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[d], bv[t], acc[l][t], 0, 0, 0);
+                    if (k == 0 && q + g < n1) {
+                        accb.x += bv[0]; accb.y += bv[1]; accb.z += bv[2]; accb.w += bv[3];
+                    }
+                }
+            }
+        }
+    }
+    constexpr int WSZ_ = (L + 1) * 16 * C;
+    float* p = part + (long long)(blockIdx.x / HV) * (WSZ_ + (bias_row ? C : 0));
+    if (bias_row) {                                                // the four lane groups hold the sums of their own nodes
+        accb.x += __shfl_xor(accb.x, 16, 64); accb.y += __shfl_xor(accb.y, 16, 64); accb.z += __shfl_xor(accb.z, 16, 64); accb.w += __shfl_xor(accb.w, 16, 64);
+        accb.x += __shfl_xor(accb.x, 32, 64); accb.y += __shfl_xor(accb.y, 32, 64); accb.z += __shfl_xor(accb.z, 32, 64); accb.w += __shfl_xor(accb.w, 32, 64);
+    }
+    if (!act) return;
+    // accumulator register r of tile t: row u = 4 g + r, column i = channel cc + t
+#pragma unroll
+    for (int l = 0; l <= L; ++l) {
+        if (out_cu) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                *reinterpret_cast<float4*>(p + ((long long)l * C + cc + t) * 16 + 4 * g) = make_float4(acc[l][t][0], acc[l][t][1], acc[l][t][2], acc[l][t][3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<float4*>(p + ((long long)l * 16 + 4 * g + r) * C + cc) = make_float4(acc[l][0][r], acc[l][1][r], acc[l][2][r], acc[l][3][r]);
+        }
+    }
+    if (bias_row && g == 0) *reinterpret_cast<float4*>(p + WSZ_ + cc) = accb;
+}
+
 static inline int so3_skinny_npb(int N, int target_blocks) {
     int npb = (N + target_blocks - 1) / target_blocks;
     return npb < 8 ? 8 : npb;
@@ -2952,22 +3114,23 @@ __global__ void __launch_bounds__(64) rmsnorm_bwd_kernel(const float* __restrict
 //     forward   Y = X W^T     A = X  (RC)   B = W   (RC)
 //     d input   dX = dY W     A = dY (RC)   B = W   (output-contiguous)
 //     d weight  dW = dY^T X   A = dY (OC)   B = X   (OC), reduction over the edges, split over workgroups (partials)
-// Workgroup = 256 threads = 2 x 2 wavefronts, macro tile 128 x 128, wavefront tile 64 x 64 = 2 x 2 MFMA tiles (64
-// accumulator registers); K step 32 staged through LDS in [r][i] order for both operands, so that the fragment of k-pair
-// (r, r+1) is one ds_read_b32 per 32-row block (lane l reads [r + l/32][i0 + l%32]: conflict-free).  Reduction-contiguous
-// operands are transposed on the LDS write (row pitch 129 floats: the 32 lanes of a write group hit 32 banks);
-// output-contiguous ones are copied as float4 (pitch 132).  Global loads of step t+1 are issued before the 64 MFMAs of
-// step t and written to the other LDS buffer after them: one barrier per step.  Tiles are numbered so that the
-// workgroups of one XCD (blockIdx % 8) walk consecutive column tiles of the same row tile: its A rows stay in that L2.
+// Workgroup = 256 threads; macro tile 128 x 128 (2 x 2 wavefronts of 64 x 64 = 2 x 2 MFMA tiles, 64 accumulator registers)
+// or one of the smaller tiles listed at the kernel; K step 32, two LDS buffers, two register sets (the loads of step s + 2
+// are in flight during step s); LDS images and fragment reads as described in front of the kernel.  Tiles are numbered row
+// tile by row tile and, inside, problem by problem; every XCD (blockIdx % 8) takes a contiguous range of tile ids, so its
+// workgroups share the A rows of a row tile in that XCD's L2 and every XCD sees the same mix of problems.
 // Rows of A and C may be grouped (row i -> (i / group) * ld_group + (i % group) * ld): the (2l+1) coefficient rows of a
-// degree inside [N, K, C] node tensors.
+// degree inside [N, K, C] node tensors.  Epilogue options per problem: bias[j]; ReLU; zeroing where a second tensor of C's
+// layout is not positive (the gradient of a ReLU whose output was kept).
 struct GemmProb {
     const float* A;
     const float* B;
     float* C;
     const float* bias;
+    const float* mask;      // same layout as C (plain rows): C is zeroed where mask <= 0
+    const float* addend;    // same layout as C (plain rows): added to the product (after the bias, before the ReLU)
     long long lda, ldb, ldc, a_gld, b_gld, c_gld, c_split;
-    int I, J, R, a_group, b_group, c_group, tiles_j, tile_begin;
+    int I, J, R, a_group, b_group, c_group, tiles_j, tile_begin, relu;
 };
 struct GemmBatch {
     GemmProb p[SINGA_GEMM_MAX];
@@ -2976,7 +3139,9 @@ struct GemmBatch {
 };
 
 // CFG 0: macro tile 128 x 128 (2 x 2 wavefronts of 64 x 64); CFG 1: 128 x 32 (4 x 1 wavefronts of 32 x 32) for outputs with
-// few columns, CFG 2: 32 x 128 (1 x 4 wavefronts) for outputs with few rows (the 16-channel sides of SO3_LinearV2).
+// few columns, CFG 2: 32 x 128 (1 x 4 wavefronts) for outputs with few rows (the 16-channel sides of SO3_LinearV2); CFG 3:
+// 64 x 64 (2 x 2 wavefronts of 32 x 32) for launches whose 128 x 128 tiles would not fill the 256 CUs (the CProMG
+// transformer's 256-wide projections on a few thousand rows).
 //
 // LDS images, K step 32.  A reduction-contiguous operand keeps its global layout, [row][r] with a pitch of 36 floats: global
 // float4 -> ds_write_b128 with no transposition, and a lane's fragment for FOUR k-steps is ONE ds_read_b128 (row = lane % 32,
@@ -2989,7 +3154,7 @@ struct GemmBatch {
 // float4 rows - 4x fewer store instructions, full 256-byte row segments.
 template <bool A_RC, bool B_RC, int CFG>
 __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
-    constexpr int BM = CFG == 2 ? 32 : 128, BN = CFG == 0 ? 128 : (CFG == 1 ? 32 : 128), BK = 32, PR = BK + 4;
+    constexpr int BM = CFG == 2 ? 32 : (CFG == 3 ? 64 : 128), BN = CFG == 1 ? 32 : (CFG == 3 ? 64 : 128), BK = 32, PR = BK + 4;
     constexpr int MT = CFG == 0 ? 2 : 1, NT = CFG == 0 ? 2 : 1;   // 32 x 32 MFMA tiles per wavefront
     constexpr int NA = BM / 32, NB = BN / 32;                      // float4 loads per thread and K step
     constexpr int LDA = BM + 4, LDB = BN + 4;                      // pitches of the [r][col] images
@@ -3021,8 +3186,8 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
     const long long r_begin = (long long)split * gb.r_chunk;
     const long long r_end = (r_begin + gb.r_chunk < P.R) ? r_begin + gb.r_chunk : P.R;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wrow = CFG == 0 ? (wave >> 1) * 64 : (CFG == 1 ? wave * 32 : 0);     // the wavefront's block of the macro tile
-    const int wcol = CFG == 0 ? (wave & 1) * 64 : (CFG == 1 ? 0 : wave * 32);
+    const int wrow = CFG == 0 ? (wave >> 1) * 64 : (CFG == 1 ? wave * 32 : (CFG == 3 ? (wave >> 1) * 32 : 0));   // the wavefront's block
+    const int wcol = CFG == 0 ? (wave & 1) * 64 : (CFG == 1 ? 0 : (CFG == 3 ? (wave & 1) * 32 : wave * 32));
     const int l31 = lane & 31, half = lane >> 5;
     const int kq = tid & 7, rr = tid >> 3;                          // reduction-contiguous staging: float4 kq of row rr + 32 j
 
@@ -3263,13 +3428,407 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
                 v.x += bias4.x; v.y += bias4.y; v.z += bias4.z; v.w += bias4.w;
                 const long long row = P.c_group == (1 << 30) ? (long long)i * P.ldc
                                                              : (long long)(i / P.c_group) * P.c_gld + (long long)(i % P.c_group) * P.ldc;
+                if (P.addend) {
+                    const float4 ad = *reinterpret_cast<const float4*>(P.addend + row + jcol);
+                    v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+                }
+                if (P.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (P.mask) {
+                    const float4 m = *reinterpret_cast<const float4*>(P.mask + row + jcol);
+                    v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+                }
                 *reinterpret_cast<float4*>(Cb + row + jcol) = v;
             }
         }
     }
 }
 
+// ------------------------------------------------------------------------------------------------ n2: Laplacian eigenvectors
+// dgl.lap_pe / `lap_pe` of the reference (model/CProMG.py:562-571, called inside forward at model/GAN.py:71,77): the k
+// eigenvectors after the smallest of the normalised Laplacian I - D^-1/2 A D^-1/2 of every graph of the batch.  One workgroup
+// of 1024 threads per graph, fp64, on the dense symmetric matrix (n <= 1024 atoms: a few MB, cache resident):
+//   1. Householder tridiagonalisation in place.  Full symmetric storage, so that "column r" is read as the contiguous row r;
+//      the rank-2 update of step j and the matrix-vector product of step j + 1 are ONE pass over the trailing block (the row
+//      that defines reflector j + 1 is updated first): 16 bytes of traffic per trailing element and step, 16/3 n^3 in all.
+//      Reflector j stays in row j right of the diagonal (v[j + 1] = 1 implied ... stored), its factor in beta[j].
+//   2. the k + 1 smallest eigenvalues of the tridiagonal matrix by multi-section on the Sturm count (64 shifts per
+//      eigenvalue and round, 9 rounds: 64^9 > 2^53),
+//   3. their eigenvectors by inverse iteration (tridiagonal LU with partial pivoting, one lane per vector), with
+//      Gram-Schmidt inside clusters of close eigenvalues - a bonded pocket graph has dozens of connected components, i.e.
+//      a many-fold zero eigenvalue: any orthonormal basis of the invariant subspace is as good as the reference's (dgl draws
+//      random signs on top) -
+//   4. back-transformation through the reflectors, sign convention (entry of largest magnitude positive), fp32 output.
+#ifndef SINGA_EMUL      // (workgroup-cooperative: not part of the sequential CPU emulation build of tests/emul)
+template <int NQ>
+__global__ void __launch_bounds__(1024) lap_eig_kernel(double* __restrict__ Aall, const int* __restrict__ nnodes, const int* __restrict__ first,
+                                                       double* __restrict__ work, float* __restrict__ out, int ld, int kout) {
+    constexpr int NW = 16, KV = 9;                                 // wavefronts per workgroup; vectors computed (k + 1 <= 9)
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = nnodes[g];
+    if (n <= 0) return;
+    double* A = Aall + (long long)g * ld * ld;
+    const int sl = ld < 32 ? 32 : ld;     // stride of the LDS arrays (the Sturm counts need 16 * sl >= 306 doubles)
+    double* va = sm;                      // [sl] reflector of the current step
+    double* wa = sm + sl;                 // [sl]
+    double* vb = sm + 2 * sl;             // [sl] reflector of the next step
+    double* wb = sm + 3 * sl;             // [sl]
+    double* pw = sm + 4 * sl;             // [NW][sl] per-wavefront partial products; later the vectors Z [KV][sl]
+    double* red = sm + (4 + NW) * sl;     // [NW + 8] reduction scratch / broadcast scalars
+    double* dd = work + (long long)g * (3 + 4 * KV) * ld;          // diagonal
+    double* ee = dd + ld;                                          // off-diagonal
+    double* bb = ee + ld;                                          // reflector factors
+    double* lu = bb + ld;                                          // [KV][4][ld] scratch of the tridiagonal solves
+
+    auto block_sum = [&](double x) -> double {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        __syncthreads();
+        if (lane == 0) red[wave] = x;
+        __syncthreads();
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += red[w];
+        return s;
+    };
+    // reflector from row `row` (columns row + 1 .. n - 1) -> vec[] (entries <= row are zero), d / e / beta of that row
+    auto reflector = [&](int row, double* vec) {
+        double x = 0.0, sq = 0.0;
+        if (tid < n) {
+            x = tid > row ? A[(long long)row * ld + tid] : 0.0;
+            if (tid > row + 1) sq = x * x;
+        }
+        const double sigma = block_sum(sq);
+        if (tid == row + 1) red[NW] = x;
+        __syncthreads();
+        const double alpha = red[NW];
+        double b = 0.0, mu = alpha, v0 = 1.0;
+        if (sigma != 0.0) {
+            mu = sqrt(alpha * alpha + sigma);
+            v0 = alpha <= 0.0 ? alpha - mu : -sigma / (alpha + mu);
+            b = 2.0 * v0 * v0 / (sigma + v0 * v0);
+        }
+        if (tid < n) {
+            double v = 0.0;
+            if (tid == row + 1) v = 1.0;
+            else if (tid > row + 1) v = sigma != 0.0 ? x / v0 : 0.0;
+            vec[tid] = v;
+            if (tid > row) A[(long long)row * ld + tid] = v;       // the reflector replaces the row it came from
+        }
+        if (tid == 0) {
+            dd[row] = A[(long long)row * ld + row];
+            ee[row] = mu;
+            bb[row] = b;
+            red[NW + 1] = b;
+        }
+        __syncthreads();
+        return red[NW + 1];
+    };
+    // one pass over the trailing block rows / columns >= lo: a -= vu[c] wu[r] + wu[c] vu[r] (if upd), then p[r] += a vn[c]
+    // (if acc); the wave partials of p end up in pw
+    auto pass = [&](int lo, bool upd, const double* vu, const double* wu, bool acc, const double* vn) {
+        // the lane's own entries of the update vectors: registers for graphs of up to 512 nodes, LDS reads beyond (1024
+        // threads leave 128 registers per lane)
+        constexpr int NR = NQ <= 8 ? NQ : 1;
+        double pacc[NQ], vr[NR], wr[NR];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) pacc[q] = 0.0;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const int r = lo + lane + 64 * q;
+            vr[q] = (upd && r < n) ? vu[r] : 0.0;
+            wr[q] = (upd && r < n) ? wu[r] : 0.0;
+        }
+        for (int c = lo + wave; c < n; c += NW) {
+            const double vc = upd ? vu[c] : 0.0, wc = upd ? wu[c] : 0.0, nc = acc ? vn[c] : 0.0;
+            double* row = A + (long long)c * ld;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int r = lo + lane + 64 * q;
+                if (r < n) {
+                    double a = row[r];
+                    if (upd) {
+                        if constexpr (NQ <= 8) a -= vc * wr[q] + wc * vr[q];
+                        else a -= vc * wu[r] + wc * vu[r];
+                        row[r] = a;
+                    }
+                    pacc[q] += a * nc;
+                }
+            }
+        }
+        if (acc) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const int r = lo + lane + 64 * q;
+                if (r < n) pw[wave * sl + r] = pacc[q];
+            }
+        }
+        __syncthreads();
+    };
+    // w = b p - (b / 2) (b p . v) v with p = sum of the wave partials (entries >= lo)
+    auto finish_w = [&](int lo, double b, const double* vec, double* wout) {
+        double p = 0.0, pv = 0.0;
+        if (tid >= lo && tid < n) {
+#pragma unroll
+            for (int w = 0; w < NW; ++w) p += pw[w * sl + tid];
+            p *= b;
+            pv = p * vec[tid];
+        }
+        const double gam = 0.5 * b * block_sum(pv);
+        if (tid < n) wout[tid] = (tid >= lo) ? p - gam * vec[tid] : 0.0;
+        __syncthreads();
+    };
+
+    // ---- 1. tridiagonalisation
+    if (n >= 3) {
+        double b = reflector(0, vb);
+        pass(1, false, nullptr, nullptr, true, vb);
+        finish_w(1, b, vb, wb);
+        for (int j = 0; j + 2 < n; ++j) {
+            double* t = va; va = vb; vb = t;
+            t = wa; wa = wb; wb = t;
+            const int row = j + 1;
+            // row j + 1 gets its update first: it defines the next reflector
+            if (tid >= row && tid < n) A[(long long)row * ld + tid] -= va[row] * wa[tid] + wa[row] * va[tid];
+            __syncthreads();
+            const bool more = row + 2 < n;
+            double bn = 0.0;
+            if (more) bn = reflector(row, vb);
+            pass(row + 1, true, va, wa, more, vb);
+            if (more) finish_w(row + 1, bn, vb, wb);
+        }
+    }
+    if (tid == 0) {
+        if (n >= 2) {
+            dd[n - 2] = A[(long long)(n - 2) * ld + n - 2];
+            ee[n - 2] = A[(long long)(n - 2) * ld + n - 1];
+        }
+        dd[n - 1] = A[(long long)(n - 1) * ld + n - 1];
+        if (n >= 2) ee[n - 1] = 0.0;
+    }
+    __syncthreads();
+    // ---- 2. eigenvalues 0 .. m - 1 of the tridiagonal matrix (d, e): multi-section on the Sturm count
+    const int m = n < KV ? n : KV;
+    double* td = va;                       // diagonal and squared off-diagonal in LDS
+    double* te2 = wa;
+    double* lam = wb;                      // [KV]
+    double gl = 0.0, gu = 0.0;
+    if (tid < n) {
+        const double d = dd[tid], el = tid > 0 ? fabs(ee[tid - 1]) : 0.0, er = tid + 1 < n ? fabs(ee[tid]) : 0.0;
+        td[tid] = d;
+        te2[tid] = tid + 1 < n ? ee[tid] * ee[tid] : 0.0;
+        gl = d - el - er;
+        gu = d + el + er;
+    }
+    {   // Gershgorin bounds (block min / max through the sum helper's scratch)
+        double lo = tid < n ? gl : 1e300, hi = tid < n ? gu : -1e300;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fmin(lo, __shfl_xor(lo, o, 64));
+            hi = fmax(hi, __shfl_xor(hi, o, 64));
+        }
+        __syncthreads();
+        if (lane == 0) pw[wave] = lo, pw[NW + wave] = hi;
+        __syncthreads();
+        lo = pw[0], hi = pw[NW];
+        for (int w = 1; w < NW; ++w) lo = fmin(lo, pw[w]), hi = fmax(hi, pw[NW + w]);
+        __syncthreads();
+        const double span = hi - lo + 1e-300;
+        if (tid < KV) pw[tid] = lo - 1e-12 * span - 1e-300, pw[KV + tid] = hi + 1e-12 * span + 1e-300;   // [lo_k | hi_k]
+        __syncthreads();
+    }
+    {
+        constexpr int P = 64;
+        const int ke = tid / P, pi = tid % P;              // eigenvalue index and shift index of this thread
+        int* cnt = reinterpret_cast<int*>(pw + 2 * KV);    // [KV][P] Sturm counts
+        for (int round = 0; round < 10; ++round) {
+            double x = 0.0;
+            if (ke < m) {
+                const double lo = pw[ke], hi = pw[KV + ke];
+                x = lo + (hi - lo) * (double)(pi + 1) / (double)(P + 1);
+                int c = 0;
+                double q = 1.0;
+                for (int i = 0; i < n; ++i) {
+                    q = td[i] - x - (i > 0 ? te2[i - 1] / q : 0.0);
+                    if (fabs(q) < 1e-300) q = -1e-300;
+                    c += q < 0.0;
+                }
+                cnt[ke * P + pi] = c;
+            }
+            __syncthreads();
+            double nlo = 0.0, nhi = 0.0;
+            bool setlo = false, sethi = false;
+            if (ke < m) {
+                // eigenvalue ke lies in (x_{i-1}, x_i] for the first shift i with count > ke
+                const int c = cnt[ke * P + pi];
+                const int cp = pi > 0 ? cnt[ke * P + pi - 1] : -1;
+                const int cn = pi + 1 < P ? cnt[ke * P + pi + 1] : 1 << 30;
+                if (c > ke && cp <= ke) sethi = true, nhi = x;
+                if (c <= ke && cn > ke) setlo = true, nlo = x;
+            }
+            __syncthreads();
+            if (sethi) pw[KV + ke] = nhi;
+            if (setlo) pw[ke] = nlo;
+            __syncthreads();
+        }
+        if (tid < m) lam[tid] = 0.5 * (pw[tid] + pw[KV + tid]);
+        __syncthreads();
+    }
+    // ---- 3. inverse iteration, one lane per vector; Z[k] in LDS (pw region)
+    double tnorm = 0.0;
+    {
+        double t = tid < n ? fmax(fabs(td[tid]), sqrt(te2[tid])) : 0.0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t = fmax(t, __shfl_xor(t, o, 64));
+        __syncthreads();
+        if (lane == 0) vb[wave] = t;
+        __syncthreads();
+        for (int w = 0; w < NW; ++w) tnorm = fmax(tnorm, vb[w]);
+        __syncthreads();
+    }
+    const double eps = 2.220446049250313e-16, tiny = eps * (tnorm > 0.0 ? tnorm : 1.0);
+    double* Z = pw;                         // [KV][ld] (the eigenvalue intervals / counts kept there are dead now)
+    if (tid < m) vb[tid] = lam[tid];         // shifts; separated inside clusters below (LAPACK dstein does the same)
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < m; ++k) {
+            const double sep = 10.0 * eps * fmax(fabs(vb[k]), tnorm);
+            if (vb[k] - vb[k - 1] < sep) vb[k] = vb[k - 1] + sep;
+        }
+    }
+    __syncthreads();
+    for (int r = tid; r < m * sl; r += 1024) {
+        const int k = r / sl, i = r - k * sl;
+        // deterministic start vectors in (-1, 1)
+        unsigned h = (unsigned)(i * 2654435761u) ^ (unsigned)((k + 1) * 40503u * 2246822519u);
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        Z[r] = i < n ? ((double)(h & 0xFFFFFF) / 8388608.0 - 1.0) : 0.0;
+    }
+    __syncthreads();
+    for (int it = 0; it < 5; ++it) {
+        if (tid < m) {
+            const int k = tid;
+            const double shift = vb[k];
+            double* dl = lu + (long long)(k * 4 + 0) * ld;      // sub-diagonal (multipliers after elimination are not kept)
+            double* dg = lu + (long long)(k * 4 + 1) * ld;      // diagonal
+            double* du = lu + (long long)(k * 4 + 2) * ld;      // first super-diagonal
+            double* d2 = lu + (long long)(k * 4 + 3) * ld;      // second super-diagonal (pivoting fill-in)
+            double* x = Z + k * sl;
+            for (int i = 0; i < n; ++i) {
+                dg[i] = td[i] - shift;
+                const double e = i + 1 < n ? ee[i] : 0.0;
+                dl[i] = e, du[i] = e, d2[i] = 0.0;
+            }
+            for (int i = 0; i + 1 < n; ++i) {
+                if (fabs(dg[i]) >= fabs(dl[i])) {
+                    if (dg[i] == 0.0) dg[i] = tiny;
+                    const double f = dl[i] / dg[i];
+                    dg[i + 1] -= f * du[i];
+                    x[i + 1] -= f * x[i];
+                    if (i + 2 < n) d2[i] = 0.0;
+                } else {
+                    const double f = dg[i] / dl[i];
+                    dg[i] = dl[i];
+                    const double t = dg[i + 1];
+                    dg[i + 1] = du[i] - f * t;
+                    if (i + 2 < n) {
+                        d2[i] = du[i + 1];
+                        du[i + 1] = -f * du[i + 1];
+                    }
+                    du[i] = t;
+                    const double xi = x[i];
+                    x[i] = x[i + 1];
+                    x[i + 1] = xi - f * x[i + 1];
+                }
+            }
+            if (dg[n - 1] == 0.0) dg[n - 1] = tiny;
+            x[n - 1] /= dg[n - 1];
+            if (n > 1) x[n - 2] = (x[n - 2] - du[n - 2] * x[n - 1]) / dg[n - 2];
+            for (int i = n - 3; i >= 0; --i) x[i] = (x[i] - du[i] * x[i + 1] - d2[i] * x[i + 2]) / dg[i];
+            // scale against overflow before the dot products
+            double mx = 0.0;
+            for (int i = 0; i < n; ++i) mx = fmax(mx, fabs(x[i]));
+            const double sc = mx > 0.0 ? 1.0 / mx : 1.0;
+            for (int i = 0; i < n; ++i) x[i] *= sc;
+        }
+        __syncthreads();
+        // Gram-Schmidt inside clusters (in eigenvalue order) + normalisation, all threads
+        for (int k = 0; k < m; ++k) {
+            double* x = Z + k * sl;
+            for (int j = 0; j < k; ++j) {
+                if (fabs(lam[k] - lam[j]) < 1e-3 * (tnorm > 0.0 ? tnorm : 1.0)) {
+                    const double* y = Z + j * sl;
+                    const double dot = block_sum(tid < n ? x[tid] * y[tid] : 0.0);
+                    if (tid < n) x[tid] -= dot * y[tid];
+                    __syncthreads();
+                }
+            }
+            const double nn = block_sum(tid < n ? x[tid] * x[tid] : 0.0);
+            if (tid < n) x[tid] *= nn > 0.0 ? rsqrt(nn) : 0.0;
+            __syncthreads();
+        }
+    }
+    // ---- 4. back-transformation x = H_0 H_1 .. H_{n-3} y: one wavefront per vector, reflectors from the matrix rows
+    if (n >= 3 && wave < m) {
+        double* x = Z + wave * sl;
+        for (int j = n - 3; j >= 0; --j) {
+            const double b = bb[j];
+            if (b == 0.0) continue;
+            const double* v = A + (long long)j * ld;
+            double s = 0.0;
+            for (int r = j + 1 + lane; r < n; r += 64) s += v[r] * x[r];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            s *= b;
+            for (int r = j + 1 + lane; r < n; r += 64) x[r] -= s * v[r];
+        }
+    }
+    __syncthreads();
+    // sign convention + output: columns 1 .. kout of the spectrum (the smallest eigenvalue's vector is dropped)
+    float* o = out + (long long)first[g] * kout;
+    for (int k = 1; k <= kout; ++k) {
+        if (k >= m) {
+            if (tid < n) o[(long long)tid * kout + k - 1] = 0.f;
+            continue;
+        }
+        const double* x = Z + k * sl;
+        // entry of largest magnitude (first one on ties): value packed with its index for a max reduction
+        double best = tid < n ? fabs(x[tid]) : -1.0;
+        int bi = tid;
+#pragma unroll
+        for (int oo = 32; oo > 0; oo >>= 1) {
+            const double ob = __shfl_xor(best, oo, 64);
+            const int oi = __shfl_xor(bi, oo, 64);
+            if (ob > best || (ob == best && oi < bi)) best = ob, bi = oi;
+        }
+        __syncthreads();
+        if (lane == 0) red[wave] = best, reinterpret_cast<int*>(red + NW)[wave] = bi;
+        __syncthreads();
+        best = red[0], bi = reinterpret_cast<int*>(red + NW)[0];
+        for (int w = 1; w < NW; ++w) {
+            const double ob = red[w];
+            const int oi = reinterpret_cast<int*>(red + NW)[w];
+            if (ob > best || (ob == best && oi < bi)) best = ob, bi = oi;
+        }
+        const double sg = x[bi] < 0.0 ? -1.0 : 1.0;
+        if (tid < n) o[(long long)tid * kout + k - 1] = (float)(sg * x[tid]);
+        __syncthreads();
+    }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------ host helpers
+bool attn_pitch(int token_major, int heads, long long lq, long long lk, long long lv, const float* q, const float* k, const float* v,
+                AttnPitch* out) {
+    out->q = (int)(lq > 0 ? lq : heads * 32);
+    out->k = (int)(lk > 0 ? lk : heads * 32);
+    out->v = (int)(lv > 0 ? lv : heads * 64);
+    if (!token_major) return lq <= 0 && lk <= 0 && lv <= 0;
+    if (lq > (1 << 30) || lk > (1 << 30) || lv > (1 << 30)) return false;
+    if (out->q % 4 || out->k % 4 || out->v % 4 || out->q < heads * 32 || out->k < heads * 32 || out->v < heads * 64) return false;
+    return !(((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15));
+}
+
 int grid_for(long long work, int cap = 256 * 32) {
     long long g = work < 1 ? 1 : work;
     return (int)(g > cap ? cap : g);
@@ -3786,16 +4345,31 @@ int singa_so3_skinny_nparts(int N, int lmax, int C) {
         }                                                                                  \
     } while (0)
 
+static int g_skinny_valu = 0;       // tests / lab: 1 = the VALU (lane-broadcast) kernels instead of the MFMA ones
+int singa_so3_skinny_variant(int valu) {
+    g_skinny_valu = valu ? 1 : 0;
+    return SINGA_OK;
+}
+
 int singa_so3_skinny_expand(const float* small, const float* W, long long w_l, long long w_c, long long w_u, const float* bias,
                             float* big, int N, int C, int lmax, void* stream) {
     if (!small || !W || !big) return fail(SINGA_E_NULL, "so3_skinny_expand: null pointer");
     if (!so3_skinny_channels_ok(C)) return fail(SINGA_E_SHAPE, "so3_skinny: built for 512 and 112 wide channels");
+    if (((uintptr_t)small & 15) || ((uintptr_t)big & 15) || (bias && ((uintptr_t)bias & 15)))
+        return fail(SINGA_E_SHAPE, "so3_skinny_expand: 16-byte aligned tensors");
     if (N <= 0) return SINGA_OK;
-    const int npb = so3_skinny_npb(N, 1536);
     hipStream_t st = (hipStream_t)stream;
-    SINGA_SKINNY_LC(lmax, C, hipLaunchKernelGGL((so3_skinny_expand_kernel<L_, C_>),
-                                                dim3((unsigned)(SkinnyCfg<C_>::HALVES * ((N + npb - 1) / npb))),
-                                                dim3(SkinnyCfg<C_>::BLOCK), 0, st, small, W, w_l, w_c, w_u, bias, big, N, npb));
+    if (g_skinny_valu) {
+        const int npb = so3_skinny_npb(N, 1536);
+        SINGA_SKINNY_LC(lmax, C, hipLaunchKernelGGL((so3_skinny_expand_kernel<L_, C_>),
+                                                    dim3((unsigned)(SkinnyCfg<C_>::HALVES * ((N + npb - 1) / npb))),
+                                                    dim3(SkinnyCfg<C_>::BLOCK), 0, st, small, W, w_l, w_c, w_u, bias, big, N, npb));
+    } else {
+        const int npb = (so3_skinny_npb(N, 2048) + 15) / 16 * 16;      // runs of whole 16-node tiles
+        SINGA_SKINNY_LC(lmax, C, hipLaunchKernelGGL((so3_skinny_expand_mfma_kernel<L_, C_>),
+                                                    dim3((unsigned)(SkinnyCfg<C_>::HALVES * ((N + npb - 1) / npb))),
+                                                    dim3(SkinnyCfg<C_>::BLOCK), 0, st, small, W, w_l, w_c, w_u, bias, big, N, npb));
+    }
     return check_launch("so3_skinny_expand");
 }
 
@@ -3807,10 +4381,44 @@ int singa_so3_skinny_reduce(const float* small, const float* big, float* part, i
     const int runs = C == 512 ? so3_skinny_reduce_runs<512>(lmax) : so3_skinny_reduce_runs<112>(lmax);
     const int npb = so3_skinny_npb(N, runs);
     hipStream_t st = (hipStream_t)stream;
-    SINGA_SKINNY_LC(lmax, C, hipLaunchKernelGGL((so3_skinny_reduce_kernel<L_, C_>),
-                                                dim3((unsigned)(SkinnyCfg<C_>::HALVES * ((N + npb - 1) / npb))),
-                                                dim3(SkinnyCfg<C_>::BLOCK), 0, st, small, big, part, N, npb, out_cu, bias_row));
+    if (((uintptr_t)small & 15) || ((uintptr_t)big & 15) || ((uintptr_t)part & 15))
+        return fail(SINGA_E_SHAPE, "so3_skinny_reduce: 16-byte aligned tensors");
+    if (g_skinny_valu)
+        SINGA_SKINNY_LC(lmax, C, hipLaunchKernelGGL((so3_skinny_reduce_kernel<L_, C_>),
+                                                    dim3((unsigned)(SkinnyCfg<C_>::HALVES * ((N + npb - 1) / npb))),
+                                                    dim3(SkinnyCfg<C_>::BLOCK), 0, st, small, big, part, N, npb, out_cu, bias_row));
+    else
+        SINGA_SKINNY_LC(lmax, C, hipLaunchKernelGGL((so3_skinny_reduce_mfma_kernel<L_, C_>),
+                                                    dim3((unsigned)(SkinnyCfg<C_>::HALVES * ((N + npb - 1) / npb))),
+                                                    dim3(SkinnyCfg<C_>::BLOCK), 0, st, small, big, part, N, npb, out_cu, bias_row));
     return check_launch("so3_skinny_reduce");
+}
+
+int singa_lap_eig_work(int B, int ld) { return (B < 0 || ld < 0) ? 0 : B * (3 + 4 * 9) * ld; }
+
+int singa_lap_eig(double* A, const int32_t* nnodes, const int32_t* first, double* work, float* out, int B, int ld, int kout,
+                  void* stream) {
+    if (!A || !nnodes || !first || !work || !out) return fail(SINGA_E_NULL, "lap_eig: null pointer");
+    if (kout < 1 || kout > 8) return fail(SINGA_E_SHAPE, "lap_eig: 1..8 eigenvectors");
+    if (ld < 1 || ld > 1016) return fail(SINGA_E_SHAPE, "lap_eig: graphs of up to 1016 nodes (20 vectors of LDS per graph)");
+    if (B <= 0) return SINGA_OK;
+#ifdef SINGA_EMUL
+    return fail(SINGA_E_SHAPE, "lap_eig: not part of the emulation build");
+#else
+    const size_t lds = (size_t)((4 + 16) * (ld < 32 ? 32 : ld) + 16 + 8) * sizeof(double);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e;
+    if (ld <= 512) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_eig_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail((int)e, "lap_eig: LDS size refused");
+        hipLaunchKernelGGL(lap_eig_kernel<8>, dim3(B), dim3(1024), lds, st, A, nnodes, first, work, out, ld, kout);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_eig_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail((int)e, "lap_eig: LDS size refused");
+        hipLaunchKernelGGL(lap_eig_kernel<16>, dim3(B), dim3(1024), lds, st, A, nnodes, first, work, out, ld, kout);
+    }
+    return check_launch("lap_eig");
+#endif
 }
 
 int singa_adam_step(float* const* p, const float* const* g, float* const* m, float* const* v, const long long* sizes,
@@ -3839,11 +4447,20 @@ int singa_gemm_occupancy(int a_r_contig, int b_r_contig, int cfg) {
     int n = -1;
     hipError_t e = hipErrorInvalidValue;
 #define SINGA_OCC(ARC, BRC, CFG) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_f32_kernel<ARC, BRC, CFG>, 256, 0)
-    if (a_r_contig && b_r_contig) { if (cfg == 0) SINGA_OCC(true, true, 0); else if (cfg == 1) SINGA_OCC(true, true, 1); else SINGA_OCC(true, true, 2); }
-    else if (a_r_contig) { if (cfg == 0) SINGA_OCC(true, false, 0); else if (cfg == 1) SINGA_OCC(true, false, 1); else SINGA_OCC(true, false, 2); }
-    else { if (cfg == 0) SINGA_OCC(false, false, 0); else if (cfg == 1) SINGA_OCC(false, false, 1); else SINGA_OCC(false, false, 2); }
+#define SINGA_OCC4(ARC, BRC) do { if (cfg == 0) SINGA_OCC(ARC, BRC, 0); else if (cfg == 1) SINGA_OCC(ARC, BRC, 1); else if (cfg == 2) SINGA_OCC(ARC, BRC, 2); else SINGA_OCC(ARC, BRC, 3); } while (0)
+    if (a_r_contig && b_r_contig) SINGA_OCC4(true, true);
+    else if (a_r_contig) SINGA_OCC4(true, false);
+    else SINGA_OCC4(false, false);
+#undef SINGA_OCC4
 #undef SINGA_OCC
     return e == hipSuccess ? n : -(int)e;
+}
+
+static int g_gemm_force_cfg = -1;
+int singa_gemm_force_cfg(int cfg) {
+    if (cfg < -1 || cfg > 3) return fail(SINGA_E_SHAPE, "gemm_force_cfg: -1 (automatic), 0 (128x128) or 3 (64x64)");
+    g_gemm_force_cfg = cfg;
+    return SINGA_OK;
 }
 
 int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_contig, int splits, void* stream) {
@@ -3859,9 +4476,16 @@ int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_con
     for (int k = 0; k < n; ++k) jmax = probs[k].J > jmax ? probs[k].J : jmax;
     int imax = 0;
     for (int k = 0; k < n; ++k) imax = probs[k].I > imax ? probs[k].I : imax;
-    // 128 x 32 tiles for outputs with at most 32 columns, 32 x 128 for outputs with at most 32 rows, else 128 x 128
-    const int cfg = jmax <= 32 ? 1 : (imax <= 32 ? 2 : 0);
-    const int BM = cfg == 2 ? 32 : 128, BN = cfg == 1 ? 32 : 128;
+    // 128 x 32 tiles for outputs with at most 32 columns, 32 x 128 for outputs with at most 32 rows; else 128 x 128 - unless
+    // those would leave most of the 256 CUs (two workgroups each) without a tile: then 64 x 64
+    int cfg = jmax <= 32 ? 1 : (imax <= 32 ? 2 : 0);
+    if (cfg == 0) {
+        long long t128 = 0;
+        for (int k = 0; k < n; ++k) t128 += (long long)((probs[k].I + 127) / 128) * ((probs[k].J + 127) / 128);
+        if (t128 * splits < 384) cfg = 3;
+        if (g_gemm_force_cfg == 0 || g_gemm_force_cfg == 3) cfg = g_gemm_force_cfg;      // tests: both tile shapes on every case
+    }
+    const int BM = cfg == 2 ? 32 : (cfg == 3 ? 64 : 128), BN = cfg == 1 ? 32 : (cfg == 3 ? 64 : 128);
     int tj_total = 0, ti_max = 0, tiles_seq = 0;
     bool same_rows = true;
     for (int k = 1; k < n; ++k) same_rows = same_rows && probs[k].I == probs[0].I;
@@ -3881,9 +4505,12 @@ int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_con
         if (q.J % 4 || q.ldc % 4 || q.c_group_ld % 4 || q.c_split_stride % 4 || ((uintptr_t)q.c & 15) ||
             (q.bias && ((uintptr_t)q.bias & 15)))
             return fail(SINGA_E_SHAPE, "gemm_f32: the result's columns, pitches and base must be multiples of 4 floats / 16 bytes");
-        if (splits > 1 && (q.c_group > 0 || q.ldc != q.J || q.bias || q.c_split_stride < (long long)q.I * q.J))
-            return fail(SINGA_E_SHAPE, "gemm_f32: split reductions write dense [I, J] partial slabs (c_split_stride apart), no bias");
-        P.A = q.a; P.B = q.b; P.C = q.c; P.bias = q.bias;
+        if (splits > 1 && (q.c_group > 0 || q.ldc != q.J || q.bias || q.mask || q.addend || q.relu ||
+                           q.c_split_stride < (long long)q.I * q.J))
+            return fail(SINGA_E_SHAPE, "gemm_f32: split reductions write dense [I, J] partial slabs (c_split_stride apart), no epilogue options");
+        if ((q.mask || q.addend) && (q.c_group > 0 || ((uintptr_t)q.mask & 15) || ((uintptr_t)q.addend & 15)))
+            return fail(SINGA_E_SHAPE, "gemm_f32: mask / addend have the result's plain-row layout and are 16-byte aligned");
+        P.A = q.a; P.B = q.b; P.C = q.c; P.bias = q.bias; P.mask = q.mask; P.addend = q.addend; P.relu = q.relu;
         P.lda = q.lda; P.ldb = q.ldb; P.ldc = q.ldc;
         P.a_group = q.a_group > 0 ? q.a_group : (1 << 30);
         P.b_group = q.b_group > 0 ? q.b_group : (1 << 30);
@@ -3915,6 +4542,7 @@ int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_con
     do {                                                                                                    \
         if (cfg == 1) SINGA_LAUNCH(tag, 0, tiles, (gemm_f32_kernel<ARC, BRC, 1>), grid, block, st, gb);     \
         else if (cfg == 2) SINGA_LAUNCH(tag, 0, tiles, (gemm_f32_kernel<ARC, BRC, 2>), grid, block, st, gb); \
+        else if (cfg == 3) SINGA_LAUNCH(tag, 0, tiles, (gemm_f32_kernel<ARC, BRC, 3>), grid, block, st, gb); \
         else SINGA_LAUNCH(tag, 0, tiles, (gemm_f32_kernel<ARC, BRC, 0>), grid, block, st, gb);              \
     } while (0)
     if (a_r_contig && b_r_contig) SINGA_GEMM_GO(SINGA_PROF_GEMM_NT, true, true);
@@ -4118,31 +4746,36 @@ int singa_masked_softmax_bwd(const float* p, const float* gp, const unsigned cha
 
 int singa_attn_fwd(const float* q, const float* k, const float* v, const unsigned char* mask, long long mask_stride_b,
                    long long mask_stride_t, float* ctx, float* lse, int BH, int T, int S, int heads, int DK, int DV,
-                   int token_major, float scale, void* stream) {
+                   int token_major, long long ld_q, long long ld_k, long long ld_v, float scale, void* stream) {
     if (!q || !k || !v || !mask || !ctx || !lse) return fail(SINGA_E_NULL, "attn_fwd: null pointer");
     if (DK != 32 || DV != 64) return fail(SINGA_E_SHAPE, "attn: built for 32 key / 64 value channels per head");
     if (heads <= 0 || BH % heads) return fail(SINGA_E_SHAPE, "attn: BH must be batch x heads");
     if (BH <= 0 || T <= 0 || S <= 0) return SINGA_OK;
+    AttnPitch ld;
+    if (!attn_pitch(token_major, heads, ld_q, ld_k, ld_v, q, k, v, &ld)) return fail(SINGA_E_SHAPE, "attn: token pitches must be multiples of 4 floats, at least heads * D, 16-byte aligned bases");
     const long long waves = (long long)BH * ((T + 31) / 32);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(((waves + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, q, k, v, mask,
-                       mask_stride_b, mask_stride_t, ctx, lse, BH, T, S, heads, token_major ? 1 : 0, scale);
+                       mask_stride_b, mask_stride_t, ctx, lse, BH, T, S, heads, token_major ? 1 : 0, scale, ld);
     return check_launch("attn_fwd");
 }
 
 int singa_attn_bwd(const float* q, const float* k, const float* v, const unsigned char* mask, long long mask_stride_b,
                    long long mask_stride_t, const float* ctx, const float* lse, const float* g_ctx, float* g_q, float* g_k,
-                   float* g_v, float* dsum, int BH, int T, int S, int heads, int DK, int DV, int token_major, float scale,
-                   void* stream) {
+                   float* g_v, float* dsum, int BH, int T, int S, int heads, int DK, int DV, int token_major, long long ld_q,
+                   long long ld_k, long long ld_v, float scale, void* stream) {
     if (!q || !k || !v || !mask || !ctx || !lse || !g_ctx || !g_q || !g_k || !g_v || !dsum)
         return fail(SINGA_E_NULL, "attn_bwd: null pointer");
     if (DK != 32 || DV != 64) return fail(SINGA_E_SHAPE, "attn: built for 32 key / 64 value channels per head");
     if (heads <= 0 || BH % heads) return fail(SINGA_E_SHAPE, "attn: BH must be batch x heads");
     if (BH <= 0 || T <= 0 || S <= 0) return SINGA_OK;
+    AttnPitch ld;
+    if (!attn_pitch(token_major, heads, ld_q, ld_k, ld_v, q, k, v, &ld) || ((uintptr_t)g_q & 15) || ((uintptr_t)g_k & 15) || ((uintptr_t)g_v & 15))
+        return fail(SINGA_E_SHAPE, "attn: token pitches must be multiples of 4 floats, at least heads * D, 16-byte aligned bases");
     const long long wq = (long long)BH * ((T + 31) / 32), wk = (long long)BH * ((S + 31) / 32);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(((wq + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, q, k, v, mask,
-                       mask_stride_b, mask_stride_t, ctx, lse, g_ctx, g_q, dsum, BH, T, S, heads, token_major ? 1 : 0, scale);
+                       mask_stride_b, mask_stride_t, ctx, lse, g_ctx, g_q, dsum, BH, T, S, heads, token_major ? 1 : 0, scale, ld);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)(((wk + 3) / 4 + 7) / 8 * 8)), dim3(256), 0, (hipStream_t)stream, q, k, v, mask,
-                       mask_stride_b, mask_stride_t, lse, dsum, g_ctx, g_k, g_v, BH, T, S, heads, token_major ? 1 : 0, scale);
+                       mask_stride_b, mask_stride_t, lse, dsum, g_ctx, g_k, g_v, BH, T, S, heads, token_major ? 1 : 0, scale, ld);
     return check_launch("attn_bwd");
 }
 

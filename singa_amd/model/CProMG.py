@@ -232,14 +232,16 @@ class MultiHeadAttention(nn.Module):
         else:                                    # other widths: the same two MLPs as library GEMMs + the k15d kernel
             W_k = self._edge_mlp(self.weight_k_net, edges.attr)
             W_v = self._edge_mlp(self.weight_v_net, edges.attr)
-        qp = ops.linear(h_queries, self.weight_k_lin.weight.t())                 # (q W)[n,h,:]
-        cterm = ops.rowdot_bias(h_queries, self.weight_k_lin.bias) * scale
+        qp = ops.linear_nn(h_queries, self.weight_k_lin.weight)                  # (q W)[n,h,:]
+        cterm = ops.rowdot_bias(h_queries, self.weight_k_lin.bias, scale)
         qk_ij = ops.edge_logits(qp, W_k, h_keys, cterm, edges, scale)
         alpha = ops.segment_softmax(qk_ij, edges.row_ptr, 0.0)
         S = ops.gather_wsum(alpha, W_v, h_values, edges)                         # [N, heads, 64]
         aggr_msg = ops.linear(S, self.weight_v_lin.weight, self.weight_v_lin.bias).view(N, -1)
-        out = self.centroid_lin(node_attr) + aggr_msg
-        return ops.layer_norm_residual(self.out_transform(self.act(out)), None, self.layer_norm)
+        # centroid_lin(node_attr) + aggr_msg, then ShiftedSoftplus (CP:76-77): the sum rides in the GEMM's epilogue, the
+        # Linear's bias in the activation kernel (k15d)
+        out = ops.bias_ssp(ops.linear_add(node_attr, self.centroid_lin.weight, None, aggr_msg), self.centroid_lin.bias)
+        return ops.layer_norm_residual(self.out_transform(out), None, self.layer_norm)
 
 
 def _dense_attention(module, Q, K, V, attn_mask, key_channels, hidden_channels):
@@ -247,9 +249,19 @@ def _dense_attention(module, Q, K, V, attn_mask, key_channels, hidden_channels):
     dk, dv = key_channels // heads, hidden_channels // heads
     scale = 1.0 / math.sqrt(dk)
     if dk == 32 and dv == 64:       # the shipped head geometry: scores never leave the MFMA registers (k19), and the kernel
-        # reads q / k / v in the projections' own [B, T, heads, d] layout and writes the context in it: no head transposes
-        context = ops.attention(module.W_Q(Q).view(B, -1, heads, dk), module.W_K(K).view(B, -1, heads, dk),
-                                module.W_V(V).view(B, -1, heads, dv), attn_mask, scale, heads, token_major=True)
+        # reads q / k / v in the projections' own [B, T, heads, d] layout and writes the context in it: no head transposes.
+        # Projections that share their input are ONE launch (W_Q | W_K | W_V of a self attention, W_K | W_V of a cross
+        # attention); the kernel reads their column blocks in place
+        WQ, WK, WV = ((m.weight, m.bias) for m in (module.W_Q, module.W_K, module.W_V))
+        if Q is K and K is V:
+            q_s, k_s, v_s = ops.linear_multi(Q, [WQ, WK, WV])
+        elif K is V:
+            q_s = module.W_Q(Q)
+            k_s, v_s = ops.linear_multi(K, [WK, WV])
+        else:
+            q_s, k_s, v_s = module.W_Q(Q), module.W_K(K), module.W_V(V)
+        context = ops.attention(q_s.view(B, -1, heads, dk), k_s.view(B, -1, heads, dk), v_s.view(B, -1, heads, dv), attn_mask,
+                                scale, heads, token_major=True)
         return ops.layer_norm_residual(module.linear(context.view(B, -1, hidden_channels)), Q, module.layer_norm)
     q_s = module.W_Q(Q).view(B, -1, heads, dk).transpose(1, 2)
     k_s = module.W_K(K).view(B, -1, heads, dk).transpose(1, 2)
@@ -305,8 +317,8 @@ class PoswiseFeedForwardNet(nn.Module):
         self.batch_norm = BatchNorm1d(hidden_channels, device=device)
 
     def forward(self, inputs):
-        h = F.relu(ops.linear(inputs, self.conv1.weight, self.conv1.bias))
-        return ops.layer_norm_residual(ops.linear(h, self.conv2.weight, self.conv2.bias), inputs, self.layer_norm)
+        h = ops.pos_ffn(inputs, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
+        return ops.layer_norm_residual(h, inputs, self.layer_norm)
 
 
 class PoswiseFeedForwardDeNet(nn.Module):
@@ -317,8 +329,8 @@ class PoswiseFeedForwardDeNet(nn.Module):
         self.layer_norm = LayerNorm(hidden_channels, device=device)
 
     def forward(self, inputs):
-        h = F.relu(ops.linear(inputs, self.conv1.weight, self.conv1.bias))
-        return ops.layer_norm_residual(ops.linear(h, self.conv2.weight, self.conv2.bias), inputs, self.layer_norm)
+        h = ops.pos_ffn(inputs, self.conv1.weight, self.conv1.bias, self.conv2.weight, self.conv2.bias)
+        return ops.layer_norm_residual(h, inputs, self.layer_norm)
 
 
 class PositionalEncoding(nn.Module):

@@ -103,6 +103,23 @@ def edge_frames(vec, rand, stats):
     return rot
 
 
+def lap_eig(lap, num, start, n_total, k=8):
+    """n2: the k eigenvectors after the smallest of each graph's dense symmetric matrix lap[b] ([B, mx, mx] fp64, leading
+    num[b] x num[b] block; DESTROYED), entry of largest magnitude positive -> fp32 [n_total, k], graph b's rows at
+    start[b] (reference model/CProMG.py:562-571; no gradient)."""
+    if not lap.is_cuda or lap.dtype != torch.float64 or lap.dim() != 3 or lap.shape[1] != lap.shape[2]:
+        raise RuntimeError("lap_eig: a CUDA fp64 [B, mx, mx] batch of symmetric matrices")
+    lap = lap.contiguous()
+    B, mx = lap.shape[0], lap.shape[1]
+    _lib.ensure_init(lap.device.index if lap.device.index is not None else torch.cuda.current_device())
+    lib = _lib.lib()
+    nn, st = num.to(torch.int32).contiguous(), start.to(torch.int32).contiguous()
+    work = torch.empty(max(lib.singa_lap_eig_work(B, mx), 1), device=lap.device, dtype=torch.float64)
+    out = torch.zeros(n_total, k, device=lap.device, dtype=torch.float32)
+    _chk(lib.singa_lap_eig(_p(lap), _p(nn), _p(st), _p(work), _p(out), B, mx, k, _stream()), "singa_lap_eig")
+    return out
+
+
 def wigner_rows(rot, L, M=2):
     """k2: rot [E,3,3] -> reduced Wigner rows [E, WSZ] (no gradient, EF:485-528)."""
     rot = rot.detach().contiguous().float()
@@ -670,33 +687,64 @@ def masked_softmax(s, mask, scale, heads):
     return _MaskedSoftmax.apply(s, mask, scale, heads)
 
 
+def _tok_view(t, heads, D):
+    """A token-major attention operand [B, T, heads, D]: dense, or a column block of a wider [B, T, P] buffer (the fused
+    W_Q | W_K | W_V projection output).  Returns (tensor usable as it is, token pitch in floats) - a copy if the view
+    cannot be addressed as (base, pitch)."""
+    B, T = t.shape[0], t.shape[1]
+    st = t.stride()
+    ok = (st[3] == 1 and st[2] == D and st[1] % 4 == 0 and st[1] >= heads * D and (T == 1 or st[0] == T * st[1] or B == 1)
+          and t.data_ptr() % 16 == 0)
+    if B > 1 and T == 1:
+        ok = ok and st[0] == st[1]
+    if not ok:
+        t = t.contiguous()
+        return t, heads * D
+    return t, st[1]
+
+
+def _fused_blocks(ts):
+    """True when the views ts (same leading shape) are consecutive column blocks of one row-pitched buffer."""
+    p0, pitch = ts[0].data_ptr(), ts[0].stride(1)
+    off = 0
+    for t in ts:
+        if t.stride(1) != pitch or t.stride(0) != ts[0].stride(0) or t.data_ptr() != p0 + 4 * off:
+            return False
+        off += t.shape[2] * t.shape[3]
+    return pitch >= off
+
+
 class _Attention(torch.autograd.Function):
     """softmax(masked_fill(q k^T * scale, mask, -1e9)) v on the MFMA (k19): scores never leave registers; the backward
     recomputes them from q, k and the stored log-sum-exp.  token_major: q / k / v / context are [B, T|S, heads, D] (as the
-    projections produce them) instead of [B*heads, T|S, D] - no head transposes."""
+    projections produce them) instead of [B*heads, T|S, D] - no head transposes; q / k / v may then be column blocks of one
+    fused projection output, and their gradients are written as the same column blocks of one buffer, so that the fused
+    projection's backward takes them without a copy."""
 
     @staticmethod
     def forward(ctx, q, k, v, mask, scale, heads, token_major):
-        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
-        _dev(q, k, v)
         assert mask.dtype == torch.bool and mask.dim() == 3 and mask.stride(2) == 1 and mask.is_cuda
         if token_major:
             B, T, _, DK = q.shape
             S, DV = v.shape[1], v.shape[3]
             BH = B * heads
             assert q.shape[2] == heads and k.shape == (B, S, heads, DK) and v.shape[:3] == (B, S, heads)
+            (q, lq), (k, lk), (v, lv) = _tok_view(q, heads, DK), _tok_view(k, heads, DK), _tok_view(v, heads, DV)
             out = torch.empty(B, T, heads, DV, device=q.device, dtype=torch.float32)
         else:
+            q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+            lq = lk = lv = 0
             BH, T, DK = q.shape
             S, DV = v.shape[1], v.shape[2]
             out = torch.empty(BH, T, DV, device=q.device, dtype=torch.float32)
+        _dev(q, k, v)
         assert mask.shape[0] * heads == BH and mask.shape[2] == S and mask.shape[1] in (1, T)
         ctx.mst = 0 if mask.shape[1] == 1 else mask.stride(1)
         lse = torch.empty(BH, T, 2, device=q.device, dtype=torch.float32)       # (row maximum, 1 / row sum)
         _chk(_lib.lib().singa_attn_fwd(_p(q), _p(k), _p(v), _p(mask), mask.stride(0), ctx.mst, _p(out), _p(lse), BH, T, S, heads,
-                                       DK, DV, int(token_major), scale, _stream()), "singa_attn_fwd")
+                                       DK, DV, int(token_major), lq, lk, lv, scale, _stream()), "singa_attn_fwd")
         ctx.save_for_backward(q, k, v, mask, out, lse)
-        ctx.scale, ctx.heads, ctx.tm, ctx.dims = scale, heads, bool(token_major), (BH, T, S, DK, DV)
+        ctx.scale, ctx.heads, ctx.tm, ctx.dims, ctx.ld = scale, heads, bool(token_major), (BH, T, S, DK, DV), (lq, lk, lv)
         return out
 
     @staticmethod
@@ -704,17 +752,44 @@ class _Attention(torch.autograd.Function):
         q, k, v, mask, out, lse = ctx.saved_tensors
         g = g.contiguous()
         BH, T, S, DK, DV = ctx.dims
-        gq, gk, gv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        lq, lk, lv = ctx.ld
+
+        def like(ts):
+            """Gradients laid out like the operands: column blocks of ONE buffer where the operands are."""
+            if ctx.tm and len(ts) > 1 and _fused_blocks(ts):
+                B, rows, pitch = ts[0].shape[0], ts[0].shape[1], ts[0].stride(1)
+                buf = torch.empty(B, rows, pitch, device=g.device, dtype=torch.float32)
+                outs, off = [], 0
+                for t in ts:
+                    w = t.shape[2] * t.shape[3]
+                    outs.append(buf[:, :, off:off + w].view(B, rows, t.shape[2], t.shape[3]))
+                    off += w
+                if off < pitch:                       # columns of the buffer no operand covers (none in the model's layouts)
+                    buf[:, :, off:].zero_()
+                return outs
+            return [torch.empty(t.shape, device=g.device, dtype=torch.float32) for t in ts]
+
+        if ctx.tm and T == S and _fused_blocks([q, k, v]):
+            gq, gk, gv = like([q, k, v])
+        elif ctx.tm and _fused_blocks([k, v]):
+            (gq,), (gk, gv) = like([q]), like([k, v])
+        else:
+            (gq,), (gk,), (gv,) = like([q]), like([k]), like([v])
+        if ctx.tm:
+            lq, lk, lv = gq.stride(1), gk.stride(1), gv.stride(1)
+            # the kernels address the gradients with the operands' pitches: they agree by construction
+            assert (lq, lk, lv) == (q.stride(1), k.stride(1), v.stride(1))
         dsum = torch.empty(BH, T, device=q.device, dtype=torch.float32)
         _chk(_lib.lib().singa_attn_bwd(_p(q), _p(k), _p(v), _p(mask), mask.stride(0), ctx.mst, _p(out), _p(lse), _p(g), _p(gq),
-                                       _p(gk), _p(gv), _p(dsum), BH, T, S, ctx.heads, DK, DV, int(ctx.tm), ctx.scale, _stream()),
-             "singa_attn_bwd")
+                                       _p(gk), _p(gv), _p(dsum), BH, T, S, ctx.heads, DK, DV, int(ctx.tm), lq, lk, lv, ctx.scale,
+                                       _stream()), "singa_attn_bwd")
         return gq, gk, gv, None, None, None, None
 
 
 def attention(q, k, v, mask, scale, heads, token_major=False):
     """Dense attention core (k19) for q[B*heads,T,32], k[B*heads,S,32], v[B*heads,S,64] - or, token_major, q[B,T,heads,32],
-    k[B,S,heads,32], v[B,S,heads,64] -> context in the same layout - and a boolean mask [B, T|1, S]."""
+    k[B,S,heads,32], v[B,S,heads,64] (dense, or column blocks of a fused projection output) -> context in the same layout
+    - and a boolean mask [B, T|1, S]."""
     return _Attention.apply(q, k, v, mask, scale, heads, token_major)
 
 
@@ -1103,10 +1178,11 @@ class _Linear(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------- k7 / k11: own f32 MFMA GEMM
-USE_OWN_GEMM = _os.environ.get("SINGA_GEMM", "own") == "own"      # "lib": the library GEMMs (kept as the tests' cross-check)
-USE_OWN_SO3 = _os.environ.get("SINGA_SO3_GEMM", "own") == "own"
-USE_SKINNY_SO3 = _os.environ.get("SINGA_SO3_SKINNY", "1") == "1"      # k11s for the 16 <-> 512 channel SO3 linears
-_GEMM_SPLIT_ROWS = int(_os.environ.get("SINGA_GEMM_SPLIT_ROWS", "2048"))
+# The BLAS-library evaluation of the same contractions lives in tests/lib_gemm.py (the tests' second opinion); the product has
+# one path.  USE_SKINNY_SO3: the VALU kernels k11s for the 16 <-> 512 / 112 channel SO3 linears (the tests switch it off to
+# reach the MFMA kernel's grouped-row problems on those shapes too).
+USE_SKINNY_SO3 = True
+_GEMM_SPLIT_ROWS = 2048
 
 
 def _rows(t):
@@ -1209,40 +1285,9 @@ class _SO2Linear3(torch.autograd.Function):
         return gX, gws[0], gb, gws[1], gws[2], None, None
 
 
-class _SO2Linear3Lib(torch.autograd.Function):
-    """The same three GEMMs through the BLAS libraries (hipBLASLt / rocBLAS via torch): the cross-check of k7 in the tests
-    (SINGA_GEMM=lib selects it)."""
-
-    @staticmethod
-    def forward(ctx, X, w0, b0, w1, w2, n0, n1):
-        blocks = (X[:, :n0], X[:, n0:n0 + n1], X[:, n0 + n1:])
-        ctx.save_for_backward(X, w0, w1, w2)
-        ctx.n0, ctx.n1 = n0, n1
-        outs = []
-        for xb, w, b in zip(blocks, (w0, w1, w2), (b0, None, None)):
-            with _blas(xb.shape[0], w.shape[0], xb.shape[1]):
-                outs.append(torch.addmm(b, xb, w.t()) if b is not None else xb @ w.t())
-        return tuple(outs)
-
-    @staticmethod
-    def backward(ctx, g0, g1, g2):
-        X, w0, w1, w2 = ctx.saved_tensors
-        n0, n1 = ctx.n0, ctx.n1
-        bounds = ((0, n0), (n0, n0 + n1), (n0 + n1, X.shape[1]))
-        gX = torch.empty_like(X) if ctx.needs_input_grad[0] else None
-        gws = []
-        for g, w, (a, b) in zip((g0, g1, g2), (w0, w1, w2), bounds):
-            g = g.contiguous()
-            if gX is not None:
-                with _blas(g.shape[0], w.shape[1], g.shape[1]):
-                    torch.mm(g, w, out=gX[:, a:b])
-            gws.append(_splitk_tn(g, X[:, a:b]))
-        return gX, gws[0], colsum(g0), gws[1], gws[2], None, None
-
-
 def so2_linear3(X, w0, b0, w1, w2, n0, n1):
     """(X[:, :n0] w0^T + b0, X[:, n0:n0+n1] w1^T, X[:, n0+n1:] w2^T) - see _SO2Linear3."""
-    return (_SO2Linear3 if USE_OWN_GEMM else _SO2Linear3Lib).apply(X, w0, b0, w1, w2, n0, n1)
+    return _SO2Linear3.apply(X, w0, b0, w1, w2, n0, n1)
 
 
 class _SO3Linear(torch.autograd.Function):
@@ -1341,36 +1386,8 @@ class _SO3Linear(torch.autograd.Function):
         return gx, gw, param_colsum(g[:, 0, :], [(0, cout, ctx.params[1])])[0], None
 
 
-class _SO3LinearLib(torch.autograd.Function):
-    """SO3_LinearV2 as one batched library GEMM over the K rows (the cross-check of k11; SINGA_GEMM=lib selects it)."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, L):
-        x = x.contiguous()
-        N, K, _ = x.shape
-        w = weight.index_select(0, _degree_index(L, x.device))                    # [K, out, in]
-        out = torch.empty(N, K, weight.shape[1], device=x.device, dtype=x.dtype)
-        torch.bmm(x.transpose(0, 1), w.transpose(1, 2), out=out.transpose(0, 1))
-        out[:, 0, :] += bias
-        ctx.save_for_backward(x, w)
-        ctx.L = L
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        x, w = ctx.saved_tensors
-        g = g.contiguous()
-        K = x.shape[1]
-        gT = g.transpose(0, 1)                                                    # [K, N, out] view
-        gx = torch.empty_like(x)
-        torch.bmm(gT, w, out=gx.transpose(0, 1))
-        gw_rows = torch.bmm(gT.transpose(1, 2), x.transpose(0, 1))               # [K, out, in]
-        gw = (_degree_onehot(ctx.L, x.device) @ gw_rows.view(K, -1)).view(ctx.L + 1, *gw_rows.shape[1:])
-        return gx, gw, colsum(g[:, 0, :]), None
-
-
 def so3_linear(x, weight, bias, L):
-    return (_SO3Linear if (USE_OWN_GEMM and USE_OWN_SO3) else _SO3LinearLib).apply(x, weight, bias, L)
+    return _SO3Linear.apply(x, weight, bias, L)
 
 
 class _GroupedLinear(torch.autograd.Function):
@@ -1418,10 +1435,279 @@ def grouped_linear(h, w, heads=None):
     return _GroupedLinear.apply(h, w, heads)
 
 
+def _tn_splits(rows, out, cin):
+    """Split count of a weight-gradient GEMM dW[out, cin] = g^T x over `rows` rows: enough workgroups to fill the chip
+    (~512 tiles in all), at least 256 rows per split, at most 64 splits."""
+    tiles = -(-out // 128) * -(-cin // 128)
+    return max(1, min(64, max(-(-rows // 4096), -(-512 // tiles)), rows // 256))
+
+
+def _own_linear_ok(x, w, b):
+    K = x.shape[-1]
+    N = w.shape[0]
+    return x.is_cuda and x.dtype == torch.float32 and K % 4 == 0 and N % 4 == 0 and x.numel() > 0
+
+
+class _LinearOwn(torch.autograd.Function):
+    """nn.Linear / 1x1 Conv1d on rows (CP:55-61, 96-117, 161-191) on the library's own f32 MFMA GEMM (k7): y = x W^T + b
+    (+ addend, a tensor shaped like y: the sum of two Linears' outputs costs no extra pass) in ONE launch, dX one launch,
+    dW one split-reduction launch whose partial slabs - like the bias gradient - are added up by the step's shared
+    column-sum launch (ops._GradSink)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, addend):
+        ctx.params = (w, b)
+        K, N = x.shape[-1], w.shape[0]
+        x2 = _rows(x.reshape(-1, K))
+        w2 = _rows(w.view(N, K))
+        _dev(x2, w2, b)
+        M = x2.shape[0]
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        ad = None
+        if addend is not None:
+            ad = addend.reshape(M, N).contiguous()
+            _dev(ad)
+        _gemm([dict(a=x2.data_ptr(), lda=x2.stride(0), b=w2.data_ptr(), ldb=w2.stride(0), c=y.data_ptr(), ldc=N,
+                    bias=b.data_ptr() if b is not None else None, addend=ad.data_ptr() if ad is not None else None,
+                    I=M, J=N, R=K)], True, True)
+        ctx.save_for_backward(x2, w2)
+        ctx.xshape, ctx.has_bias, ctx.ashape = x.shape, b is not None, (addend.shape if addend is not None else None)
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w2 = ctx.saved_tensors
+        M, K = x2.shape
+        N = w2.shape[0]
+        g2 = _rows(g.reshape(-1, N))
+        wp, bp = ctx.params
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(M, K, device=g.device, dtype=torch.float32)
+            _gemm([dict(a=g2.data_ptr(), lda=g2.stride(0), b=w2.data_ptr(), ldb=w2.stride(0), c=gx.data_ptr(), ldc=K,
+                        I=M, J=K, R=N)], True, False)
+            gx = gx.view(ctx.xshape)
+        if ctx.needs_input_grad[1]:
+            gw = _tn_grad(g2, x2, wp)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = param_colsum(g2, [(0, N, bp)])[0]
+        ga = g.reshape(ctx.ashape) if ctx.ashape is not None and ctx.needs_input_grad[3] else None
+        return gx, gw, gb, ga
+
+
+class _LinearNN(torch.autograd.Function):
+    """y = x W for a parameter W [K, N] used untransposed (the hoisted `weight_k_lin` of the graph attention: (q W), CP:61
+    with W(w*k) moved to the query side) - the (1, 0) form of the own GEMM, no transposed copy of W."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.param = w
+        K, N = w.shape
+        x2 = _rows(x.reshape(-1, K))
+        w2 = _rows(w)
+        _dev(x2, w2)
+        M = x2.shape[0]
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        _gemm([dict(a=x2.data_ptr(), lda=x2.stride(0), b=w2.data_ptr(), ldb=w2.stride(0), c=y.data_ptr(), ldc=N, I=M, J=N, R=K)],
+              True, False)
+        ctx.save_for_backward(x2, w2)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w2 = ctx.saved_tensors
+        M, K = x2.shape
+        N = w2.shape[1]
+        g2 = _rows(g.reshape(-1, N))
+        gx = gw = None
+        if ctx.needs_input_grad[0]:                  # dx = g W^T: W [K, N] is the [J][R] operand of the (1, 1) form
+            gx = torch.empty(M, K, device=g.device, dtype=torch.float32)
+            _gemm([dict(a=g2.data_ptr(), lda=g2.stride(0), b=w2.data_ptr(), ldb=w2.stride(0), c=gx.data_ptr(), ldc=K,
+                        I=M, J=K, R=N)], True, True)
+            gx = gx.view(ctx.xshape)
+        if ctx.needs_input_grad[1]:                  # dW [K, N] = x^T g
+            gw = _tn_grad(x2, g2, ctx.param)
+        return gx, gw
+
+
+def linear_nn(x, w):
+    if x.is_cuda and w.shape[0] % 4 == 0 and w.shape[1] % 4 == 0 and x.numel() > 0:
+        return _LinearNN.apply(x, w)
+    return linear(x, w.t())
+
+
+def _tn_grad(g2, x2, param):
+    """dW[N, K] = g2^T x2 (reduction over the rows, split over workgroups) as partial slabs -> param_colsum: returns the
+    gradient shaped like `param`, or None when it was queued into param.grad."""
+    M, N = g2.shape
+    K = x2.shape[1]
+    S = _tn_splits(M, N, K)
+    part = torch.empty(S, N * K, device=g2.device, dtype=torch.float32)
+    _gemm([dict(a=g2.data_ptr(), lda=g2.stride(0), b=x2.data_ptr(), ldb=x2.stride(0), c=part.data_ptr(), ldc=K,
+                I=N, J=K, R=M, c_split_stride=N * K)], False, False, S)
+    gw = param_colsum(part, [(0, N * K, param)])[0]
+    return gw.view(param.shape) if gw is not None else None
+
+
 def linear(x, w, b=None):
-    """y = x W^T + b with gradients that are all GEMMs: dW by batched split-K when the row count is large (per-edge
-    layers: 10^4..10^6 rows against <= 10^3 columns), db as a ones-row GEMM (see colsum)."""
+    """y = x W^T + b (w: [out, in] or a 1x1 Conv1d weight [out, in, 1]) on the own MFMA GEMM (k7); shapes the kernel's float4
+    accesses cannot take (a reduction or an output that is not a multiple of 4: the 3-column property embedding) go
+    through the BLAS library."""
+    if _own_linear_ok(x, w, b):
+        return _LinearOwn.apply(x, w, b, None)
     return _Linear.apply(x, w, b)
+
+
+class _LinearMulti(torch.autograd.Function):
+    """Several nn.Linear layers applied to the SAME input (W_Q | W_K | W_V of a self-attention, W_K | W_V of a cross
+    attention; CP:96-101, 140-143): one launch forward - one problem per layer, each writing its column block of ONE
+    [M, sum N] buffer - one launch for dX (a single product over the concatenated output columns: no per-layer input
+    gradients to add up) and one split-reduction launch for all weight gradients.  The outputs are views of the fused
+    buffer; the attention kernels read them in place and hand back their gradients in the same arrangement."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        ws, bs = wb[0::2], wb[1::2]
+        ctx.params = (ws, bs)
+        K = x.shape[-1]
+        x2 = _rows(x.reshape(-1, K))
+        w2 = [_rows(w.view(w.shape[0], K)) for w in ws]
+        _dev(x2, *w2, *bs)
+        M = x2.shape[0]
+        ns = [w.shape[0] for w in w2]
+        tot = sum(ns)
+        y = torch.empty(M, tot, device=x.device, dtype=torch.float32)
+        items, off = [], 0
+        for w, b, n in zip(w2, bs, ns):
+            items.append(dict(a=x2.data_ptr(), lda=x2.stride(0), b=w.data_ptr(), ldb=w.stride(0), c=y.data_ptr() + 4 * off,
+                              ldc=tot, bias=b.data_ptr() if b is not None else None, I=M, J=n, R=K))
+            off += n
+        _gemm(items, True, True)
+        ctx.save_for_backward(x2, *w2)
+        ctx.xshape, ctx.ns = x.shape, ns
+        lead = x.shape[:-1]
+        outs, off = [], 0
+        for n in ns:
+            outs.append(y[:, off:off + n].view(*lead, n))
+            off += n
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        x2, *w2 = ctx.saved_tensors
+        ns = ctx.ns
+        tot = sum(ns)
+        M, K = x2.shape
+        ws, bs = ctx.params
+        g2 = [g.reshape(M, n) for g, n in zip(gs, ns)]
+        # the gradients normally arrive as the column blocks of one [M, tot] buffer (ops._Attention writes them so)
+        fused = all(g.stride(1) == 1 and g.stride(0) == g2[0].stride(0) for g in g2) and g2[0].stride(0) >= tot
+        off = 0
+        for g, n in zip(g2, ns):
+            fused = fused and g.data_ptr() == g2[0].data_ptr() + 4 * off
+            off += n
+        if fused and g2[0].data_ptr() % 16 == 0 and g2[0].stride(0) % 4 == 0:
+            G, ldg = g2[0], g2[0].stride(0)
+        else:
+            G = torch.cat(g2, 1)
+            ldg = tot
+        gp = G.data_ptr()
+        gx = None
+        if ctx.needs_input_grad[0]:
+            wcat = torch.cat(w2, 0)                                  # [tot, K]: the reduction runs over all output columns
+            gx = torch.empty(M, K, device=x2.device, dtype=torch.float32)
+            _gemm([dict(a=gp, lda=ldg, b=wcat.data_ptr(), ldb=K, c=gx.data_ptr(), ldc=K, I=M, J=K, R=tot)], True, False)
+            gx = gx.view(ctx.xshape)
+        sizes = [n * K for n in ns]
+        S = _tn_splits(M, max(ns), K)
+        part = torch.empty(S, tot * K, device=x2.device, dtype=torch.float32)
+        items, off, poff = [], 0, 0
+        for n, sz in zip(ns, sizes):
+            items.append(dict(a=gp + 4 * off, lda=ldg, b=x2.data_ptr(), ldb=x2.stride(0), c=part.data_ptr() + 4 * poff, ldc=K,
+                              I=n, J=K, R=M, c_split_stride=tot * K))
+            off, poff = off + n, poff + sz
+        _gemm(items, False, False, S)
+        offs = [sum(sizes[:i]) for i in range(len(sizes))]
+        gws = param_colsum(part, [(o, sz, w) for o, sz, w in zip(offs, sizes, ws)])
+        gws = [gw.view(w.shape) if gw is not None else None for gw, w in zip(gws, ws)]
+        Gv = torch.as_strided(G, (M, tot), (ldg, 1))
+        coff = [sum(ns[:i]) for i in range(len(ns))]
+        gbs = param_colsum(Gv, [(o, n, b) for o, n, b in zip(coff, ns, bs)]) if all(b is not None for b in bs) else [None] * len(ns)
+        out = [gx]
+        for gw, gb in zip(gws, gbs):
+            out += [gw, gb]
+        return tuple(out)
+
+
+def linear_multi(x, layers):
+    """[(weight, bias), ...] applied to the same x -> tuple of outputs (views of one fused buffer).  Falls back to
+    separate ops.linear calls for shapes the own GEMM cannot take."""
+    if all(_own_linear_ok(x, w, b) and b is not None for w, b in layers) and len(layers) <= 8:
+        flat = []
+        for w, b in layers:
+            flat += [w, b]
+        return _LinearMulti.apply(x, *flat)
+    return tuple(linear(x, w, b) for w, b in layers)
+
+
+def linear_add(x, w, b, addend):
+    """x W^T + b + addend (addend shaped like the result) in one launch."""
+    if _own_linear_ok(x, w, b):
+        return _LinearOwn.apply(x, w, b, addend)
+    return _Linear.apply(x, w, b) + addend
+
+
+class _PosFFN(torch.autograd.Function):
+    """PoswiseFeedForward(De)Net up to its residual LayerNorm (CP:161-191): Linear(256 -> 1024) + ReLU + Linear(1024 -> 256)
+    as two launches forward (ReLU in the first GEMM's epilogue) and four backward: dh = (g W2) masked by h > 0 in the
+    epilogue of its own GEMM, dx = dh W1, and the two split-reduction weight gradients; bias gradients ride in the step's
+    shared column-sum launch."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        ctx.params = (w1, b1, w2, b2)
+        K, H = x.shape[-1], w1.shape[0]
+        x2 = _rows(x.reshape(-1, K))
+        a1, a2 = _rows(w1.view(H, K)), _rows(w2.view(w2.shape[0], H))
+        _dev(x2, a1, a2, b1, b2)
+        M, N = x2.shape[0], a2.shape[0]
+        h = torch.empty(M, H, device=x.device, dtype=torch.float32)
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        _gemm([dict(a=x2.data_ptr(), lda=x2.stride(0), b=a1.data_ptr(), ldb=a1.stride(0), c=h.data_ptr(), ldc=H,
+                    bias=b1.data_ptr(), I=M, J=H, R=K, relu=1)], True, True)
+        _gemm([dict(a=h.data_ptr(), lda=H, b=a2.data_ptr(), ldb=a2.stride(0), c=y.data_ptr(), ldc=N, bias=b2.data_ptr(),
+                    I=M, J=N, R=H)], True, True)
+        ctx.save_for_backward(x2, a1, a2, h)
+        ctx.xshape = x.shape
+        return y.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, a1, a2, h = ctx.saved_tensors
+        M, K = x2.shape
+        H, N = a1.shape[0], a2.shape[0]
+        g2 = _rows(g.reshape(-1, N))
+        w1, b1, w2, b2 = ctx.params
+        dh = torch.empty(M, H, device=g.device, dtype=torch.float32)
+        _gemm([dict(a=g2.data_ptr(), lda=g2.stride(0), b=a2.data_ptr(), ldb=a2.stride(0), c=dh.data_ptr(), ldc=H,
+                    I=M, J=H, R=N, mask=h.data_ptr())], True, False)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(M, K, device=g.device, dtype=torch.float32)
+            _gemm([dict(a=dh.data_ptr(), lda=H, b=a1.data_ptr(), ldb=a1.stride(0), c=gx.data_ptr(), ldc=K, I=M, J=K, R=H)],
+                  True, False)
+            gx = gx.view(ctx.xshape)
+        gw2 = _tn_grad(g2, h, w2)
+        gw1 = _tn_grad(dh, x2, w1)
+        gb2 = param_colsum(g2, [(0, N, b2)])[0]
+        gb1 = param_colsum(dh, [(0, H, b1)])[0]
+        return gx, gw1, gb1, gw2, gb2
+
+
+def pos_ffn(x, w1, b1, w2, b2):
+    """relu(x W1^T + b1) W2^T + b2 (the position-wise feed-forward of CP:161-191 before its residual LayerNorm)."""
+    return _PosFFN.apply(x, w1, b1, w2, b2)
 
 
 def skinny_linear(x, w, b):
@@ -1455,20 +1741,20 @@ def embedding(weight, idx, padding_idx=None):
 
 
 class _RowDotBias(torch.autograd.Function):
-    """(x[..., d] * b[d]).sum(-1) with a replay-safe, GEMV-free bias gradient (rocBLAS gemv took 236 us here)."""
+    """scale * (x[..., d] * b[d]).sum(-1) with a replay-safe, GEMV-free bias gradient (rocBLAS gemv took 236 us here)."""
 
     @staticmethod
-    def forward(ctx, x, b):
+    def forward(ctx, x, b, scale):
         ctx.save_for_backward(x, b)
-        ctx.param = b
-        return (x * b).sum(-1)
+        ctx.param, ctx.scale = b, scale
+        return (x * (b * scale)).sum(-1)
 
     @staticmethod
     def backward(ctx, g):
         x, b = ctx.saved_tensors
-        ge = g.unsqueeze(-1)
-        return ge * b, param_colsum((ge * x).reshape(-1, x.shape[-1]), [(0, x.shape[-1], ctx.param)])[0]
+        ge = g.unsqueeze(-1) * ctx.scale
+        return ge * b, param_colsum((ge * x).reshape(-1, x.shape[-1]), [(0, x.shape[-1], ctx.param)])[0], None
 
 
-def rowdot_bias(x, b):
-    return _RowDotBias.apply(x, b)
+def rowdot_bias(x, b, scale=1.0):
+    return _RowDotBias.apply(x, b, scale)

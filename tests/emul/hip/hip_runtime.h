@@ -4,6 +4,7 @@
 // library is built by hipcc for gfx950 only.  Kernels that use cross-lane intrinsics (__shfl_xor) cannot be emulated
 // sequentially and abort here; they are covered by the -m gpu tests.
 #pragma once
+#define SINGA_EMUL 1
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -83,6 +84,14 @@ static inline void __syncthreads() {
 struct floatx16_emul { float v[16]; float& operator[](int i) { return v[i]; } };
 #define SINGA_FLOATX16 floatx16_emul
 static inline floatx16_emul __builtin_amdgcn_mfma_f32_32x32x2f32(float, float, floatx16_emul c, int, int, int) {
+    fprintf(stderr, "emul: matrix-core kernel cannot be emulated sequentially\n");
+    abort();
+    return c;
+}
+
+struct floatx4_emul { float v[4]; float& operator[](int i) { return v[i]; } };
+#define SINGA_FLOATX4 floatx4_emul
+static inline floatx4_emul __builtin_amdgcn_mfma_f32_16x16x4f32(float, float, floatx4_emul c, int, int, int) {
     fprintf(stderr, "emul: matrix-core kernel cannot be emulated sequentially\n");
     abort();
     return c;

@@ -281,8 +281,8 @@ def test_eager_backward_before_capture():
     model = SINGA(load_config(lmax=2), device="cuda")
     model.load_state_dict(state_from_spec("singa_L2"), strict=False)
     model.eval()
-    logits = model(batch)
-    torch.nn.functional.cross_entropy(logits, batch["ligand_data"]["smiIndices_tgt"].reshape(-1)).backward()
+    # (no reference to the logits is kept: a live autograd graph would itself pin the AccumulateGrad nodes)
+    torch.nn.functional.cross_entropy(model(batch), batch["ligand_data"]["smiIndices_tgt"].reshape(-1)).backward()
     assert not EF_layers._bw_cache
     model.zero_grad(set_to_none=True)
     eng = TrainStep(model, Adam(model.parameters(), lr=1e-4, betas=(0.99, 0.999)), None, use_graph=True)

@@ -17,11 +17,21 @@ def _f64(t):
     return t.detach().cpu().double()
 
 
+@pytest.fixture
+def tile_shape(request):
+    """Force the 128 x 128 (0) or the 64 x 64 (3) macro tile wherever the library would choose between the two."""
+    from singa_amd import _lib
+    assert _lib.lib().singa_gemm_force_cfg(request.param) == 0
+    yield request.param
+    assert _lib.lib().singa_gemm_force_cfg(-1) == 0
+
+
+@pytest.mark.parametrize("tile_shape", [0, 3], indirect=True)
 @pytest.mark.parametrize("M,N,K", [(1, 16, 16), (130, 40, 36), (129, 992, 160), (1000, 560, 640), (257, 16, 112), (300, 32, 512),
                                    (64, 1024, 256), (5000, 128, 8)])
-def test_gemm_nt_nn_tn_against_float64(M, N, K):
-    """y = x W^T + b, dx = dy W, dW = dy^T x (split reduction) for sizes with ragged tiles in every dimension; exact
-    integers first (any indexing slip shows as an O(1) error), then random floats."""
+def test_gemm_nt_nn_tn_against_float64(M, N, K, tile_shape):
+    """y = x W^T + b, dx = dy W, dW = dy^T x (split reduction) for sizes with ragged tiles in every dimension, on both
+    macro-tile shapes; exact integers first (any indexing slip shows as an O(1) error), then random floats."""
     from singa_amd import ops
     g = torch.Generator().manual_seed(M * 7 + N)
     for kind in ("int", "float"):
@@ -86,8 +96,10 @@ def test_so2_convolution_matches_oracle(L, cin, cout, extra):
     ((want * gy).sum() + ((ex * gex).sum() if extra else 0.0)).backward()
     to_m = torch.as_tensor(lay.to_m)
     st = lay.seg_start
+    from tests.lib_gemm import _SO2Linear3Lib
     for own in (True, False):
-        ops.USE_OWN_GEMM, ops._GEMM_SPLIT_ROWS = own, 200
+        ops._GEMM_SPLIT_ROWS = 200
+        so2 = ops.so2_linear3 if own else _SO2Linear3Lib.apply
         try:
             X = x[:, to_m].reshape(E, -1).to(DEV).requires_grad_(True)       # m-primary rows, what k4 hands over
             w0 = sd["c.fc_m0.weight"].to(DEV).requires_grad_(True)
@@ -98,7 +110,7 @@ def test_so2_convolution_matches_oracle(L, cin, cout, extra):
                 with torch.no_grad():
                     mod.fc.weight.copy_(sd[f"c.so2_m_conv.{m - 1}.fc.weight"])
                 fcs.append(mod)
-            h0, h1, h2 = ops.so2_linear3(X, w0, b0, fcs[0].block_weight(), fcs[1].block_weight(), st[1] * cin, (st[2] - st[1]) * cin)
+            h0, h1, h2 = so2(X, w0, b0, fcs[0].block_weight(), fcs[1].block_weight(), st[1] * cin, (st[2] - st[1]) * cin)
             got = torch.cat([h0[:, extra:], h1, h2], 1).reshape(E, lay.KR, cout)        # m-primary rows
             assert rel_err(got.detach().cpu(), want[:, to_m]) < 2e-6
             if extra:
@@ -111,7 +123,7 @@ def test_so2_convolution_matches_oracle(L, cin, cout, extra):
             for m in (1, 2):
                 assert rel_err(fcs[m - 1].fc.weight.grad.cpu(), sdo[f"c.so2_m_conv.{m - 1}.fc.weight"].grad) < 1e-5, (own, m)
         finally:
-            ops.USE_OWN_GEMM, ops._GEMM_SPLIT_ROWS = True, 2048
+            ops._GEMM_SPLIT_ROWS = 2048
 
 
 @pytest.mark.parametrize("L,cin,cout", [(2, 16, 512), (2, 512, 16), (4, 16, 512), (4, 512, 16), (4, 112, 16), (6, 16, 512),
@@ -130,19 +142,21 @@ def test_so3_linear_matches_oracle(L, cin, cout):
     want = O.so3_linear(sdo, "p", xo, L)
     gy = torch.randn(want.shape, generator=g)
     (want * gy).sum().backward()
+    from tests.lib_gemm import _SO3LinearLib
     for own, skinny in ((True, True), (True, False), (False, False)):
-        ops.USE_OWN_GEMM, ops._GEMM_SPLIT_ROWS, ops.USE_SKINNY_SO3 = own, 500, skinny
+        ops._GEMM_SPLIT_ROWS, ops.USE_SKINNY_SO3 = 500, skinny
+        so3 = ops.so3_linear if own else _SO3LinearLib.apply
         try:
             xd = x.to(DEV).requires_grad_(True)
             w, b = sd["p.weight"].to(DEV).requires_grad_(True), sd["p.bias"].to(DEV).requires_grad_(True)
-            got = ops.so3_linear(xd, w, b, L)
+            got = so3(xd, w, b, L)
             assert rel_err(got.detach().cpu(), want) < 2e-6
             (got * gy.to(DEV)).sum().backward()
             assert rel_err(xd.grad.cpu(), xo.grad) < 5e-6
             assert rel_err(w.grad.cpu(), sdo["p.weight"].grad) < 1e-5
             assert rel_err(b.grad.cpu(), sdo["p.bias"].grad) < 1e-5
         finally:
-            ops.USE_OWN_GEMM, ops._GEMM_SPLIT_ROWS, ops.USE_SKINNY_SO3 = True, 2048, True
+            ops._GEMM_SPLIT_ROWS, ops.USE_SKINNY_SO3 = 2048, True
 
 
 def test_so2_and_so3_linear_on_empty_inputs():
@@ -162,3 +176,56 @@ def test_so2_and_so3_linear_on_empty_inputs():
     assert y.shape == (0, 9, 32)
     y.sum().backward()
     assert float(w.grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("tile_shape", [0, 3], indirect=True)
+def test_gemm_epilogue_options(tile_shape):
+    """bias + addend + ReLU, and the positive-mask (ReLU gradient) epilogue, on ragged tiles; exact on integers."""
+    from singa_amd import ops
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 333, 200, 72
+    ri = lambda *s: torch.randint(-3, 4, s, generator=g).float()
+    x, w, b, ad, mk = ri(M, K), ri(N, K), ri(N), ri(M, N), ri(M, N)
+    xd, wd, bd, add, mkd = (t.to(DEV) for t in (x, w, b, ad, mk))
+    y = torch.empty(M, N, device=DEV)
+    ops._gemm([dict(a=xd.data_ptr(), lda=K, b=wd.data_ptr(), ldb=K, c=y.data_ptr(), ldc=N, bias=bd.data_ptr(),
+                    addend=add.data_ptr(), relu=1, I=M, J=N, R=K)], True, True)
+    assert torch.equal(y.cpu(), torch.relu(x @ w.t() + b + ad))
+    dy = ri(M, N).to(DEV)
+    dx = torch.empty(M, K, device=DEV)
+    hm = ri(M, K).to(DEV)                                     # "forward output" whose sign gates the gradient
+    ops._gemm([dict(a=dy.data_ptr(), lda=N, b=wd.data_ptr(), ldb=K, c=dx.data_ptr(), ldc=K, I=M, J=K, R=N, mask=hm.data_ptr())],
+              True, False)
+    assert torch.equal(dx.cpu(), (dy.cpu() @ w) * (hm.cpu() > 0))
+
+
+@pytest.mark.parametrize("M,K,N", [(3417, 256, 256), (700, 256, 1024), (129, 64, 32), (45, 400, 256), (2000, 8, 256), (640, 256, 116)])
+def test_linear_and_pos_ffn_match_torch(M, K, N):
+    """ops.linear / linear_add (own GEMM with the bias and the addend in the epilogue) and ops.pos_ffn (CP:161-191: Linear,
+    ReLU, Linear) against plain torch in float64, outputs and all gradients - the CProMG transformer's projections."""
+    from singa_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x, w, b, ad = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    gy = torch.randn(M, N, generator=g)
+    ref_in = [t.double().requires_grad_(True) for t in (x, w, b, ad)]
+    ref = ref_in[0] @ ref_in[1].t() + ref_in[2] + ref_in[3]
+    (ref * gy.double()).sum().backward()
+    got_in = [t.to(DEV).requires_grad_(True) for t in (x, w, b, ad)]
+    got = ops.linear_add(got_in[0], got_in[1], got_in[2], got_in[3])
+    assert rel_err(got.detach().cpu(), ref.detach()) < 2e-6
+    (got * gy.to(DEV)).sum().backward()
+    for a, r in zip(got_in, ref_in):
+        assert rel_err(a.grad.cpu(), r.grad) < 1e-5
+    if K == 256 and N % 4 == 0:
+        H = 1024 if N == 256 else 64
+        w1, b1 = torch.randn(H, K, 1, generator=g) / K ** 0.5, torch.randn(H, generator=g)         # 1x1 Conv1d weights as they are
+        w2, b2 = torch.randn(N, H, 1, generator=g) / H ** 0.5, torch.randn(N, generator=g)
+        rin = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        ref = torch.relu(rin[0] @ rin[1][:, :, 0].t() + rin[2]) @ rin[3][:, :, 0].t() + rin[4]
+        (ref * gy.double()).sum().backward()
+        gin = [t.to(DEV).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+        got = ops.pos_ffn(*gin)
+        assert rel_err(got.detach().cpu(), ref.detach()) < 3e-6
+        (got * gy.to(DEV)).sum().backward()
+        for a, r in zip(gin, rin):
+            assert rel_err(a.grad.cpu(), r.grad) < 2e-5

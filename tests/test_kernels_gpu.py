@@ -572,3 +572,69 @@ def test_attention_matches_torch(T, S, kind):
     assert torch.equal(back(got2), got)
     for a, b in zip(got2_g, got_g):
         assert torch.equal(back(a), b)
+
+
+def _lap_np(ei, n):
+    a = np.zeros((n, n))
+    a[ei[0], ei[1]] = 1.0
+    dinv = np.clip(a.sum(0), 1, None) ** -0.5
+    lap = np.eye(n) - dinv[:, None] * a * dinv[None, :]
+    return 0.5 * (lap + lap.T)
+
+
+def _sym_edges(pairs):
+    a, b = np.asarray(pairs, dtype=np.int64).reshape(-1, 2).T
+    return np.stack([np.concatenate([a, b]), np.concatenate([b, a])])
+
+
+def test_lap_eig_batched_against_numpy():
+    """n2 (singa_lap_eig through graph.laplacian_pe_batched): per graph the 8 eigenvectors after the smallest of the
+    normalised Laplacian, checked basis-free against numpy's eigh of the same matrix (reference model/CProMG.py:562-571;
+    dgl's own output carries random signs, so the subspace is what can be compared): orthonormal columns, invariant
+    subspace, Ritz values = eigenvalues 1..8, sign convention.  Cases: a path (distinct, clustered small eigenvalues), a
+    ring with chords, many small components (a 30-fold zero eigenvalue), graphs with fewer than 9 nodes (zero-padded
+    columns), a single node, an edgeless graph, and 800-atom graphs (the two-pass register layout for n > 512)."""
+    from singa_amd import graph as G
+    rs = np.random.RandomState(0)
+    graphs = []
+    n = 300
+    graphs.append((n, _sym_edges([(i, i + 1) for i in range(n - 1)])))                                   # path
+    n = 470
+    graphs.append((n, _sym_edges([(i, (i + 1) % n) for i in range(n)] + [(i, (i * 7 + 3) % n) for i in range(0, n, 5)])))
+    n = 240
+    graphs.append((n, _sym_edges([(8 * c + i, 8 * c + i + 1) for c in range(30) for i in range(7)])))    # 30 components
+    graphs.append((5, _sym_edges([(0, 1), (1, 2), (3, 4)])))
+    graphs.append((1, np.zeros((2, 0), np.int64)))
+    graphs.append((12, np.zeros((2, 0), np.int64)))
+    graphs.append((9, _sym_edges([(i, i + 1) for i in range(8)])))
+    for big in (False, True):
+        gs = list(graphs)
+        if big:
+            n = 800
+            pairs = [(i, i + 1) for i in range(n - 1)] + [(int(a), int(b)) for a, b in rs.randint(0, n, (400, 2)) if a != b]
+            gs = [(n, _sym_edges(pairs)), gs[0], gs[3]]
+        off, eis, batch = 0, [], []
+        for gi, (n, ei) in enumerate(gs):
+            eis.append(ei + off)
+            batch += [gi] * n
+            off += n
+        ei = torch.tensor(np.concatenate(eis, 1), device=DEV)
+        bt = torch.tensor(batch, device=DEV)
+        pe = G.laplacian_pe_batched(ei, bt, len(gs)).cpu().double().numpy()
+        assert pe.shape == (off, 8) and np.isfinite(pe).all()
+        off = 0
+        for n, e in gs:
+            v = pe[off:off + n]
+            off += n
+            lap = _lap_np(e, n)
+            w = np.linalg.eigvalsh(lap)
+            kk = min(8, n - 1)
+            assert np.abs(v[:, kk:]).max(initial=0.0) == 0.0                      # columns the graph is too small for
+            if kk == 0:
+                continue
+            v = v[:, :kk]
+            assert np.abs(v.T @ v - np.eye(kk)).max() < 2e-6, n
+            ritz = v.T @ lap @ v
+            assert np.abs(lap @ v - v @ ritz).max() < 2e-6, n
+            assert np.abs(np.linalg.eigvalsh(ritz) - w[1:kk + 1]).max() < 2e-6, n
+            assert (v.max(0) >= (-v).max(0) - 1e-6).all()

@@ -10,12 +10,12 @@ from singa_amd.config import load_config
 from singa_amd.engine import TrainStep
 from singa_amd.model.GAN import SINGA
 from singa_amd.optim import Adam
-wl = dict(G.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg3_b128_l4"]); n = wl.pop("n_graphs"); L = wl.pop("lmax")
+L, wl, ids, _ = G.resolve_workload(sys.argv[1] if len(sys.argv) > 1 else "cfg3_b128_l4"); n = len(ids)
 cfg = load_config(lmax=L); torch.manual_seed(0)
 model = SINGA(cfg, device="cuda").train()
 model.model.overlap_encoders = False
 eng = TrainStep(model, Adam(model.parameters(), lr=1e-4), None, use_graph=False)
-batch = G.synthetic_batch(n, **wl).to("cuda")
+batch = G.synthetic_batch(n, ids=ids, **wl).to("cuda")
 for _ in range(3): eng.step(batch)
 torch.cuda.synchronize()
 model.prepare(batch)
@@ -59,5 +59,5 @@ for e in evs:
     cnt[s] += len(e.kernels); tim[s] += sum(k.duration for k in e.kernels)
 tot = sum(cnt.values())
 print(f"{tot} launches attributed")
-for s, c in cnt.most_common(70):
+for s, c in cnt.most_common(140):
     print(f"{c:5d} launches {tim[s] / 1e3:8.3f} ms  {s}")
