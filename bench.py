@@ -53,6 +53,8 @@ def parse():
                     help="different resident batches cycled through the timed steps (ragged sizes -> padded / bucketed replay; "
                          "1 = the same batch every step)")
     ap.add_argument("--growth", type=float, default=1.04, help="width of a size class of the bucketed replay")
+    ap.add_argument("--lap-pe-resident", action="store_true",
+                    help="keep the Laplacian encodings made at generation time instead of recomputing them inside every step")
     ap.add_argument("--roofline-steps", type=int, default=2, help="instrumented eager steps after the timed region")
     ap.add_argument("--cpu-graphs", type=int, default=8, help="graphs in the bounded CPU-oracle sample")
     ap.add_argument("--cpu-graphs-1t", type=int, default=2, help="graphs of the one-thread CPU-oracle figure (0 = skip)")
@@ -404,10 +406,17 @@ def main():
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
     D = max(1, args.distinct_batches)
+    bucket_mode = (not args.eager) and D > 1
 
     def make_batches(ids, stride, count):
-        """`count` different batches of the graphs `ids` (batch k: ids + k * stride), resident in HBM."""
-        return [G.synthetic_batch(len(ids), ids=[i + k * stride for i in ids], **kw).to(dev) for k in range(count)]
+        """`count` different batches of the graphs `ids` (batch k: ids + k * stride), resident in HBM.  Their Laplacian
+        positional encodings are recomputed by every step that takes them (`lap_pe_in_step`: the reference runs dgl.lap_pe
+        inside forward, GAN.py:71,77) - with the library's eigensolver, in the step's preparation phase."""
+        out = [G.synthetic_batch(len(ids), ids=[i + k * stride for i in ids], **kw).to(dev) for k in range(count)]
+        if bucket_mode and not args.lap_pe_resident:
+            for b in out:
+                b.extras["lap_pe_in_step"] = True
+        return out
 
     # ---- this rank's graphs (resident in HBM before the timed region starts)
     if scaling == "strong" and world > 1:
@@ -624,8 +633,10 @@ def main():
                           "captures_in_timed_region": captures_timed,
                           "prepare": "in step" if args.no_prefetch else "prefetched on a second stream during the previous step",
                           "prepare_ms_of_step": round(prepare_ms, 2), "lap_pe_ms": round(lap_pe_ms, 2),
-                          "lap_pe": "Laplacian PE of one batch (both node types) by graph.laplacian_pe_batched, timed on its own; "
-                                    "the bench batches carry theirs from generation time",
+                          "lap_pe": ("recomputed inside every step (preparation phase, prefetch stream) by the library's batched "
+                                     "eigensolver singa_lap_eig; lap_pe_ms = the same computation timed on its own"
+                                     if bucket_mode and not args.lap_pe_resident else
+                                     "carried by the batches from generation time; lap_pe_ms = graph.laplacian_pe_batched timed on its own"),
                           "graph_captures": engine.captures,
                           "grad_allreduce_bytes": reducer.payload_bytes},
                "final_loss": round(final_loss, 5), "roofline": roof}

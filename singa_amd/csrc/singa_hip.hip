@@ -3152,6 +3152,14 @@ struct GemmBatch {
 // Epilogue: an accumulator holds 4 consecutive ROWS of one column per register quad, so a direct store is 64 dword stores
 // per lane; instead each wavefront passes its 32-row blocks through LDS (the K-loop buffers are free by then) and writes
 // float4 rows - 4x fewer store instructions, full 256-byte row segments.
+#ifndef SINGA_GEMM_PIPE
+#define SINGA_GEMM_PIPE 1
+#endif
+#if SINGA_GEMM_PIPE   // the 128 x 128 tile takes the interleaved issue order (`pipeline` below) instead of the three fenced phases
+#define SINGA_GEMM_FENCE() do { if constexpr (CFG != 0) __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SINGA_GEMM_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 template <bool A_RC, bool B_RC, int CFG>
 __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
     constexpr int BM = CFG == 2 ? 32 : (CFG == 3 ? 64 : 128), BN = CFG == 1 ? 32 : (CFG == 3 ? 64 : 128), BK = 32, PR = BK + 4;
@@ -3343,6 +3351,40 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
     // may not move anything across the marks: only then does the compiler wait with a COUNT (the older set's loads) before
     // the LDS writes instead of vmcnt(0), i.e. only then are two steps of loads really in flight.  (With `if (st + 2 <
     // nsteps) load` inside one loop it issued vmcnt(0) at every join and hoisted the LDS writes above the new loads.)
+    // Issue order of one steady-state K step of the 128 x 128 tile (SINGA_GEMM_PIPE): the step's 8 global loads, its LDS
+    // fragment reads and its 8 LDS writes are spread BETWEEN the 64 MFMAs instead of standing in front of and behind them.
+    // An MFMA occupies the matrix core for 64 cycles while the wavefront goes on issuing: with the three phases fenced off
+    // (load | 64 MFMAs | store) a wavefront issued no MFMA during ~15 % of a step and the pipe only stayed busy when the
+    // CU's second workgroup happened to be in its MFMA phase (MFMA-busy 0.75).  Groups (llvm.amdgcn.sched.group.barrier):
+    // k-group 0: 2 MFMA + 1 load, 8 times, with the fragment reads of k-group 1 among them; k-groups 1, 2: 16 MFMAs with
+    // the next group's fragment reads; k-group 3: 2 MFMA + 1 LDS write, 8 times.
+    auto pipeline = [&]() {
+#if SINGA_GEMM_PIPE
+        if constexpr (CFG == 0) {
+            constexpr int DSR = (A_RC ? MT : 4 * MT) + (B_RC ? NT : 4 * NT);      // fragment reads per k-group
+            constexpr int MF = 0x008, VM = 0x020, DR = 0x100, DW = 0x200;
+            __builtin_amdgcn_sched_group_barrier(DR, DSR, 0);                      // k-group 0's fragments first
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(MF, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(VM, 1, 0);
+                if (i % 2 == 1) __builtin_amdgcn_sched_group_barrier(DR, DSR / 4, 0);
+            }
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(MF, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(DR, DSR / 4, 0);
+                }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                __builtin_amdgcn_sched_group_barrier(MF, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(DW, 1, 0);
+            }
+        }
+#endif
+    };
     auto k_loop = [&](auto all_c) {
         unsigned ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;
         if (nsteps > 0) {
@@ -3358,16 +3400,18 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
         if (nsteps > 3) __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0) only
         for (; st + 3 < nsteps; st += 2) {
             load_ab(all_c, ra0, rb0, ma0, mb0, r_begin + (st + 2) * BK);
-            __builtin_amdgcn_sched_barrier(0);
+            SINGA_GEMM_FENCE();
             compute(0, 4);
-            __builtin_amdgcn_sched_barrier(0);
+            SINGA_GEMM_FENCE();
             store_ab(ra1, rb1, ma1, mb1, 1);
+            pipeline();
             __syncthreads();
             load_ab(all_c, ra1, rb1, ma1, mb1, r_begin + (st + 3) * BK);
-            __builtin_amdgcn_sched_barrier(0);
+            SINGA_GEMM_FENCE();
             compute(1, 4);
-            __builtin_amdgcn_sched_barrier(0);
+            SINGA_GEMM_FENCE();
             store_ab(ra0, rb0, ma0, mb0, 0);
+            pipeline();
             __syncthreads();
         }
 #endif

@@ -125,8 +125,12 @@ class TrainStep:
         if "pad" in batch.extras and "sig" in batch.extras["pad"]:
             return batch
         B = batch.num_graphs
+        # the Laplacian positional encoding (reference: dgl.lap_pe inside forward, GAN.py:71,77): computed here, i.e. inside
+        # the step (on the prefetch stream when the batch was prefetched), for batches that do not carry one - and again on
+        # every arrival for batches marked `lap_pe_in_step` (bench.py: resident batches cycled through the timed steps must
+        # not keep the encoding of their previous visit)
         for nt, et in ((PA, E_PP), (LA, E_LL)):
-            if "lap_pe" not in batch[nt]:
+            if "lap_pe" not in batch[nt] or batch.extras.get("lap_pe_in_step"):
                 batch[nt]["lap_pe"] = G.laplacian_pe_batched(batch[et]["edge_index"], batch[nt]["batch"], B,
                                                              self.model.config.model.encoder.lap_dim)
         # Several ranks: sizes, layout widths and kNN edge counts are agreed with a MAX over the ranks (a few integers over

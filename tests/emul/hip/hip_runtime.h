@@ -5,6 +5,7 @@
 // sequentially and abort here; they are covered by the -m gpu tests.
 #pragma once
 #define SINGA_EMUL 1
+#define SINGA_GEMM_PIPE 0
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
