@@ -338,14 +338,16 @@ int singa_so3_skinny_reduce(const float* small, const float* big, float* part, i
                             void* stream);
 
 /* n2 - Laplacian positional encoding (reference model/CProMG.py:562-571 `lap_pe` -> dgl.lap_pe(g, k), called inside forward
- * at model/GAN.py:71,77): for each of B graphs the kout (<= 8) eigenvectors after the smallest of its dense symmetric
- * matrix A[b] (fp64, [ld, ld] row-major, only the leading nnodes[b] x nnodes[b] block is used and DESTROYED), entry of
- * largest magnitude made positive, written as fp32 rows out[first[b] + i, 0..kout-1]; graphs with fewer than kout + 1
- * nodes get zero columns.  work: singa_lap_eig_work(B, ld) doubles.  ld <= 1016.  One workgroup per graph: Householder
- * tridiagonalisation, Sturm multi-section, inverse iteration, back-transformation. */
-int singa_lap_eig_work(int B, int ld);
-int singa_lap_eig(double* A, const int32_t* nnodes, const int32_t* first, double* work, float* out, int B, int ld, int kout,
-                  void* stream);
+ * at model/GAN.py:71,77): for each of B graphs the kout (<= 8) eigenvectors after the smallest of its normalised Laplacian
+ * I - D^-1/2 A D^-1/2 (A[src, dst] = 1 for every edge, repeats count once; D = in-degree clipped at 1; symmetrised), entry
+ * of largest magnitude made positive, written as fp32 rows out[first[b] + i, 0..kout-1]; graphs with fewer than kout + 1
+ * atoms get zero columns.  Edges: esrc / edst are LOCAL atom indices (0 .. nnodes[b] - 1), grouped by graph, graph b owning
+ * eptr[b] .. eptr[b+1] - 1.  A: [B, ld, ld] doubles of scratch (ld >= max nnodes, <= 896; not initialised by the caller),
+ * work: singa_lap_pe_work(B, ld) doubles.  One workgroup per graph; all O(n^3) work is per connected component (Householder
+ * tridiagonalisation, Sturm multi-section, inverse iteration, back-transformation). */
+int singa_lap_pe_work(int B, int ld);
+int singa_lap_pe(double* A, const int32_t* esrc, const int32_t* edst, const int32_t* eptr, const int32_t* nnodes, const int32_t* first,
+                 double* work, float* out, int B, int ld, int kout, void* stream);
 
 /* Total 2-norm of all gradients over the same (tensor, chunk) table as singa_adam_step: torch.nn.utils.clip_grad_norm_'s
  * norm (reference train.py:126), deterministic and HIP-graph replayable.  partial: nchunks floats of scratch; out: 1 float. */

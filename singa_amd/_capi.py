@@ -87,8 +87,8 @@ _SIGS = {
     "singa_so3_skinny_reduce": ([P, P, P, I32, I32, I32, I32, I32, P], I32),
     "singa_colsum_multi_work": ([C.c_longlong, I32], C.c_longlong),
     "singa_colsum_multi": ([I32, P, P, P, P, P, I32, P, P, P, C.c_longlong, P], I32),
-    "singa_lap_eig_work": ([I32, I32], I32),
-    "singa_lap_eig": ([P, P, P, P, P, I32, I32, I32, P], I32),
+    "singa_lap_pe_work": ([I32, I32], I32),
+    "singa_lap_pe": ([P] * 8 + [I32, I32, I32, P], I32),
     "singa_adam_step": ([P, P, P, P, P, P, P, I32, I32, P, P, F32, F32, F32, P], I32),
     "singa_grad_norm": ([P, P, P, P, I32, I32, P, P, P], I32),
     "singa_gemm_f32": ([C.POINTER(Gemm), I32, I32, I32, I32, P], I32),

@@ -3156,7 +3156,7 @@ struct GemmBatch {
 #define SINGA_GEMM_PIPE 1
 #endif
 #if SINGA_GEMM_PIPE   // the 128 x 128 tile takes the interleaved issue order (`pipeline` below) instead of the three fenced phases
-#define SINGA_GEMM_FENCE() do { if constexpr (CFG != 0) __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SINGA_GEMM_FENCE() do { if constexpr (CFG != 0 || !decltype(all_c)::value) __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SINGA_GEMM_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
@@ -3282,13 +3282,13 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
         for (int j = 0; j < n; ++j)
             *reinterpret_cast<float4*>(S + (rq + rows * j) * pitch + 4 * c4) = (mask >> j) & 1u ? reg[j] : make_float4(0.f, 0.f, 0.f, 0.f);
     };
-    auto load_ab = [&](auto all_c, float4* ra, float4* rb, unsigned& ma, unsigned& mb, long long r0) {
+    auto load_ab = [&](auto all_c, float4* ra, float4* rb, unsigned& ma, unsigned& mb, long long r0) __attribute__((always_inline)) {
         if (A_RC) load_rc(all_c, ra, ma, arow, P.A, NA, r0);
         else load_oc(all_c, ra, ma, P.A, P.lda, P.a_group, P.a_gld, i0, P.I, NA, BM / 4, r0);
         if (B_RC) load_rc(all_c, rb, mb, brow, P.B, NB, r0);
         else load_oc(all_c, rb, mb, P.B, P.ldb, P.b_group, P.b_gld, j0, P.J, NB, BN / 4, r0);
     };
-    auto store_ab = [&](const float4* ra, const float4* rb, unsigned ma, unsigned mb, int buf) {
+    auto store_ab = [&](const float4* ra, const float4* rb, unsigned ma, unsigned mb, int buf) __attribute__((always_inline)) {
         if (A_RC) store_rc(As0 + buf * SZA, ra, ma, NA);
         else store_oc(As0 + buf * SZA, ra, ma, LDA, NA, BM / 4);
         if (B_RC) store_rc(Bs0 + buf * SZB, rb, mb, NB);
@@ -3296,7 +3296,7 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
     };
     // fragments of k-group t (8 reduction indices = 4 MFMA k-steps) for the wavefront's MT / NT 32-wide blocks
     const int ia = wrow + l31, jb = wcol + l31;
-    auto frag = [&](const float* S, bool rc, int pitch, int col, int t, float (&f)[4]) {
+    auto frag = [&](const float* S, bool rc, int pitch, int col, int t, float (&f)[4]) __attribute__((always_inline)) {
         if (rc) {
             const float4 v = *reinterpret_cast<const float4*>(S + col * PR + 8 * t + 4 * half);
             f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
@@ -3316,7 +3316,17 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
 
     // nt8: k-groups of 8 reduction indices that hold data in this step (4, fewer in a ragged last step: a reduction of
     // 16 - the 16-channel side of SO3_LinearV2 - then costs 32 MFMAs per wavefront instead of 64 on zero padding)
-    auto compute = [&](int buf, int nt8) {
+    // 32-wide blocks of this wavefront's tile that lie inside the matrices: a ragged tile (the last column tile of a 560- or
+    // 160-wide output, the last row tile) issues no MFMAs for blocks that only hold padding - they would be a quarter of the
+    // work of the 160 / 192-wide conv1 outputs and an eighth of conv2's
+    unsigned blkv = 0;                                             // bit a * NT + b: block (a, b) holds at least one output
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+            blkv |= ((i0 + wrow + 32 * a < P.I) && (j0 + wcol + 32 * b < P.J) ? 1u : 0u) << (a * NT + b);
+    blkv = __builtin_amdgcn_readfirstlane(blkv);
+    auto compute = [&](auto edge_c, int buf, int nt8) __attribute__((always_inline)) {
         const float* Sa = As0 + buf * SZA;
         const float* Sb = Bs0 + buf * SZB;
         float fa[2][MT][4], fb[2][NT][4];
@@ -3339,8 +3349,14 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
 #pragma unroll
                 for (int a = 0; a < MT; ++a)
 #pragma unroll
-                    for (int b = 0; b < NT; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][a][q], fb[cur][b][q], acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < NT; ++b) {
+                        if constexpr (decltype(edge_c)::value) {
+                            if ((blkv >> (a * NT + b)) & 1u)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][a][q], fb[cur][b][q], acc[a][b], 0, 0, 0);
+                        } else {
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][a][q], fb[cur][b][q], acc[a][b], 0, 0, 0);
+                        }
+                    }
         }
     };
 
@@ -3358,9 +3374,9 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
     // CU's second workgroup happened to be in its MFMA phase (MFMA-busy 0.75).  Groups (llvm.amdgcn.sched.group.barrier):
     // k-group 0: 2 MFMA + 1 load, 8 times, with the fragment reads of k-group 1 among them; k-groups 1, 2: 16 MFMAs with
     // the next group's fragment reads; k-group 3: 2 MFMA + 1 LDS write, 8 times.
-    auto pipeline = [&]() {
+    auto pipeline = [&](auto interior_c) __attribute__((always_inline)) {
 #if SINGA_GEMM_PIPE
-        if constexpr (CFG == 0) {
+        if constexpr (CFG == 0 && decltype(interior_c)::value) {
             constexpr int DSR = (A_RC ? MT : 4 * MT) + (B_RC ? NT : 4 * NT);      // fragment reads per k-group
             constexpr int MF = 0x008, VM = 0x020, DR = 0x100, DW = 0x200;
             __builtin_amdgcn_sched_group_barrier(DR, DSR, 0);                      // k-group 0's fragments first
@@ -3385,7 +3401,8 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
         }
 #endif
     };
-    auto k_loop = [&](auto all_c) {
+    auto k_loop = [&](auto all_c) __attribute__((always_inline)) {
+        constexpr std::integral_constant<bool, !decltype(all_c)::value> edge_c{};      // ragged tiles skip padding blocks
         unsigned ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;
         if (nsteps > 0) {
             load_ab(all_c, ra0, rb0, ma0, mb0, r_begin);
@@ -3401,41 +3418,41 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
         for (; st + 3 < nsteps; st += 2) {
             load_ab(all_c, ra0, rb0, ma0, mb0, r_begin + (st + 2) * BK);
             SINGA_GEMM_FENCE();
-            compute(0, 4);
+            compute(edge_c, 0, 4);
             SINGA_GEMM_FENCE();
             store_ab(ra1, rb1, ma1, mb1, 1);
-            pipeline();
+            pipeline(all_c);
             __syncthreads();
             load_ab(all_c, ra1, rb1, ma1, mb1, r_begin + (st + 3) * BK);
             SINGA_GEMM_FENCE();
-            compute(1, 4);
+            compute(edge_c, 1, 4);
             SINGA_GEMM_FENCE();
             store_ab(ra0, rb0, ma0, mb0, 0);
-            pipeline();
+            pipeline(all_c);
             __syncthreads();
         }
 #endif
         for (; st < nsteps; st += 2) {         // the last (up to three) steps, and the tools/lab variants
 #if defined(SINGA_GEMM_LAB_NOLOAD) || defined(SINGA_GEMM_LAB_NOSYNC)   // tools/lab only: which part of a step costs what
-            compute(0, 4);
+            compute(edge_c, 0, 4);
 #ifndef SINGA_GEMM_LAB_NOSYNC
             if (st + 1 < nsteps) store_ab(ra1, rb1, ma1, mb1, 1);
             __syncthreads();
 #endif
             if (st + 1 >= nsteps) break;
-            compute(1, 4);
+            compute(edge_c, 1, 4);
 #ifndef SINGA_GEMM_LAB_NOSYNC
             if (st + 2 < nsteps) store_ab(ra0, rb0, ma0, mb0, 0);
             __syncthreads();
 #endif
 #else
             if (st + 2 < nsteps) load_ab(all_c, ra0, rb0, ma0, mb0, r_begin + (st + 2) * BK);
-            compute(0, st + 1 == nsteps ? last8 : 4);
+            compute(edge_c, 0, st + 1 == nsteps ? last8 : 4);
             if (st + 1 < nsteps) store_ab(ra1, rb1, ma1, mb1, 1);
             __syncthreads();
             if (st + 1 >= nsteps) break;
             if (st + 3 < nsteps) load_ab(all_c, ra1, rb1, ma1, mb1, r_begin + (st + 3) * BK);
-            compute(1, st + 2 == nsteps ? last8 : 4);
+            compute(edge_c, 1, st + 2 == nsteps ? last8 : 4);
             if (st + 2 < nsteps) store_ab(ra0, rb0, ma0, mb0, 0);
             __syncthreads();
 #endif
@@ -3489,23 +3506,30 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
 
 // ------------------------------------------------------------------------------------------------ n2: Laplacian eigenvectors
 // dgl.lap_pe / `lap_pe` of the reference (model/CProMG.py:562-571, called inside forward at model/GAN.py:71,77): the k
-// eigenvectors after the smallest of the normalised Laplacian I - D^-1/2 A D^-1/2 of every graph of the batch.  One workgroup
-// of 1024 threads per graph, fp64, on the dense symmetric matrix (n <= 1024 atoms: a few MB, cache resident):
-//   1. Householder tridiagonalisation in place.  Full symmetric storage, so that "column r" is read as the contiguous row r;
-//      the rank-2 update of step j and the matrix-vector product of step j + 1 are ONE pass over the trailing block (the row
-//      that defines reflector j + 1 is updated first): 16 bytes of traffic per trailing element and step, 16/3 n^3 in all.
-//      Reflector j stays in row j right of the diagonal (v[j + 1] = 1 implied ... stored), its factor in beta[j].
-//   2. the k + 1 smallest eigenvalues of the tridiagonal matrix by multi-section on the Sturm count (64 shifts per
-//      eigenvalue and round, 9 rounds: 64^9 > 2^53),
-//   3. their eigenvectors by inverse iteration (tridiagonal LU with partial pivoting, one lane per vector), with
-//      Gram-Schmidt inside clusters of close eigenvalues - a bonded pocket graph has dozens of connected components, i.e.
-//      a many-fold zero eigenvalue: any orthonormal basis of the invariant subspace is as good as the reference's (dgl draws
-//      random signs on top) -
-//   4. back-transformation through the reflectors, sign convention (entry of largest magnitude positive), fp32 output.
+// eigenvectors after the smallest of the normalised Laplacian I - D^-1/2 A D^-1/2 of every graph of the batch, from the
+// graph's edge list.  One workgroup of 1024 threads per graph, fp64, dense symmetric storage (n <= 896 atoms: a few MB,
+// cache resident), but only the diagonal blocks of the graph's CONNECTED COMPONENTS are ever touched: a bonded pocket graph
+// has dozens of components (a 45-fold zero eigenvalue is typical), and all of the O(n^3) work below is per component.
+//   0. component labels by minimum-label propagation over the edges with pointer jumping (LDS); positions = atoms sorted by
+//      (component, index); everything below works in positions, `perm` maps them back.
+//   1. the Laplacian's component blocks are built in place: zero, raw adjacency, in-degrees (clipped at 1), scaling and
+//      symmetrisation.
+//   2. Householder tridiagonalisation per component.  Full symmetric storage, so that "column r" is read as row r; the
+//      rank-2 update of step j and the matrix-vector product of step j + 1 are ONE pass over the trailing block (the row that
+//      defines reflector j + 1 is updated first): 16 bytes of traffic per trailing element and step.  Reflector j stays
+//      in row j right of the diagonal, its factor in beta[j].  Off-diagonal 0 between components.
+//   3. the k + 1 smallest eigenvalues of the (block) tridiagonal matrix by multi-section on the Sturm count (64 shifts per
+//      eigenvalue and round),
+//   4. their eigenvectors by inverse iteration (tridiagonal LU with partial pivoting, one lane per vector) with Gram-Schmidt
+//      inside clusters of close eigenvalues - any orthonormal basis of a repeated eigenvalue's invariant subspace is as
+//      good as the reference's (dgl draws random signs on top) -
+//   5. back-transformation through the reflectors, sign convention (entry of largest magnitude positive), fp32 output.
 #ifndef SINGA_EMUL      // (workgroup-cooperative: not part of the sequential CPU emulation build of tests/emul)
 template <int NQ>
-__global__ void __launch_bounds__(1024) lap_eig_kernel(double* __restrict__ Aall, const int* __restrict__ nnodes, const int* __restrict__ first,
-                                                       double* __restrict__ work, float* __restrict__ out, int ld, int kout) {
+__global__ void __launch_bounds__(1024) lap_pe_kernel(double* __restrict__ Aall, const int* __restrict__ esrc, const int* __restrict__ edst,
+                                                      const int* __restrict__ eptr, const int* __restrict__ nnodes,
+                                                      const int* __restrict__ first, double* __restrict__ work, float* __restrict__ out,
+                                                      int ld, int kout) {
     constexpr int NW = 16, KV = 9;                                 // wavefronts per workgroup; vectors computed (k + 1 <= 9)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -3519,10 +3543,17 @@ __global__ void __launch_bounds__(1024) lap_eig_kernel(double* __restrict__ Aall
     double* wb = sm + 3 * sl;             // [sl]
     double* pw = sm + 4 * sl;             // [NW][sl] per-wavefront partial products; later the vectors Z [KV][sl]
     double* red = sm + (4 + NW) * sl;     // [NW + 8] reduction scratch / broadcast scalars
+    int* label = reinterpret_cast<int*>(red + NW + 8);             // [sl] component label (smallest atom index) of an ATOM
+    int* perm = label + sl;                                        // [sl] position -> atom
+    int* cend = perm + sl;                                         // [sl] last position of the component of a POSITION
+    int* cbeg = cend + sl;                                         // [sl] first position of that component
+    int* posof = cbeg + sl;                                        // [sl] atom -> position
+    int* flag = posof + sl;                                        // [2]
     double* dd = work + (long long)g * (3 + 4 * KV) * ld;          // diagonal
     double* ee = dd + ld;                                          // off-diagonal
     double* bb = ee + ld;                                          // reflector factors
     double* lu = bb + ld;                                          // [KV][4][ld] scratch of the tridiagonal solves
+    const int e0 = eptr[g], e1 = eptr[g + 1];
 
     auto block_sum = [&](double x) -> double {
 #pragma unroll
@@ -3535,11 +3566,94 @@ __global__ void __launch_bounds__(1024) lap_eig_kernel(double* __restrict__ Aall
         for (int w = 0; w < NW; ++w) s += red[w];
         return s;
     };
-    // reflector from row `row` (columns row + 1 .. n - 1) -> vec[] (entries <= row are zero), d / e / beta of that row
-    auto reflector = [&](int row, double* vec) {
+
+    // ---- 0. connected components
+    if (tid < n) label[tid] = tid;
+    __syncthreads();
+    for (int round = 0; round < n + 2; ++round) {
+        if (tid == 0) flag[0] = 0;
+        __syncthreads();
+        for (int e = e0 + tid; e < e1; e += 1024) {
+            const int a = esrc[e], b = edst[e];
+            const int la = label[a], lb = label[b];
+            if (la < lb) { atomicMin(&label[b], la); flag[0] = 1; }
+            else if (lb < la) { atomicMin(&label[a], lb); flag[0] = 1; }
+        }
+        __syncthreads();
+        if (tid < n) {                                             // pointer jumping: labels are atom indices
+            int l = label[tid];
+            for (int h = 0; h < 4; ++h) {
+                const int l2 = label[l];
+                if (l2 >= l) break;
+                l = l2;
+            }
+            if (l < label[tid]) { atomicMin(&label[tid], l); flag[0] = 1; }
+        }
+        __syncthreads();
+        const int changed = flag[0];
+        __syncthreads();
+        if (!changed) break;
+    }
+    // positions: atoms ordered by (label, index)
+    if (tid < n) {
+        const int li = label[tid];
+        int before = 0, same_before = 0, same_after = 0;
+        for (int j = 0; j < n; ++j) {
+            const int lj = label[j];
+            before += lj < li;
+            same_before += (lj == li) & (j < tid);
+            same_after += (lj == li) & (j > tid);
+        }
+        const int pos = before + same_before;
+        perm[pos] = tid;
+        posof[tid] = pos;
+        cend[pos] = pos + same_after;
+        cbeg[pos] = before;
+        bb[pos] = 0.0;
+        ee[pos] = 0.0;
+    }
+    __syncthreads();
+    // ---- 1. the Laplacian's component blocks
+    for (int s0 = wave; s0 < n; s0 += NW) {                        // zero: wavefront per row position, lanes over the block
+        const int hi = cend[s0];
+        double* row = A + (long long)perm[s0] * ld;
+        for (int t = cbeg[s0] + lane; t <= hi; t += 64) row[perm[t]] = 0.0;
+    }
+    __syncthreads();
+    for (int e = e0 + tid; e < e1; e += 1024) A[(long long)esrc[e] * ld + edst[e]] = 1.0;      // raw adjacency (repeats count once)
+    __syncthreads();
+    double* dinv = wa;                                             // [atom]
+    if (tid < n) {                                                 // in-degree of atom tid = its raw column over the component's rows
+        const int pos = posof[tid], hi = cend[pos];
+        double deg = 0.0;
+        for (int s0 = cbeg[pos]; s0 <= hi; ++s0) deg += A[(long long)perm[s0] * ld + tid];
+        dinv[tid] = 1.0 / sqrt(deg < 1.0 ? 1.0 : deg);
+    }
+    __syncthreads();
+    for (int s0 = wave; s0 < n; s0 += NW) {                        // scaling + symmetrisation: the pair (i, j), i < j, by one lane
+        const int hi = cend[s0];
+        const int i = perm[s0];
+        const double di = dinv[i];
+        for (int t = s0 + lane; t <= hi; t += 64) {
+            const int j = perm[t];
+            if (t == s0) {
+                A[(long long)i * ld + i] = 1.0 - di * di * A[(long long)i * ld + i];
+            } else {
+                const double v = -0.5 * di * dinv[j] * (A[(long long)i * ld + j] + A[(long long)j * ld + i]);
+                A[(long long)i * ld + j] = v;
+                A[(long long)j * ld + i] = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- 2. tridiagonalisation, component by component (positions cs .. ce; nend = ce + 1)
+    // reflector from row `row` (positions row + 1 .. nend - 1) -> vec[] (other entries of the component zero)
+    auto reflector = [&](int row, int nend, double* vec) {
         double x = 0.0, sq = 0.0;
-        if (tid < n) {
-            x = tid > row ? A[(long long)row * ld + tid] : 0.0;
+        const long long prow = (long long)perm[row] * ld;
+        if (tid > row && tid < nend) {
+            x = A[prow + perm[tid]];
             if (tid > row + 1) sq = x * x;
         }
         const double sigma = block_sum(sq);
@@ -3552,15 +3666,15 @@ __global__ void __launch_bounds__(1024) lap_eig_kernel(double* __restrict__ Aall
             v0 = alpha <= 0.0 ? alpha - mu : -sigma / (alpha + mu);
             b = 2.0 * v0 * v0 / (sigma + v0 * v0);
         }
-        if (tid < n) {
+        if (tid >= row && tid < nend) {
             double v = 0.0;
             if (tid == row + 1) v = 1.0;
             else if (tid > row + 1) v = sigma != 0.0 ? x / v0 : 0.0;
             vec[tid] = v;
-            if (tid > row) A[(long long)row * ld + tid] = v;       // the reflector replaces the row it came from
+            if (tid > row) A[prow + perm[tid]] = v;                // the reflector replaces the row it came from
         }
         if (tid == 0) {
-            dd[row] = A[(long long)row * ld + row];
+            dd[row] = A[prow + perm[row]];
             ee[row] = mu;
             bb[row] = b;
             red[NW + 1] = b;
@@ -3568,33 +3682,36 @@ __global__ void __launch_bounds__(1024) lap_eig_kernel(double* __restrict__ Aall
         __syncthreads();
         return red[NW + 1];
     };
-    // one pass over the trailing block rows / columns >= lo: a -= vu[c] wu[r] + wu[c] vu[r] (if upd), then p[r] += a vn[c]
-    // (if acc); the wave partials of p end up in pw
-    auto pass = [&](int lo, bool upd, const double* vu, const double* wu, bool acc, const double* vn) {
-        // the lane's own entries of the update vectors: registers for graphs of up to 512 nodes, LDS reads beyond (1024
-        // threads leave 128 registers per lane)
+    // one pass over the trailing block positions lo .. nend - 1: a -= vu[c] wu[r] + wu[c] vu[r] (if upd), then
+    // p[r] += a vn[c] (if acc); the wave partials of p end up in pw
+    auto pass = [&](int lo, int nend, bool upd, const double* vu, const double* wu, bool acc, const double* vn) {
         constexpr int NR = NQ <= 8 ? NQ : 1;
         double pacc[NQ], vr[NR], wr[NR];
+        int pr[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) pacc[q] = 0.0;
+        for (int q = 0; q < NQ; ++q) {
+            const int r = lo + lane + 64 * q;
+            pacc[q] = 0.0;
+            pr[q] = r < nend ? perm[r] : 0;
+        }
 #pragma unroll
         for (int q = 0; q < NR; ++q) {
             const int r = lo + lane + 64 * q;
-            vr[q] = (upd && r < n) ? vu[r] : 0.0;
-            wr[q] = (upd && r < n) ? wu[r] : 0.0;
+            vr[q] = (upd && r < nend) ? vu[r] : 0.0;
+            wr[q] = (upd && r < nend) ? wu[r] : 0.0;
         }
-        for (int c = lo + wave; c < n; c += NW) {
+        for (int c = lo + wave; c < nend; c += NW) {
             const double vc = upd ? vu[c] : 0.0, wc = upd ? wu[c] : 0.0, nc = acc ? vn[c] : 0.0;
-            double* row = A + (long long)c * ld;
+            double* row = A + (long long)perm[c] * ld;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int r = lo + lane + 64 * q;
-                if (r < n) {
-                    double a = row[r];
+                if (r < nend) {
+                    double a = row[pr[q]];
                     if (upd) {
                         if constexpr (NQ <= 8) a -= vc * wr[q] + wc * vr[q];
                         else a -= vc * wu[r] + wc * vu[r];
-                        row[r] = a;
+                        row[pr[q]] = a;
                     }
                     pacc[q] += a * nc;
                 }
@@ -3604,54 +3721,58 @@ __global__ void __launch_bounds__(1024) lap_eig_kernel(double* __restrict__ Aall
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const int r = lo + lane + 64 * q;
-                if (r < n) pw[wave * sl + r] = pacc[q];
+                if (r < nend) pw[wave * sl + r] = pacc[q];
             }
         }
         __syncthreads();
     };
-    // w = b p - (b / 2) (b p . v) v with p = sum of the wave partials (entries >= lo)
-    auto finish_w = [&](int lo, double b, const double* vec, double* wout) {
+    // w = b p - (b / 2) (b p . v) v with p = sum of the wave partials (positions lo .. nend - 1)
+    auto finish_w = [&](int lo, int nend, double b, const double* vec, double* wout) {
         double p = 0.0, pv = 0.0;
-        if (tid >= lo && tid < n) {
+        if (tid >= lo && tid < nend) {
 #pragma unroll
             for (int w = 0; w < NW; ++w) p += pw[w * sl + tid];
             p *= b;
             pv = p * vec[tid];
         }
         const double gam = 0.5 * b * block_sum(pv);
-        if (tid < n) wout[tid] = (tid >= lo) ? p - gam * vec[tid] : 0.0;
+        if (tid >= lo && tid < nend) wout[tid] = p - gam * vec[tid];
         __syncthreads();
     };
-
-    // ---- 1. tridiagonalisation
-    if (n >= 3) {
-        double b = reflector(0, vb);
-        pass(1, false, nullptr, nullptr, true, vb);
-        finish_w(1, b, vb, wb);
-        for (int j = 0; j + 2 < n; ++j) {
-            double* t = va; va = vb; vb = t;
-            t = wa; wa = wb; wb = t;
-            const int row = j + 1;
-            // row j + 1 gets its update first: it defines the next reflector
-            if (tid >= row && tid < n) A[(long long)row * ld + tid] -= va[row] * wa[tid] + wa[row] * va[tid];
-            __syncthreads();
-            const bool more = row + 2 < n;
-            double bn = 0.0;
-            if (more) bn = reflector(row, vb);
-            pass(row + 1, true, va, wa, more, vb);
-            if (more) finish_w(row + 1, bn, vb, wb);
+    for (int cs = 0; cs < n;) {
+        const int ce = cend[cs], nend = ce + 1, m = nend - cs;
+        if (m >= 3) {
+            double b = reflector(cs, nend, vb);
+            pass(cs + 1, nend, false, nullptr, nullptr, true, vb);
+            finish_w(cs + 1, nend, b, vb, wb);
+            for (int j = cs; j + 2 < nend; ++j) {
+                double* t = va; va = vb; vb = t;
+                t = wa; wa = wb; wb = t;
+                const int row = j + 1;
+                // row j + 1 gets its update first: it defines the next reflector
+                if (tid >= row && tid < nend) A[(long long)perm[row] * ld + perm[tid]] -= va[row] * wa[tid] + wa[row] * va[tid];
+                __syncthreads();
+                const bool more = row + 2 < nend;
+                double bn = 0.0;
+                if (more) bn = reflector(row, nend, vb);
+                pass(row + 1, nend, true, va, wa, more, vb);
+                if (more) finish_w(row + 1, nend, bn, vb, wb);
+            }
         }
-    }
-    if (tid == 0) {
-        if (n >= 2) {
-            dd[n - 2] = A[(long long)(n - 2) * ld + n - 2];
-            ee[n - 2] = A[(long long)(n - 2) * ld + n - 1];
+        if (tid == 0) {
+            if (m >= 2) {
+                dd[nend - 2] = A[(long long)perm[nend - 2] * ld + perm[nend - 2]];
+                ee[nend - 2] = A[(long long)perm[nend - 2] * ld + perm[nend - 1]];
+                bb[nend - 2] = 0.0;
+            }
+            dd[nend - 1] = A[(long long)perm[nend - 1] * ld + perm[nend - 1]];
+            ee[nend - 1] = 0.0;                                    // no coupling across the component boundary
+            bb[nend - 1] = 0.0;
         }
-        dd[n - 1] = A[(long long)(n - 1) * ld + n - 1];
-        if (n >= 2) ee[n - 1] = 0.0;
+        __syncthreads();
+        cs = nend;
     }
-    __syncthreads();
-    // ---- 2. eigenvalues 0 .. m - 1 of the tridiagonal matrix (d, e): multi-section on the Sturm count
+    // ---- 3. eigenvalues 0 .. m - 1 of the tridiagonal matrix (d, e): multi-section on the Sturm count
     const int m = n < KV ? n : KV;
     double* td = va;                       // diagonal and squared off-diagonal in LDS
     double* te2 = wa;
@@ -3664,7 +3785,7 @@ __global__ void __launch_bounds__(1024) lap_eig_kernel(double* __restrict__ Aall
         gl = d - el - er;
         gu = d + el + er;
     }
-    {   // Gershgorin bounds (block min / max through the sum helper's scratch)
+    {   // Gershgorin bounds
         double lo = tid < n ? gl : 1e300, hi = tid < n ? gu : -1e300;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
@@ -3718,7 +3839,7 @@ __global__ void __launch_bounds__(1024) lap_eig_kernel(double* __restrict__ Aall
         if (tid < m) lam[tid] = 0.5 * (pw[tid] + pw[KV + tid]);
         __syncthreads();
     }
-    // ---- 3. inverse iteration, one lane per vector; Z[k] in LDS (pw region)
+    // ---- 4. inverse iteration, one lane per vector; Z[k] in LDS (pw region), indexed by position
     double tnorm = 0.0;
     {
         double t = tid < n ? fmax(fabs(td[tid]), sqrt(te2[tid])) : 0.0;
@@ -3731,7 +3852,7 @@ __global__ void __launch_bounds__(1024) lap_eig_kernel(double* __restrict__ Aall
         __syncthreads();
     }
     const double eps = 2.220446049250313e-16, tiny = eps * (tnorm > 0.0 ? tnorm : 1.0);
-    double* Z = pw;                         // [KV][ld] (the eigenvalue intervals / counts kept there are dead now)
+    double* Z = pw;                         // [KV][sl] (the eigenvalue intervals / counts kept there are dead now)
     if (tid < m) vb[tid] = lam[tid];         // shifts; separated inside clusters below (LAPACK dstein does the same)
     __syncthreads();
     if (tid == 0) {
@@ -3743,8 +3864,9 @@ __global__ void __launch_bounds__(1024) lap_eig_kernel(double* __restrict__ Aall
     __syncthreads();
     for (int r = tid; r < m * sl; r += 1024) {
         const int k = r / sl, i = r - k * sl;
-        // deterministic start vectors in (-1, 1)
-        unsigned h = (unsigned)(i * 2654435761u) ^ (unsigned)((k + 1) * 40503u * 2246822519u);
+        // deterministic start vectors in (-1, 1), tied to the ATOM (not to its position)
+        const int at = i < n ? perm[i] : 0;
+        unsigned h = (unsigned)(at * 2654435761u) ^ (unsigned)((k + 1) * 40503u * 2246822519u);
         h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
         Z[r] = i < n ? ((double)(h & 0xFFFFFF) / 8388608.0 - 1.0) : 0.0;
     }
@@ -3753,7 +3875,7 @@ __global__ void __launch_bounds__(1024) lap_eig_kernel(double* __restrict__ Aall
         if (tid < m) {
             const int k = tid;
             const double shift = vb[k];
-            double* dl = lu + (long long)(k * 4 + 0) * ld;      // sub-diagonal (multipliers after elimination are not kept)
+            double* dl = lu + (long long)(k * 4 + 0) * ld;      // sub-diagonal
             double* dg = lu + (long long)(k * 4 + 1) * ld;      // diagonal
             double* du = lu + (long long)(k * 4 + 2) * ld;      // first super-diagonal
             double* d2 = lu + (long long)(k * 4 + 3) * ld;      // second super-diagonal (pivoting fill-in)
@@ -3812,19 +3934,21 @@ __global__ void __launch_bounds__(1024) lap_eig_kernel(double* __restrict__ Aall
             __syncthreads();
         }
     }
-    // ---- 4. back-transformation x = H_0 H_1 .. H_{n-3} y: one wavefront per vector, reflectors from the matrix rows
-    if (n >= 3 && wave < m) {
+    // ---- 5. back-transformation x = H_0 H_1 .. y: one wavefront per vector; reflector j lives in row perm[j], positions
+    // j + 1 .. cend[j] of its component
+    if (wave < m) {
         double* x = Z + wave * sl;
         for (int j = n - 3; j >= 0; --j) {
             const double b = bb[j];
             if (b == 0.0) continue;
-            const double* v = A + (long long)j * ld;
+            const double* v = A + (long long)perm[j] * ld;
+            const int hi = cend[j];
             double s = 0.0;
-            for (int r = j + 1 + lane; r < n; r += 64) s += v[r] * x[r];
+            for (int r = j + 1 + lane; r <= hi; r += 64) s += v[perm[r]] * x[r];
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
             s *= b;
-            for (int r = j + 1 + lane; r < n; r += 64) x[r] -= s * v[r];
+            for (int r = j + 1 + lane; r <= hi; r += 64) x[r] -= s * v[perm[r]];
         }
     }
     __syncthreads();
@@ -3836,26 +3960,27 @@ __global__ void __launch_bounds__(1024) lap_eig_kernel(double* __restrict__ Aall
             continue;
         }
         const double* x = Z + k * sl;
-        // entry of largest magnitude (first one on ties): value packed with its index for a max reduction
+        // entry of largest magnitude (the lowest atom index on ties)
         double best = tid < n ? fabs(x[tid]) : -1.0;
-        int bi = tid;
+        int bi = tid < n ? perm[tid] : (1 << 30), bp = tid;
 #pragma unroll
         for (int oo = 32; oo > 0; oo >>= 1) {
             const double ob = __shfl_xor(best, oo, 64);
-            const int oi = __shfl_xor(bi, oo, 64);
-            if (ob > best || (ob == best && oi < bi)) best = ob, bi = oi;
+            const int oi = __shfl_xor(bi, oo, 64), op = __shfl_xor(bp, oo, 64);
+            if (ob > best || (ob == best && oi < bi)) best = ob, bi = oi, bp = op;
         }
         __syncthreads();
-        if (lane == 0) red[wave] = best, reinterpret_cast<int*>(red + NW)[wave] = bi;
+        int* redi = reinterpret_cast<int*>(red + NW);
+        if (lane == 0) red[wave] = best, redi[wave] = bi, redi[NW + wave] = bp;
         __syncthreads();
-        best = red[0], bi = reinterpret_cast<int*>(red + NW)[0];
+        best = red[0], bi = redi[0], bp = redi[NW];
         for (int w = 1; w < NW; ++w) {
             const double ob = red[w];
-            const int oi = reinterpret_cast<int*>(red + NW)[w];
-            if (ob > best || (ob == best && oi < bi)) best = ob, bi = oi;
+            const int oi = redi[w];
+            if (ob > best || (ob == best && oi < bi)) best = ob, bi = oi, bp = redi[NW + w];
         }
-        const double sg = x[bi] < 0.0 ? -1.0 : 1.0;
-        if (tid < n) o[(long long)tid * kout + k - 1] = (float)(sg * x[tid]);
+        const double sg = x[bp] < 0.0 ? -1.0 : 1.0;
+        if (tid < n) o[(long long)perm[tid] * kout + k - 1] = (float)(sg * x[tid]);
         __syncthreads();
     }
 }
@@ -4438,30 +4563,31 @@ int singa_so3_skinny_reduce(const float* small, const float* big, float* part, i
     return check_launch("so3_skinny_reduce");
 }
 
-int singa_lap_eig_work(int B, int ld) { return (B < 0 || ld < 0) ? 0 : B * (3 + 4 * 9) * ld; }
+int singa_lap_pe_work(int B, int ld) { return (B < 0 || ld < 0) ? 0 : B * (3 + 4 * 9) * ld; }
 
-int singa_lap_eig(double* A, const int32_t* nnodes, const int32_t* first, double* work, float* out, int B, int ld, int kout,
-                  void* stream) {
-    if (!A || !nnodes || !first || !work || !out) return fail(SINGA_E_NULL, "lap_eig: null pointer");
-    if (kout < 1 || kout > 8) return fail(SINGA_E_SHAPE, "lap_eig: 1..8 eigenvectors");
-    if (ld < 1 || ld > 1016) return fail(SINGA_E_SHAPE, "lap_eig: graphs of up to 1016 nodes (20 vectors of LDS per graph)");
+int singa_lap_pe(double* A, const int32_t* esrc, const int32_t* edst, const int32_t* eptr, const int32_t* nnodes, const int32_t* first,
+                 double* work, float* out, int B, int ld, int kout, void* stream) {
+    if (!A || !esrc || !edst || !eptr || !nnodes || !first || !work || !out) return fail(SINGA_E_NULL, "lap_pe: null pointer");
+    if (kout < 1 || kout > 8) return fail(SINGA_E_SHAPE, "lap_pe: 1..8 eigenvectors");
+    if (ld < 1 || ld > 896) return fail(SINGA_E_SHAPE, "lap_pe: graphs of up to 896 atoms (22.5 vectors of LDS per graph)");
     if (B <= 0) return SINGA_OK;
 #ifdef SINGA_EMUL
-    return fail(SINGA_E_SHAPE, "lap_eig: not part of the emulation build");
+    return fail(SINGA_E_SHAPE, "lap_pe: not part of the emulation build");
 #else
-    const size_t lds = (size_t)((4 + 16) * (ld < 32 ? 32 : ld) + 16 + 8) * sizeof(double);
+    const int sl = ld < 32 ? 32 : ld;
+    const size_t lds = (size_t)((4 + 16) * sl + 16 + 8) * sizeof(double) + (size_t)(5 * sl + 4) * sizeof(int);
     hipStream_t st = (hipStream_t)stream;
     hipError_t e;
     if (ld <= 512) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_eig_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail((int)e, "lap_eig: LDS size refused");
-        hipLaunchKernelGGL(lap_eig_kernel<8>, dim3(B), dim3(1024), lds, st, A, nnodes, first, work, out, ld, kout);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_pe_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail((int)e, "lap_pe: LDS size refused");
+        hipLaunchKernelGGL(lap_pe_kernel<8>, dim3(B), dim3(1024), lds, st, A, esrc, edst, eptr, nnodes, first, work, out, ld, kout);
     } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_eig_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail((int)e, "lap_eig: LDS size refused");
-        hipLaunchKernelGGL(lap_eig_kernel<16>, dim3(B), dim3(1024), lds, st, A, nnodes, first, work, out, ld, kout);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_pe_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail((int)e, "lap_pe: LDS size refused");
+        hipLaunchKernelGGL(lap_pe_kernel<16>, dim3(B), dim3(1024), lds, st, A, esrc, edst, eptr, nnodes, first, work, out, ld, kout);
     }
-    return check_launch("lap_eig");
+    return check_launch("lap_pe");
 #endif
 }
 

@@ -394,28 +394,34 @@ def load_reference_pt(path, with_lap=True):
 
 def laplacian_pe_batched(edge_index, batch, num_graphs, k=8):
     """laplacian_pe for every graph of a collated batch on the tensors' own device (reference
-    model/CProMG.py:562-571, called inside forward at GAN.py:71,77): dense per-graph normalised Laplacians, then - on the
-    GPU - the library's own batched symmetric eigensolver (ops.lap_eig: one workgroup per graph, Householder
-    tridiagonalisation + Sturm multi-section + inverse iteration, fp64), same sign convention as `laplacian_pe`.
-    Eigenvectors of a repeated eigenvalue (a bonded pocket graph has dozens of connected components, i.e. a many-fold zero
-    eigenvalue) are ANY orthonormal basis of that invariant subspace, as in the reference (dgl adds random signs on top).
-    CPU tensors / graphs of more than 1016 atoms: one batched torch.linalg.eigh (padding rows get a unit diagonal above
-    every real eigenvalue (<= 2), so they sort last)."""
+    model/CProMG.py:562-571, called inside forward at GAN.py:71,77).  On the GPU: the library's own batched eigensolver
+    (ops.lap_pe -> singa_lap_pe: one workgroup per graph builds the normalised Laplacian from the graph's edges and
+    diagonalises it per connected component - Householder tridiagonalisation + Sturm multi-section + inverse iteration,
+    fp64), same sign convention as `laplacian_pe`.  Eigenvectors of a repeated eigenvalue (a bonded pocket graph has dozens
+    of connected components, i.e. a many-fold zero eigenvalue) are ANY orthonormal basis of that invariant subspace, as in
+    the reference (dgl adds random signs on top).  CPU tensors / graphs of more than 896 atoms: dense Laplacians and one
+    batched torch.linalg.eigh (padding rows get a unit diagonal above every real eigenvalue (<= 2), so they sort last)."""
     dev = edge_index.device
     n = batch.numel()
     num = torch.zeros(num_graphs, dtype=torch.long, device=dev).index_add_(0, batch, torch.ones_like(batch))
     mx = int(num.max())
     start = num.cumsum(0) - num
+    gb = batch[edge_index[0]]
+    if edge_index.is_cuda and mx <= 896 and k <= 8:
+        from . import ops
+        # edges grouped by graph (a collated batch already has them so; the stable sort makes no assumption)
+        order = torch.argsort(gb, stable=True)
+        gs = gb[order]
+        src = (edge_index[0][order] - start[gs]).to(torch.int32)
+        dst = (edge_index[1][order] - start[gs]).to(torch.int32)
+        eptr = torch.searchsorted(gs, torch.arange(num_graphs + 1, device=dev)).to(torch.int32)
+        return ops.lap_pe(src, dst, eptr, num, start, n, mx, k)
     local = torch.arange(n, device=dev) - start[batch]
     a = torch.zeros(num_graphs, mx, mx, dtype=torch.float64, device=dev)
-    gb = batch[edge_index[0]]
     a[gb, local[edge_index[0]], local[edge_index[1]]] = 1.0
     dinv = a.sum(1).clamp(min=1).pow(-0.5)
     lap = torch.eye(mx, dtype=torch.float64, device=dev).unsqueeze(0) - dinv.unsqueeze(2) * a * dinv.unsqueeze(1)
     lap = 0.5 * (lap + lap.transpose(1, 2))
-    if lap.is_cuda and mx <= 1016 and k <= 8:
-        from . import ops
-        return ops.lap_eig(lap, num, start, n, k)
     pad = torch.arange(mx, device=dev).unsqueeze(0) >= num.unsqueeze(1)          # [B, mx]
     lap = lap.masked_fill(pad.unsqueeze(1) | pad.unsqueeze(2), 0.0) + torch.diag_embed(pad.double() * 3.0)
     _, v = torch.linalg.eigh(lap)

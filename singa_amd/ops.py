@@ -103,20 +103,24 @@ def edge_frames(vec, rand, stats):
     return rot
 
 
-def lap_eig(lap, num, start, n_total, k=8):
-    """n2: the k eigenvectors after the smallest of each graph's dense symmetric matrix lap[b] ([B, mx, mx] fp64, leading
-    num[b] x num[b] block; DESTROYED), entry of largest magnitude positive -> fp32 [n_total, k], graph b's rows at
-    start[b] (reference model/CProMG.py:562-571; no gradient)."""
-    if not lap.is_cuda or lap.dtype != torch.float64 or lap.dim() != 3 or lap.shape[1] != lap.shape[2]:
-        raise RuntimeError("lap_eig: a CUDA fp64 [B, mx, mx] batch of symmetric matrices")
-    lap = lap.contiguous()
-    B, mx = lap.shape[0], lap.shape[1]
-    _lib.ensure_init(lap.device.index if lap.device.index is not None else torch.cuda.current_device())
+def lap_pe(src, dst, eptr, num, start, n_total, mx, k=8):
+    """n2: Laplacian positional encoding of every graph of a batch (reference model/CProMG.py:562-571; no gradient).
+    src / dst: int32 LOCAL atom indices of the edges, grouped by graph; eptr [B + 1] the graphs' edge ranges; num [B]
+    atoms per graph; start [B] first row of each graph in the result; mx >= max(num).  -> fp32 [n_total, k]."""
+    for t in (src, dst, eptr):
+        if not t.is_cuda or t.dtype != torch.int32:
+            raise RuntimeError("lap_pe: CUDA int32 edge arrays (no CPU path)")
+    B = num.numel()
+    dev = src.device
+    _lib.ensure_init(dev.index if dev.index is not None else torch.cuda.current_device())
     lib = _lib.lib()
+    src, dst, eptr = src.contiguous(), dst.contiguous(), eptr.contiguous()
     nn, st = num.to(torch.int32).contiguous(), start.to(torch.int32).contiguous()
-    work = torch.empty(max(lib.singa_lap_eig_work(B, mx), 1), device=lap.device, dtype=torch.float64)
-    out = torch.zeros(n_total, k, device=lap.device, dtype=torch.float32)
-    _chk(lib.singa_lap_eig(_p(lap), _p(nn), _p(st), _p(work), _p(out), B, mx, k, _stream()), "singa_lap_eig")
+    scratch = torch.empty(B * mx * mx, device=dev, dtype=torch.float64)           # only the components' diagonal blocks are touched
+    work = torch.empty(max(lib.singa_lap_pe_work(B, mx), 1), device=dev, dtype=torch.float64)
+    out = torch.zeros(n_total, k, device=dev, dtype=torch.float32)
+    _chk(lib.singa_lap_pe(_p(scratch), _p(src), _p(dst), _p(eptr), _p(nn), _p(st), _p(work), _p(out), B, mx, k, _stream()),
+         "singa_lap_pe")
     return out
 
 

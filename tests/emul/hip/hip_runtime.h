@@ -80,6 +80,7 @@ static inline void __syncthreads() {
 
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define __builtin_amdgcn_sched_barrier(a) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x)
 #define __builtin_amdgcn_s_waitcnt(a) ((void)0)
 #define __builtin_amdgcn_wave_barrier() ((void)0)
 struct floatx16_emul { float v[16]; float& operator[](int i) { return v[i]; } };

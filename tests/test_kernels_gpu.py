@@ -607,6 +607,12 @@ def test_lap_eig_batched_against_numpy():
     graphs.append((1, np.zeros((2, 0), np.int64)))
     graphs.append((12, np.zeros((2, 0), np.int64)))
     graphs.append((9, _sym_edges([(i, i + 1) for i in range(8)])))
+    # repeated edges (count once) and one-directional edges (in-degree normalisation, then symmetrised)
+    one_way = np.array([[0, 1, 2, 2, 5, 6, 7, 3, 3], [1, 2, 3, 3, 6, 7, 5, 0, 0]], np.int64)
+    graphs.append((10, np.concatenate([one_way, _sym_edges([(8, 9), (8, 9), (4, 8)])], 1)))
+    # components interleaved in index order (positions != atom indices inside the kernel)
+    n = 60
+    graphs.append((n, _sym_edges([(i, i + 3) for i in range(n - 3)])))                                   # three interleaved paths
     for big in (False, True):
         gs = list(graphs)
         if big:
