@@ -252,8 +252,8 @@ int singa_s2act_sep_bwd(const singa_seg_t* x, int nseg, const float* gate, int64
  * x[N,K,C] -> y[N,K,C]; weight[L+1,C], bias[C]. */
 int singa_so3_rmsnorm_fwd(const float* x, const float* weight, const float* bias, float* y, int N, int C, int lmax,
                           float eps, void* stream);
-/* backward: gx[N,K,C]; gw_part[nparts,K,C] and gb_part[nparts,C] are per-wave partial sums the caller reduces
- * (nparts = singa_so3_rmsnorm_nparts(N)). */
+/* backward: gx[N,K,C]; gw_part[nparts,L+1,C] (already summed over the 2l+1 rows of each degree) and gb_part[nparts,C] are
+ * per-wave partial sums the caller reduces (nparts = singa_so3_rmsnorm_nparts(N)). */
 int singa_so3_rmsnorm_nparts(int N);
 int singa_so3_rmsnorm_bwd(const float* x, const float* weight, const float* gy, float* gx, float* gw_part,
                           float* gb_part, int N, int C, int lmax, float eps, void* stream);
@@ -298,7 +298,7 @@ int singa_adam_step(float* const* p, const float* const* g, float* const* m, flo
  *   64 x 64 when the launch has fewer than 384 tiles of 128 x 128.
  * Contiguous axes (of A, B and of the result: J, ldc) must be multiples of 4 floats and 16-byte aligned.  Enqueue-only
  * on `stream`. */
-#define SINGA_GEMM_MAX 8
+#define SINGA_GEMM_MAX 12
 typedef struct {
     const float* a;
     const float* b;

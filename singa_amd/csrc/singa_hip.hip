@@ -3096,11 +3096,24 @@ __global__ void __launch_bounds__(64) rmsnorm_bwd_kernel(const float* __restrict
             if (idx < KC) go[idx] = g[t];
         }
     }
-    float* wp = gw_part + (long long)blockIdx.x * KC;
+    // the affine weight is per DEGREE (EF:2114: affine_weight [L + 1, C], expanded over the 2l + 1 rows): the rows of a degree
+    // are added up here (one wavefront per workgroup: a wave barrier orders the LDS round trip), so that the partials are
+    // [nparts][(L + 1) * C] and go straight into the step's shared column-sum launch
+    __shared__ float sh[KC];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         int idx = lane + 64 * t;
-        if (idx < KC) wp[idx] = gwp[t];
+        if (idx < KC) sh[idx] = gwp[t];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): the LDS writes above have landed
+    __builtin_amdgcn_wave_barrier();
+    float* wp = gw_part + (long long)blockIdx.x * (L + 1) * C;
+    for (int idx = lane; idx < (L + 1) * C; idx += 64) {
+        const int l = idx / C, c = idx - l * C;
+        float acc = 0.f;
+        for (int k = l * l; k < (l + 1) * (l + 1); ++k) acc += sh[k * C + c];
+        wp[idx] = acc;
     }
     if (lane < C) gb_part[(long long)blockIdx.x * C + lane] = gbp;
 }

@@ -224,7 +224,8 @@ class MultiHeadAttention(nn.Module):
         W sum_e a_e (w_e*v) + b (sum_e a_e = 1).  They are therefore applied to NODE tensors, and the two per-edge
         contractions run as fused gather kernels without any [E,heads,channels] intermediate."""
         N = node_attr.size(0)
-        h_keys, h_queries, h_values = (self._grouped(c, node_attr) for c in (self.k_lin, self.q_lin, self.v_lin))
+        h_keys, h_queries, h_values = ops.grouped_linear3(node_attr, self.k_lin.weight, self.q_lin.weight, self.v_lin.weight,
+                                                          self.num_heads)
         scale = 1.0 / math.sqrt(h_keys.size(-1))
         if edges.attr.shape[1] == 64 and self.weight_k_net[0].out_features == 32 and self.weight_v_net[0].out_features == 64:
             W_k, W_v = ops.edge_mlp_pair(edges.attr, (self.weight_k_net[0], self.weight_k_net[2]),

@@ -530,11 +530,13 @@ class _SO3RMSNorm(torch.autograd.Function):
         N, K, C = x.shape
         nparts = _lib.lib().singa_so3_rmsnorm_nparts(N)
         gx = torch.empty_like(x)
-        gwp = torch.empty(nparts, K, C, device=x.device, dtype=torch.float32)
+        gwp = torch.empty(nparts, (L + 1) * C, device=x.device, dtype=torch.float32)       # already summed over each degree's rows
         gbp = torch.empty(nparts, C, device=x.device, dtype=torch.float32)
         _chk(_lib.lib().singa_so3_rmsnorm_bwd(_p(x), _p(weight), _p(gy), _p(gx), _p(gwp), _p(gbp), N, C, L, eps,
                                               _stream()), "singa_so3_rmsnorm_bwd")
-        gw = _degree_onehot(L, x.device) @ colsum(gwp)
+        gw = param_colsum(gwp, [(0, (L + 1) * C, ctx.params[0])])[0]
+        if gw is not None:
+            gw = gw.view(L + 1, C)
         return gx, gw, param_colsum(gbp, [(0, C, ctx.params[1])])[0], None, None
 
 
@@ -1429,6 +1431,84 @@ class _GroupedLinear(torch.autograd.Function):
             else:
                 gw = torch.bmm(gT.transpose(1, 2), h.view(N, heads, ig).transpose(0, 1)).view(wp.shape)
         return gh.view(N, heads * ig), gw, None
+
+
+class _GroupedLinear3(torch.autograd.Function):
+    """The three grouped 1x1 Conv1d layers of the graph attention (k_lin, q_lin, v_lin: CP:27-29, 55-57) on the SAME node
+    rows h [N, heads * ig] as ONE launch of the own MFMA GEMM (k7) with one problem per (layer, head) - h's column block
+    of the head times that head's [og, ig] weight block into the head's column block of the layer's output - instead of
+    three batched library GEMMs; backward: the three input-gradient contributions as three chained launches (each adds the
+    previous one's result in its epilogue: no separate additions) and one split-reduction launch for all weight gradients."""
+
+    @staticmethod
+    def forward(ctx, h, wk, wq, wv, heads):
+        ctx.params = (wk, wq, wv)
+        h = _rows(h)
+        ws = [_rows(w.view(w.shape[0], w.shape[1])) for w in (wk, wq, wv)]       # [heads * og, ig] (the Conv1d weight as it is)
+        _dev(h, *ws)
+        N, ig = h.shape[0], ws[0].shape[1]
+        ogs = [w.shape[0] // heads for w in ws]
+        outs = [torch.empty(N, heads, og, device=h.device, dtype=torch.float32) for og in ogs]
+        items = []
+        for w, o, og in zip(ws, outs, ogs):
+            for g in range(heads):
+                items.append(dict(a=h.data_ptr() + 4 * g * ig, lda=h.stride(0), b=w.data_ptr() + 4 * g * og * ig, ldb=ig,
+                                  c=o.data_ptr() + 4 * g * og, ldc=heads * og, I=N, J=og, R=ig))
+        if N > 0:
+            _gemm(items, True, True)
+        ctx.save_for_backward(h, *ws)
+        ctx.heads, ctx.ogs = heads, ogs
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, gk, gq, gv):
+        h, *ws = ctx.saved_tensors
+        heads, ogs = ctx.heads, ctx.ogs
+        N, ig = h.shape[0], ws[0].shape[1]
+        gs = [_rows(g.reshape(N, heads * og)) for g, og in zip((gk, gq, gv), ogs)]
+        gh = None
+        if ctx.needs_input_grad[0] and N > 0:
+            prev = None
+            for g, w, og in zip(gs, ws, ogs):                        # dh += g_layer W_layer, head by head; chained through `addend`
+                cur = torch.empty(N, heads * ig, device=h.device, dtype=torch.float32)
+                items = []
+                for hd in range(heads):
+                    items.append(dict(a=g.data_ptr() + 4 * hd * og, lda=g.stride(0), b=w.data_ptr() + 4 * hd * og * ig, ldb=ig,
+                                      c=cur.data_ptr() + 4 * hd * ig, ldc=heads * ig, I=N, J=ig, R=og,
+                                      addend=(prev.data_ptr() + 4 * hd * ig) if prev is not None else None))
+                _gemm(items, True, False)
+                prev = cur
+            gh = prev
+        elif ctx.needs_input_grad[0]:
+            gh = torch.zeros_like(h)
+        sizes = [heads * og * ig for og in ogs]
+        tot = sum(sizes)
+        if N > 0:
+            S = _tn_splits(N, max(ogs), ig)
+            part = torch.empty(S, tot, device=h.device, dtype=torch.float32)
+            items, off = [], 0
+            for g, og in zip(gs, ogs):
+                for hd in range(heads):                              # dW[layer][head] [og, ig] = g_head^T h_head
+                    items.append(dict(a=g.data_ptr() + 4 * hd * og, lda=g.stride(0), b=h.data_ptr() + 4 * hd * ig, ldb=h.stride(0),
+                                      c=part.data_ptr() + 4 * off, ldc=ig, I=og, J=ig, R=N, c_split_stride=tot))
+                    off += og * ig
+            _gemm(items, False, False, S)
+            offs = [0, sizes[0], sizes[0] + sizes[1]]
+            gws = param_colsum(part, [(o, sz, p) for o, sz, p in zip(offs, sizes, ctx.params)])
+            gws = [gw.view(p.shape) if gw is not None else None for gw, p in zip(gws, ctx.params)]
+        else:
+            gws = [torch.zeros_like(p) for p in ctx.params]
+        return gh, gws[0], gws[1], gws[2], None
+
+
+def grouped_linear3(h, wk, wq, wv, heads):
+    """(k_lin(h), q_lin(h), v_lin(h)) for grouped 1x1 Conv1d weights [heads * og, ig, 1] -> three [N, heads, og] tensors."""
+    ig = wk.shape[1]
+    ok = (h.is_cuda and ig % 4 == 0 and all((w.shape[0] // heads) % 4 == 0 and w.shape[1] == ig for w in (wk, wq, wv))
+          and 3 * heads <= 12)
+    if ok:
+        return _GroupedLinear3.apply(h, wk, wq, wv, heads)
+    return tuple(grouped_linear(h, w, heads) for w in (wk, wq, wv))
 
 
 def grouped_linear(h, w, heads=None):

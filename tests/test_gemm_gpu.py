@@ -229,3 +229,33 @@ def test_linear_and_pos_ffn_match_torch(M, K, N):
         (got * gy.to(DEV)).sum().backward()
         for a, r in zip(gin, rin):
             assert rel_err(a.grad.cpu(), r.grad) < 2e-5
+
+
+@pytest.mark.parametrize("N", [1, 333, 6499])
+def test_grouped_linear3_matches_torch(N):
+    """The graph attention's three grouped 1x1 Conv1d layers (k_lin, q_lin, v_lin: CP:27-29, 55-57) as one 12-problem launch
+    against torch's grouped conv1d in float64: outputs, the (chained) input gradient, all weight gradients."""
+    from singa_amd import ops
+    heads, ig = 4, 64
+    g = torch.Generator().manual_seed(N)
+    h = torch.randn(N, heads * ig, generator=g)
+    ws = [torch.randn(heads * og, ig, 1, generator=g) / ig ** 0.5 for og in (32, 32, 64)]
+    gys = [torch.randn(N, heads, og, generator=g) for og in (32, 32, 64)]
+    hr = h.double().requires_grad_(True)
+    wr = [w.double().requires_grad_(True) for w in ws]
+    loss = 0.0
+    refs = []
+    for w, gy in zip(wr, gys):
+        y = torch.nn.functional.conv1d(hr.t().unsqueeze(0), w, groups=heads)[0].t().reshape(N, heads, -1)
+        refs.append(y)
+        loss = loss + (y * gy.double()).sum()
+    loss.backward()
+    hd = h.to(DEV).requires_grad_(True)
+    wd = [w.to(DEV).requires_grad_(True) for w in ws]
+    outs = ops.grouped_linear3(hd, *wd, heads)
+    for o, r in zip(outs, refs):
+        assert o.shape == r.shape and rel_err(o.detach().cpu(), r.detach()) < 2e-6
+    sum((o * gy.to(DEV)).sum() for o, gy in zip(outs, gys)).backward()
+    assert rel_err(hd.grad.cpu(), hr.grad) < 1e-5
+    for a, r in zip(wd, wr):
+        assert rel_err(a.grad.cpu(), r.grad) < 1e-5
