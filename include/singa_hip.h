@@ -174,19 +174,19 @@ int singa_dec_ffn(const float* z, const float* w1_t, const float* b1, const floa
 
 /* k15c — the two per-edge MLPs of the CProMG graph attention (reference model/CProMG.py:41-48 `weight_k_net`,
  * `weight_v_net` = Linear -> ShiftedSoftplus -> Linear, applied at CP:58 and CP:68): wk[E,HK] and wv[E,HV] from
- * attr[E,CIN] in one pass on the f32 MFMA, hidden activations never stored.  All weight matrices TRANSPOSED:
- * w1t*[CIN][H] (first Linear), w2t*[H][H] (second Linear); b1*, b2* [H].  Built for CIN = 64, HK = 32, HV = 64
+ * attr[E,CIN] in one pass on the f32 MFMA, hidden activations never stored.  Weight matrices in nn.Linear's own layout:
+ * w1t* = weight[H][CIN] of the first Linear, w2t* = weight[H][H] of the second; b1*, b2* [H].  Built for CIN = 64, HK = 32, HV = 64
  * (config model.encoder: edge_channels 64, key_channels 128 / 4 heads, hidden_channels 256 / 4 heads). */
 int singa_edge_mlp_fwd(const float* attr, const float* w1tk, const float* b1k, const float* w2tk, const float* b2k,
                        const float* w1tv, const float* b1v, const float* w2tv, const float* b2v, float* wk, float* wv, int E,
                        int CIN, int HK, int HV, void* stream);
 
 /* backward of ONE of the nets of k15c (H hidden = H output units, 32 or 64): recomputes the hidden units and accumulates
- * all four parameter gradients on the MFMA.  The hidden units are handled in slices of 32 (S = H/32 slices);
- * part[singa_edge_mlp_bwd_nparts(E, H)][S][32*64 + 32 + H*32 + H] holds, per workgroup and slice s, the partial
- * [dW1[32s:32s+32, :] (rows of the first Linear's weight) | db1[32s:32s+32] | dW2[:, 32s:32s+32] ([out][32], columns of
- * the second Linear's weight) | db2 (the same in every slice)], to be reduced over the workgroups with singa_colsum.
- * w1t[CIN][H] transposed as in the forward, w2[H][H] NOT transposed. */
+ * all four parameter gradients on the MFMA.  The hidden units are handled in slices of 32 (H/32 workgroups per edge range);
+ * part[singa_edge_mlp_bwd_nparts(E, H)][H*64 + H + H*H + H] holds, per edge range, the partial
+ * [dW1 [H][64] | db1 [H] | dW2 [H][H] | db2 [H]] in the parameters' own layouts (nn.Linear weights [out][in]), to be reduced
+ * over the edge ranges with singa_colsum / singa_colsum_multi.
+ * w1t = weight[H][CIN] of the first Linear, w2 = weight[H][H] of the second (nn.Linear's own layouts). */
 int singa_edge_mlp_bwd_nparts(int E, int H);
 int singa_edge_mlp_bwd(const float* attr, const float* g_out, const float* w1t, const float* b1, const float* w2, float* part,
                        int E, int CIN, int H, void* stream);
@@ -336,6 +336,23 @@ int singa_so3_skinny_expand(const float* small, const float* W, long long w_l, l
                             float* big, int N, int C, int lmax, void* stream);
 int singa_so3_skinny_reduce(const float* small, const float* big, float* part, int N, int C, int lmax, int out_cu, int bias_row,
                             void* stream);
+
+/* SO2_m_Convolution (reference model/EF_layers.py:677-729): its Linear fc (weight w [2h, k], Wr = w[:h], Wi = w[h:]) applied to
+ * the +m rows x_+ and the -m rows x_- with the recombination out_r = fc_r(x_+) - fc_i(x_-), out_i = fc_r(x_-) + fc_i(x_+)
+ * (EF:721-729) equals ONE Linear with the block weight out[2h, 2k] = [[Wr, -Wi], [Wi, Wr]] on [x_+ | x_-].  _fwd builds it;
+ * _bwd maps the block weight's gradient back: g_w[:h] = G[:h, :k] + G[h:, k:], g_w[h:] = G[h:, :k] - G[:h, k:] (accumulate != 0:
+ * added to g_w). */
+int singa_block_weight_fwd(const float* w, float* out, int h, int k, void* stream);
+int singa_block_weight_bwd(const float* g_block, float* g_w, int h, int k, int accumulate, void* stream);
+
+/* out[m] = scale * sum_d x[m, d] * b[d], D = 32: the bias term q . b of the graph attention's logits when `weight_k_lin` is
+ * hoisted to the query side (reference model/CProMG.py:61-65: q . (W (w * k) + b) = (q W) . (w * k) + q . b).  _bwd: gx[m, d] =
+ * scale g[m] b[d] and part[singa_rowdot_nparts(M)][32] = per-workgroup partial sums of scale g[m] x[m, d] (the caller adds them
+ * up: singa_colsum / singa_colsum_multi). */
+int singa_rowdot_nparts(long long M);
+int singa_rowdot_fwd(const float* x, const float* b, float* out, long long M, int D, float scale, void* stream);
+int singa_rowdot_bwd(const float* g, const float* x, const float* b, float* gx, float* part, long long M, int D, float scale,
+                     void* stream);
 
 /* n2 - Laplacian positional encoding (reference model/CProMG.py:562-571 `lap_pe` -> dgl.lap_pe(g, k), called inside forward
  * at model/GAN.py:71,77): for each of B graphs the kout (<= 8) eigenvectors after the smallest of its normalised Laplacian

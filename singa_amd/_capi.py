@@ -87,6 +87,11 @@ _SIGS = {
     "singa_so3_skinny_reduce": ([P, P, P, I32, I32, I32, I32, I32, P], I32),
     "singa_colsum_multi_work": ([C.c_longlong, I32], C.c_longlong),
     "singa_colsum_multi": ([I32, P, P, P, P, P, I32, P, P, P, C.c_longlong, P], I32),
+    "singa_block_weight_fwd": ([P, P, I32, I32, P], I32),
+    "singa_block_weight_bwd": ([P, P, I32, I32, I32, P], I32),
+    "singa_rowdot_nparts": ([C.c_longlong], I32),
+    "singa_rowdot_fwd": ([P, P, P, C.c_longlong, I32, F32, P], I32),
+    "singa_rowdot_bwd": ([P, P, P, P, P, C.c_longlong, I32, F32, P], I32),
     "singa_lap_pe_work": ([I32, I32], I32),
     "singa_lap_pe": ([P] * 8 + [I32, I32, I32, P], I32),
     "singa_adam_step": ([P, P, P, P, P, P, P, I32, I32, P, P, F32, F32, F32, P], I32),

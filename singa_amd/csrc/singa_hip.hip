@@ -1559,9 +1559,10 @@ __global__ void __launch_bounds__(256, 2) edge_mlp_mfma_fwd_kernel(const float* 
                                                                 const float* __restrict__ b2v, float* __restrict__ wk,
                                                                 float* __restrict__ wv, int E) {
     __shared__ float lw1k[64 * 32], lw2k[32 * 32], lw1v[64 * 64], lw2v[64 * 64], lb[32 + 32 + 64 + 64];
-    for (int t = threadIdx.x; t < 64 * 32; t += 256) lw1k[t] = w1tk[t];
-    for (int t = threadIdx.x; t < 32 * 32; t += 256) lw2k[t] = w2tk[t];
-    for (int t = threadIdx.x; t < 64 * 64; t += 256) lw1v[t] = w1tv[t], lw2v[t] = w2tv[t];
+    // LDS images are the TRANSPOSED weights ([in][out]); the parameters arrive in nn.Linear's own [out][in] layout
+    for (int t = threadIdx.x; t < 64 * 32; t += 256) lw1k[t] = w1tk[(t & 31) * 64 + (t >> 5)];
+    for (int t = threadIdx.x; t < 32 * 32; t += 256) lw2k[t] = w2tk[(t & 31) * 32 + (t >> 5)];
+    for (int t = threadIdx.x; t < 64 * 64; t += 256) lw1v[t] = w1tv[(t & 63) * 64 + (t >> 6)], lw2v[t] = w2tv[(t & 63) * 64 + (t >> 6)];
     if (threadIdx.x < 32) lb[threadIdx.x] = b1k[threadIdx.x], lb[32 + threadIdx.x] = b2k[threadIdx.x];
     if (threadIdx.x < 64) lb[64 + threadIdx.x] = b1v[threadIdx.x], lb[128 + threadIdx.x] = b2v[threadIdx.x];
     __syncthreads();
@@ -1631,7 +1632,7 @@ __global__ void __launch_bounds__(256, 2) edge_mlp_mfma_bwd_kernel(const float* 
     __shared__ float lw1[64 * 32], lw2[H * 32], lb1[32], tiles[4 * 2 * 32 * LD];
     static_assert(4 * 2 * 32 * LD >= PSZ, "the tile images double as the reduction buffer");
     const int ht = blockIdx.y;                          // hidden units [32 ht, 32 ht + 32)
-    for (int t = threadIdx.x; t < 64 * 32; t += 256) lw1[t] = w1t[(t >> 5) * H + 32 * ht + (t & 31)];
+    for (int t = threadIdx.x; t < 64 * 32; t += 256) lw1[t] = w1t[(long long)(32 * ht + (t & 31)) * 64 + (t >> 5)];   // w1 [H][64] as stored
     for (int t = threadIdx.x; t < H * 32; t += 256) lw2[t] = w2[(t >> 5) * H + 32 * ht + (t & 31)];
     if (threadIdx.x < 32) lb1[threadIdx.x] = b1[32 * ht + threadIdx.x];
     __syncthreads();
@@ -1758,8 +1759,20 @@ __global__ void __launch_bounds__(256, 2) edge_mlp_mfma_bwd_kernel(const float* 
         }
         __syncthreads();
     }
-    float* dst = part + ((long long)blockIdx.x * gridDim.y + ht) * PSZ;
-    for (int t = threadIdx.x; t < PSZ; t += 256) dst[t] = red[t];
+    // One partial row per workgroup COLUMN (blockIdx.x), the slices' pieces placed where the parameters' rows are:
+    // [dW1 [H][64] | db1 [H] | dW2 [H][H] | db2 [H]] - a column sum over the rows is then the four gradients as they are
+    // stored (the slice's 32 hidden units are rows 32 ht .. of W1 / b1 and COLUMNS 32 ht .. of W2; db2 is the same in every
+    // slice: slice 0 writes it).
+    constexpr int SL = H / 32, ROW = H * 64 + H + H * H + H;
+    float* dst = part + (long long)blockIdx.x * ROW;
+    for (int t = threadIdx.x; t < PSZ; t += 256) {
+        int off;
+        if (t < O_B1) off = ht * 32 * 64 + t;
+        else if (t < O_W2) off = SL * 32 * 64 + ht * 32 + (t - O_B1);
+        else if (t < O_B2) off = SL * 32 * 64 + SL * 32 + ((t - O_W2) >> 5) * H + ht * 32 + ((t - O_W2) & 31);
+        else off = ht == 0 ? SL * 32 * 64 + SL * 32 + H * H + (t - O_B2) : -1;
+        if (off >= 0) dst[off] = red[t];
+    }
 }
 
 
@@ -3517,6 +3530,75 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ small weight / node transforms
+// SO2_m_Convolution's Linear acts on [x_+m | x_-m] through the "complex" recombination (out_r = fc_r(x_+) - fc_i(x_-),
+// out_i = fc_r(x_-) + fc_i(x_+), EF:721-729); folded into ONE block weight B = [[Wr, -Wi], [Wi, Wr]] (Wr = w[:h], Wi = w[h:])
+// the convolution is a single GEMM.  Built by torch ops (two slices, a negation, three concatenations) this cost ~13
+// launches per module and step, forward and backward; here it is one launch each way.
+__global__ void __launch_bounds__(256) block_weight_fwd_kernel(const float* __restrict__ w, float* __restrict__ out, int h, int k) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 4LL * h * k) return;
+    const int i = (int)(t / (2 * k)), j = (int)(t - (long long)i * 2 * k);
+    float v;
+    if (i < h) v = j < k ? w[(long long)i * k + j] : -w[(long long)(h + i) * k + (j - k)];
+    else v = j < k ? w[(long long)i * k + j] : w[(long long)(i - h) * k + (j - k)];
+    out[t] = v;
+}
+// gw[:h] = G[:h, :k] + G[h:, k:],  gw[h:] = G[h:, :k] - G[:h, k:]   (accumulate != 0: added to gw)
+__global__ void __launch_bounds__(256) block_weight_bwd_kernel(const float* __restrict__ G, float* __restrict__ gw, int h, int k, int accumulate) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2LL * h * k) return;
+    const int i = (int)(t / k), j = (int)(t - (long long)i * k);
+    float v;
+    if (i < h) v = G[(long long)i * 2 * k + j] + G[(long long)(h + i) * 2 * k + k + j];
+    else v = G[(long long)i * 2 * k + j] - G[(long long)(i - h) * 2 * k + k + j];
+    gw[t] = accumulate ? gw[t] + v : v;
+}
+
+// out[m] = scale * sum_d x[m, d] b[d] for D = 32 (the hoisted bias term q . b of the graph attention's logits, CP:61-65):
+// 8 lanes per row, one float4 each.  Backward: gx[m, d] = scale g[m] b[d]; per-workgroup partial sums of the bias gradient
+// scale g[m] x[m, d] -> part[blocks][32] (added up by the step's shared column-sum launch).
+__global__ void __launch_bounds__(256) rowdot32_fwd_kernel(const float* __restrict__ x, const float* __restrict__ b, float* __restrict__ out,
+                                                           long long M, float scale) {
+    const long long row = ((long long)blockIdx.x * 256 + threadIdx.x) >> 3;
+    const int q = threadIdx.x & 7;
+    float s = 0.f;
+    if (row < M) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + row * 32 + 4 * q);
+        const float4 bv = *reinterpret_cast<const float4*>(b + 4 * q);
+        s = xv.x * bv.x + xv.y * bv.y + xv.z * bv.z + xv.w * bv.w;
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    if (row < M && q == 0) out[row] = s * scale;
+}
+constexpr int ROWDOT_ROWS = 2048;       // rows per workgroup of the backward kernel
+__global__ void __launch_bounds__(256) rowdot32_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ b,
+                                                           float* __restrict__ gx, float* __restrict__ part, long long M, float scale) {
+    __shared__ float red[32][33];
+    const int q = threadIdx.x & 7, r = threadIdx.x >> 3;            // 32 rows per pass, 8 lanes each
+    const float4 bv = *reinterpret_cast<const float4*>(b + 4 * q);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long r0 = (long long)blockIdx.x * ROWDOT_ROWS;
+    for (int p = 0; p < ROWDOT_ROWS / 32; ++p) {
+        const long long row = r0 + p * 32 + r;
+        if (row < M) {
+            const float gs = g[row] * scale;
+            const float4 xv = *reinterpret_cast<const float4*>(x + row * 32 + 4 * q);
+            *reinterpret_cast<float4*>(gx + row * 32 + 4 * q) = make_float4(gs * bv.x, gs * bv.y, gs * bv.z, gs * bv.w);
+            acc.x = fmaf(gs, xv.x, acc.x); acc.y = fmaf(gs, xv.y, acc.y); acc.z = fmaf(gs, xv.z, acc.z); acc.w = fmaf(gs, xv.w, acc.w);
+        }
+    }
+    red[r][4 * q] = acc.x, red[r][4 * q + 1] = acc.y, red[r][4 * q + 2] = acc.z, red[r][4 * q + 3] = acc.w;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float s = 0.f;
+        for (int i = 0; i < 32; ++i) s += red[i][threadIdx.x];
+        part[(long long)blockIdx.x * 32 + threadIdx.x] = s;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ n2: Laplacian eigenvectors
 // dgl.lap_pe / `lap_pe` of the reference (model/CProMG.py:562-571, called inside forward at model/GAN.py:71,77): the k
 // eigenvectors after the smallest of the normalised Laplacian I - D^-1/2 A D^-1/2 of every graph of the batch, from the
@@ -4574,6 +4656,45 @@ int singa_so3_skinny_reduce(const float* small, const float* big, float* part, i
                                                     dim3((unsigned)(SkinnyCfg<C_>::HALVES * ((N + npb - 1) / npb))),
                                                     dim3(SkinnyCfg<C_>::BLOCK), 0, st, small, big, part, N, npb, out_cu, bias_row));
     return check_launch("so3_skinny_reduce");
+}
+
+int singa_block_weight_fwd(const float* w, float* out, int h, int k, void* stream) {
+    if (!w || !out) return fail(SINGA_E_NULL, "block_weight_fwd: null pointer");
+    if (h <= 0 || k <= 0) return SINGA_OK;
+    const long long n = 4LL * h * k;
+    hipLaunchKernelGGL(block_weight_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, out, h, k);
+    return check_launch("block_weight_fwd");
+}
+
+int singa_block_weight_bwd(const float* g_block, float* g_w, int h, int k, int accumulate, void* stream) {
+    if (!g_block || !g_w) return fail(SINGA_E_NULL, "block_weight_bwd: null pointer");
+    if (h <= 0 || k <= 0) return SINGA_OK;
+    const long long n = 2LL * h * k;
+    hipLaunchKernelGGL(block_weight_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, g_block, g_w, h, k,
+                       accumulate);
+    return check_launch("block_weight_bwd");
+}
+
+int singa_rowdot_nparts(long long M) { return M <= 0 ? 0 : (int)((M + ROWDOT_ROWS - 1) / ROWDOT_ROWS); }
+
+int singa_rowdot_fwd(const float* x, const float* b, float* out, long long M, int D, float scale, void* stream) {
+    if (!x || !b || !out) return fail(SINGA_E_NULL, "rowdot_fwd: null pointer");
+    if (D != 32) return fail(SINGA_E_SHAPE, "rowdot: built for 32 channels per row");
+    if (((uintptr_t)x & 15) || ((uintptr_t)b & 15)) return fail(SINGA_E_SHAPE, "rowdot: 16-byte aligned operands");
+    if (M <= 0) return SINGA_OK;
+    hipLaunchKernelGGL(rowdot32_fwd_kernel, dim3((unsigned)((M * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, b, out, M, scale);
+    return check_launch("rowdot_fwd");
+}
+
+int singa_rowdot_bwd(const float* g, const float* x, const float* b, float* gx, float* part, long long M, int D, float scale,
+                     void* stream) {
+    if (!g || !x || !b || !gx || !part) return fail(SINGA_E_NULL, "rowdot_bwd: null pointer");
+    if (D != 32) return fail(SINGA_E_SHAPE, "rowdot: built for 32 channels per row");
+    if (((uintptr_t)x & 15) || ((uintptr_t)b & 15) || ((uintptr_t)gx & 15)) return fail(SINGA_E_SHAPE, "rowdot: 16-byte aligned operands");
+    if (M <= 0) return SINGA_OK;
+    hipLaunchKernelGGL(rowdot32_bwd_kernel, dim3((unsigned)singa_rowdot_nparts(M)), dim3(256), 0, (hipStream_t)stream, g, x, b, gx, part, M,
+                       scale);
+    return check_launch("rowdot_bwd");
 }
 
 int singa_lap_pe_work(int B, int ld) { return (B < 0 || ld < 0) ? 0 : B * (3 + 4 * 9) * ld; }

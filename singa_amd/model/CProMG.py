@@ -410,7 +410,9 @@ class Encoder(nn.Module):
         if prep is None:
             prep = self.prepare(pos, batch, int(batch.max()) + 1 if batch_size is None else batch_size, knn)
         dm, edges = prep["dense"], prep["edges"]
-        node_attr = self.protein_atom_emb(protein_atom_feature) + self.laplacian_emb(atom_laplacian)
+        # protein_atom_emb(x) + laplacian_emb(pe) (CP:300): the sum rides in the second GEMM's epilogue
+        node_attr = ops.linear_add(protein_atom_feature, self.protein_atom_emb.weight, self.protein_atom_emb.bias,
+                                   self.laplacian_emb(atom_laplacian))
         msa_outputs1 = []
         for idx, layer in enumerate(self.layers):
             msa_outputs, node_attr = layer(node_attr, edges)
@@ -442,7 +444,7 @@ class Encoder2(nn.Module):
         if prep is None:
             prep = self.prepare(aa_pos, aa_batch, int(aa_batch.max()) + 1 if batch_size is None else batch_size, knn)
         dm, edges = prep["dense"], prep["edges"]
-        node_attr = self.aa_emb(aa_feature) + self.laplacian_emb(aa_laplacian)
+        node_attr = ops.linear_add(aa_feature, self.aa_emb.weight, self.aa_emb.bias, self.laplacian_emb(aa_laplacian))
         for idx, layer in enumerate(self.layers):
             node_attr = layer(node_attr, edges, idx, atom_msa_outputs, atom_mask, dm, before_cross)
         return dm.dense(node_attr), dm.pad_mask

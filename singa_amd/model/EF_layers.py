@@ -267,10 +267,7 @@ class SO2_m_Convolution(nn.Module):
         hit = _bw_cache.get(id(self)) if _pass_token[1] else None
         if hit is not None and hit[1] == torch.is_grad_enabled():
             return hit[0]
-        w = self.fc.weight
-        h = w.shape[0] // 2
-        wr, wi = w[:h], w[h:]
-        bw = torch.cat([torch.cat([wr, -wi], 1), torch.cat([wi, wr], 1)], 0)
+        bw = ops.block_weight(self.fc.weight)                         # one launch (and one for its gradient)
         if _pass_token[1]:
             _bw_cache[id(self)] = (bw, torch.is_grad_enabled())
         return bw

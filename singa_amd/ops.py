@@ -871,9 +871,9 @@ class _EdgeMLPPair(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, attr, w1k, b1k, w2k, b2k, w1v, b1v, w2v, b2v):
+        ctx.params = (w1k, b1k, w2k, b2k, w1v, b1v, w2v, b2v)
         attr = attr.contiguous()
-        fw = [w1k.t().contiguous(), b1k.contiguous(), w2k.t().contiguous(), b2k.contiguous(),
-              w1v.t().contiguous(), b1v.contiguous(), w2v.t().contiguous(), b2v.contiguous()]
+        fw = [t.contiguous() for t in (w1k, b1k, w2k, b2k, w1v, b1v, w2v, b2v)]      # nn.Linear's own layouts, no copies
         _dev(attr, *fw)
         E, CIN = attr.shape
         HK, HV = w1k.shape[0], w1v.shape[0]
@@ -881,7 +881,7 @@ class _EdgeMLPPair(torch.autograd.Function):
         wv = torch.empty(E, HV, device=attr.device, dtype=torch.float32)
         _chk(_lib.lib().singa_edge_mlp_fwd(_p(attr), *[_p(t) for t in fw], _p(wk), _p(wv), E, CIN, HK, HV, _stream()),
              "singa_edge_mlp_fwd")
-        ctx.save_for_backward(attr, fw[0], fw[1], w2k.contiguous(), fw[4], fw[5], w2v.contiguous())
+        ctx.save_for_backward(attr, fw[0], fw[1], fw[2], fw[4], fw[5], fw[6])
         return wk, wv
 
     @staticmethod
@@ -890,18 +890,16 @@ class _EdgeMLPPair(torch.autograd.Function):
         E, CIN = attr.shape
         lib = _lib.lib()
         grads = []
-        for g, w1t, b1, w2 in ((gk, w1tk, b1k, w2k), (gv, w1tv, b1v, w2v)):
+        for g, w1t, b1, w2, params in ((gk, w1tk, b1k, w2k, ctx.params[:4]), (gv, w1tv, b1v, w2v, ctx.params[4:])):
             g = g.contiguous()
             H = w2.shape[0]
-            S = H // 32                                   # slices of 32 hidden units (include/singa_hip.h)
-            psz = 32 * CIN + 32 + H * 32 + H
-            part = torch.empty(lib.singa_edge_mlp_bwd_nparts(E, H), S, psz, device=attr.device, dtype=torch.float32)
+            row = H * CIN + H + H * H + H                 # [dW1 | db1 | dW2 | db2] in the parameters' layouts (include/singa_hip.h)
+            part = torch.empty(lib.singa_edge_mlp_bwd_nparts(E, H), row, device=attr.device, dtype=torch.float32)
             _chk(lib.singa_edge_mlp_bwd(_p(attr), _p(g), _p(w1t), _p(b1), _p(w2), _p(part), E, CIN, H, _stream()),
                  "singa_edge_mlp_bwd")
-            tot = colsum(part)                            # [S, psz]
-            o1, o2, o3 = 32 * CIN, 32 * CIN + 32, 32 * CIN + 32 + H * 32
-            grads += [tot[:, :o1].reshape(H, CIN), tot[:, o1:o2].reshape(H),
-                      tot[:, o2:o3].reshape(S, H, 32).permute(1, 0, 2).reshape(H, H), tot[0, o3:]]
+            o1, o2, o3 = H * CIN, H * CIN + H, H * CIN + H + H * H
+            gs = param_colsum(part, [(0, o1, params[0]), (o1, H, params[1]), (o2, H * H, params[2]), (o3, H, params[3])])
+            grads += [gs[0].view(H, CIN) if gs[0] is not None else None, gs[1], gs[2].view(H, H) if gs[2] is not None else None, gs[3]]
         return (None, *grads)
 
 
@@ -1825,20 +1823,73 @@ def embedding(weight, idx, padding_idx=None):
 
 
 class _RowDotBias(torch.autograd.Function):
-    """scale * (x[..., d] * b[d]).sum(-1) with a replay-safe, GEMV-free bias gradient (rocBLAS gemv took 236 us here)."""
+    """scale * (x[..., d] * b[d]).sum(-1) (the hoisted bias term of the graph attention's logits, CP:61-65) as one launch
+    each way for 32-channel rows (k15e); the bias gradient's per-workgroup partials ride in the step's shared column-sum
+    launch.  Other widths: plain torch ops with the same replay-safe bias gradient."""
 
     @staticmethod
     def forward(ctx, x, b, scale):
-        ctx.save_for_backward(x, b)
         ctx.param, ctx.scale = b, scale
+        D = x.shape[-1]
+        ctx.own = bool(x.is_cuda and D == 32 and x.numel() > 0)
+        if ctx.own:
+            x2, b2 = x.reshape(-1, D).contiguous(), b.contiguous()
+            _dev(x2, b2)
+            out = torch.empty(x2.shape[0], device=x.device, dtype=torch.float32)
+            _chk(_lib.lib().singa_rowdot_fwd(_p(x2), _p(b2), _p(out), x2.shape[0], D, scale, _stream()), "singa_rowdot_fwd")
+            ctx.save_for_backward(x2, b2)
+            ctx.xshape = x.shape
+            return out.view(x.shape[:-1])
+        ctx.save_for_backward(x, b)
         return (x * (b * scale)).sum(-1)
 
     @staticmethod
     def backward(ctx, g):
         x, b = ctx.saved_tensors
+        if ctx.own:
+            M, D = x.shape
+            g = g.reshape(-1).contiguous()
+            lib = _lib.lib()
+            gx = torch.empty_like(x)
+            part = torch.empty(lib.singa_rowdot_nparts(M), D, device=x.device, dtype=torch.float32)
+            _chk(lib.singa_rowdot_bwd(_p(g), _p(x), _p(b), _p(gx), _p(part), M, D, ctx.scale, _stream()), "singa_rowdot_bwd")
+            return gx.view(ctx.xshape), param_colsum(part, [(0, D, ctx.param)])[0], None
         ge = g.unsqueeze(-1) * ctx.scale
         return ge * b, param_colsum((ge * x).reshape(-1, x.shape[-1]), [(0, x.shape[-1], ctx.param)])[0], None
 
 
 def rowdot_bias(x, b, scale=1.0):
     return _RowDotBias.apply(x, b, scale)
+
+
+class _BlockWeight(torch.autograd.Function):
+    """[[Wr, -Wi], [Wi, Wr]] of an SO2_m_Convolution's Linear weight w = [Wr; Wi] (EF:677-729 with the recombination of
+    EF:721-729 folded in): one launch instead of two slices, a negation and three concatenations, and one launch for its
+    gradient - added straight into w.grad when the step engine's gradient sink is on."""
+
+    @staticmethod
+    def forward(ctx, w):
+        ctx.param = w
+        w2 = w.contiguous()
+        _dev(w2)
+        h, k = w2.shape[0] // 2, w2.shape[1]
+        out = torch.empty(2 * h, 2 * k, device=w.device, dtype=torch.float32)
+        _chk(_lib.lib().singa_block_weight_fwd(_p(w2), _p(out), h, k, _stream()), "singa_block_weight_fwd")
+        ctx.hk = (h, k)
+        return out
+
+    @staticmethod
+    def backward(ctx, G):
+        h, k = ctx.hk
+        G = G.contiguous()
+        wp = ctx.param
+        if _GradSink.takes(wp):
+            _chk(_lib.lib().singa_block_weight_bwd(_p(G), _p(wp.grad), h, k, 1, _stream()), "singa_block_weight_bwd")
+            return None
+        gw = torch.empty(2 * h, k, device=G.device, dtype=torch.float32)
+        _chk(_lib.lib().singa_block_weight_bwd(_p(G), _p(gw), h, k, 0, _stream()), "singa_block_weight_bwd")
+        return gw
+
+
+def block_weight(w):
+    return _BlockWeight.apply(w)

@@ -439,3 +439,25 @@ def test_ln_silu(emul):
     assert np.abs(s[:C] - gt.grad.numpy()).max() < 1e-4 * np.abs(gt.grad.numpy()).max()
     assert np.abs(s[C:] - bt.grad.numpy()).max() < 1e-4 * np.abs(bt.grad.numpy()).max()
     assert emul.singa_ln_silu_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(out), M, 32, 1e-5, None) == -3
+
+
+def test_block_weight(emul):
+    """[[Wr, -Wi], [Wi, Wr]] of an SO2_m_Convolution weight [Wr; Wi] (EF:677-729, 721-729) and the map of its gradient back
+    to the weight, against the torch expression the reference's recombination implies."""
+    rs = np.random.RandomState(4)
+    h, k = 6, 10
+    w = torch.tensor(rs.randn(2 * h, k), dtype=torch.float32, requires_grad=True)
+    wr, wi = w[:h], w[h:]
+    ref = torch.cat([torch.cat([wr, -wi], 1), torch.cat([wi, wr], 1)], 0)
+    out = np.full((2 * h, 2 * k), np.nan, np.float32)
+    assert emul.singa_block_weight_fwd(ptr(w.detach().numpy()), ptr(out), h, k, None) == 0
+    assert np.array_equal(out, ref.detach().numpy())
+    G = torch.tensor(rs.randn(2 * h, 2 * k), dtype=torch.float32)
+    ref.backward(G)
+    gw = np.full((2 * h, k), np.nan, np.float32)
+    assert emul.singa_block_weight_bwd(ptr(G.numpy()), ptr(gw), h, k, 0, None) == 0
+    assert np.abs(gw - w.grad.numpy()).max() < 1e-6
+    base = rs.randn(2 * h, k).astype(np.float32)
+    acc = base.copy()
+    assert emul.singa_block_weight_bwd(ptr(G.numpy()), ptr(acc), h, k, 1, None) == 0
+    assert np.abs(acc - (base + w.grad.numpy())).max() < 1e-6

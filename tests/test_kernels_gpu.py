@@ -644,3 +644,45 @@ def test_lap_eig_batched_against_numpy():
             assert np.abs(lap @ v - v @ ritz).max() < 2e-6, n
             assert np.abs(np.linalg.eigvalsh(ritz) - w[1:kk + 1]).max() < 2e-6, n
             assert (v.max(0) >= (-v).max(0) - 1e-6).all()
+
+
+@pytest.mark.parametrize("M", [1, 37, 26000])
+def test_rowdot_bias_matches_torch(M):
+    """k15e: scale * (x . b) per 32-channel row and its gradients (the hoisted bias term of CP:61-65) vs float64 torch."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(M)
+    x, b, gy = torch.randn(M // 4 + 1, 4, 32, generator=g), torch.randn(32, generator=g), torch.randn(M // 4 + 1, 4, generator=g)
+    xr, br = x.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = 0.25 * (xr * br).sum(-1)
+    (ref * gy.double()).sum().backward()
+    xd, bd = x.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    out = ops.rowdot_bias(xd, bd, 0.25)
+    assert out.shape == ref.shape and rel(out, ref) < 2e-6
+    (out * gy.to(DEV)).sum().backward()
+    assert rel(xd.grad, xr.grad) < 2e-6 and rel(bd.grad, br.grad) < 1e-5
+
+
+def test_block_weight_autograd():
+    """ops.block_weight through autograd on the GPU (and accumulated into an existing .grad by the gradient sink)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(2 * 48, 40, generator=g)
+    G = torch.randn(2 * 48, 2 * 40, generator=g)
+    wr_ = w.double().requires_grad_(True)
+    h = 48
+    ref = torch.cat([torch.cat([wr_[:h], -wr_[h:]], 1), torch.cat([wr_[h:], wr_[:h]], 1)], 0)
+    (ref * G.double()).sum().backward()
+    wd = w.to(DEV).requires_grad_(True)
+    out = ops.block_weight(wd)
+    assert torch.equal(out.detach().cpu().double(), ref.detach())
+    (out * G.to(DEV)).sum().backward()
+    assert rel(wd.grad, wr_.grad) < 1e-6
+    # gradient-sink mode: the backward adds into the existing buffer and returns nothing
+    wd2 = w.to(DEV).requires_grad_(True)
+    wd2.grad = torch.ones_like(wd2)
+    ops._GradSink.on = True
+    try:
+        (ops.block_weight(wd2) * G.to(DEV)).sum().backward()
+    finally:
+        ops._GradSink.on = False
+    assert rel(wd2.grad - 1.0, wr_.grad) < 1e-5
