@@ -277,8 +277,8 @@ def rocprof_in_graph_us(prof, kernel_substr, grid):
 
 
 def copy_ceiling_gbs(dev, n=64 * 1024 * 1024, reps=10):
-    """Measured device-copy bandwidth (read + write bytes / time) of the library's own float4 copy kernel
-    (singa_calib_copy) on 256 MB operands: the practical HBM ceiling next to the 8 TB/s spec peak."""
+    """Measured device-copy bandwidth (read + write bytes / time) of the library's own copy kernel (singa_calib_copy: one
+    dword per lane) on 256 MB operands: the practical HBM ceiling next to the 8 TB/s spec peak."""
     import ctypes
     from singa_amd import _lib
     a = torch.randn(n, device=dev)
@@ -592,8 +592,8 @@ def main():
                     "avg_launch_us_in_graph": in_graph,
                     "in_graph_source": f"rocprofv3 --kernel-trace of this command (replayed steps): {src}" if in_graph else None,
                     "hbm_copy_ceiling": copy_ceiling_gbs(dev),
-                    "hbm_copy_ceiling_note": "GB/s, read + write bytes of the library's float4 copy kernel on 256 MB operands, "
-                                             "measured in this process",
+                    "hbm_copy_ceiling_note": "GB/s, read + write bytes of the library's copy kernel (one dword per lane, the segment "
+                                             "kernels' access shape) on 256 MB operands, measured in this process",
                     "edges": big, "dst_nodes": n_union,
                     "timing": f"start/stop events attached to each dispatch, {args.roofline_steps} instrumented eager steps "
                               "right after the timed region (same process, same batch)",

@@ -416,8 +416,10 @@ class Encoder(nn.Module):
         msa_outputs1 = []
         for idx, layer in enumerate(self.layers):
             msa_outputs, node_attr = layer(node_attr, edges)
-            msa_outputs1.append(dm.dense(msa_outputs))
-            if layer_done is not None:
+            # the ligand encoder's cross attention reads the protein attention outputs of layers 2 and 5 only (CP:262): the
+            # other layers' dense copies (a zero fill + an index copy each) are never looked at
+            msa_outputs1.append(dm.dense(msa_outputs) if idx in (2, 5) else None)
+            if layer_done is not None and msa_outputs1[-1] is not None:
                 layer_done(idx, msa_outputs1[-1])
         return dm.dense(node_attr), dm.pad_mask, msa_outputs1
 
