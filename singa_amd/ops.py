@@ -938,6 +938,27 @@ class _GradSink:
     on = False
     found = None       # a dict while the engine records which parameters are produced by sink-aware backward functions
     jobs = []          # (src [M, n] kept alive until the flush, [(col0, flat .grad view)])
+    dw = []            # queued weight-gradient products (g [M, N], x [M, K], parameter [N, K]): see _tn_grad
+
+    @staticmethod
+    def flush_dw():
+        """The queued dW = g^T x products as one multi-problem launch (split reduction) + one column-sum job."""
+        q, _GradSink.dw = _GradSink.dw, []
+        if not q:
+            return
+        rmax = max(g.shape[0] for g, _, _ in q)
+        S = max(1, min(32, rmax // 2048))
+        sizes = [g.shape[1] * x.shape[1] for g, x, _ in q]
+        tot = sum(sizes)
+        part = torch.empty(S, tot, device=q[0][0].device, dtype=torch.float32)
+        items, off = [], 0
+        for (g, x, _), sz in zip(q, sizes):
+            items.append(dict(a=g.data_ptr(), lda=g.stride(0), b=x.data_ptr(), ldb=x.stride(0), c=part.data_ptr() + 4 * off,
+                              ldc=x.shape[1], I=g.shape[1], J=x.shape[1], R=g.shape[0], c_split_stride=tot))
+            off += sz
+        _gemm(items, False, False, S)
+        offs = [sum(sizes[:i]) for i in range(len(sizes))]
+        _GradSink.jobs.append((part, [(o, p.grad) for o, (_, _, p) in zip(offs, q)]))
 
     @staticmethod
     def takes(*params):
@@ -955,6 +976,7 @@ class _GradSink:
 
     @staticmethod
     def flush():
+        _GradSink.flush_dw()
         jobs, _GradSink.jobs = _GradSink.jobs, []
         jobs = [j for j in jobs if j[0].shape[0] > 0 and j[0].shape[1] > 0]
         if not jobs:
@@ -1621,9 +1643,18 @@ def linear_nn(x, w):
 
 def _tn_grad(g2, x2, param):
     """dW[N, K] = g2^T x2 (reduction over the rows, split over workgroups) as partial slabs -> param_colsum: returns the
-    gradient shaped like `param`, or None when it was queued into param.grad."""
+    gradient shaped like `param`, or None when it was queued into param.grad.  With the step engine's gradient sink on, the
+    product itself is queued too: up to 12 weight gradients - whatever backward functions finished meanwhile, of any
+    shapes - go out as ONE launch of the GEMM (`_GradSink.flush_dw`), since nothing in the backward pass waits for them."""
     M, N = g2.shape
     K = x2.shape[1]
+    if M > 0 and _GradSink.takes(param):
+        if any(p is param for _, _, p in _GradSink.dw):     # a weight used twice per step: its products go to different launches
+            _GradSink.flush_dw()
+        _GradSink.dw.append((g2, x2, param))
+        if len(_GradSink.dw) >= 12:
+            _GradSink.flush_dw()
+        return None
     S = _tn_splits(M, N, K)
     part = torch.empty(S, N * K, device=g2.device, dtype=torch.float32)
     _gemm([dict(a=g2.data_ptr(), lda=g2.stride(0), b=x2.data_ptr(), ldb=x2.stride(0), c=part.data_ptr(), ldc=K,
