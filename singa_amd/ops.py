@@ -938,12 +938,17 @@ class _GradSink:
     on = False
     found = None       # a dict while the engine records which parameters are produced by sink-aware backward functions
     jobs = []          # (src [M, n] kept alive until the flush, [(col0, flat .grad view)])
-    dw = []            # queued weight-gradient products (g [M, N], x [M, K], parameter [N, K]): see _tn_grad
+    dw = {}            # stream -> queued weight-gradient products (g [M, N], x [M, K], parameter [N, K]): see _tn_grad
 
     @staticmethod
-    def flush_dw():
-        """The queued dW = g^T x products as one multi-problem launch (split reduction) + one column-sum job."""
-        q, _GradSink.dw = _GradSink.dw, []
+    def flush_dw(key=None):
+        """The queued dW = g^T x products (of one stream's queue, or of all) as multi-problem launches (split reduction) +
+        one column-sum job each."""
+        if key is None:
+            for k in list(_GradSink.dw):
+                _GradSink.flush_dw(k)
+            return
+        q = _GradSink.dw.pop(key, [])
         if not q:
             return
         rmax = max(g.shape[0] for g, _, _ in q)
@@ -1649,11 +1654,17 @@ def _tn_grad(g2, x2, param):
     M, N = g2.shape
     K = x2.shape[1]
     if M > 0 and _GradSink.takes(param):
-        if any(p is param for _, _, p in _GradSink.dw):     # a weight used twice per step: its products go to different launches
-            _GradSink.flush_dw()
-        _GradSink.dw.append((g2, x2, param))
-        if len(_GradSink.dw) >= 12:
-            _GradSink.flush_dw()
+        # one queue per stream: the backward pass of the ligand encoder runs on a side stream, and a product may only be
+        # launched on the stream that made its operands (mid-pass flushes) or after the pass has joined its streams (the
+        # final flush)
+        key = torch.cuda.current_stream().cuda_stream
+        q = _GradSink.dw.setdefault(key, [])
+        if any(p is param for _, _, p in q):                # a weight used twice per step: its products go to different launches
+            _GradSink.flush_dw(key)
+            q = _GradSink.dw.setdefault(key, [])
+        q.append((g2, x2, param))
+        if len(q) >= 12:
+            _GradSink.flush_dw(key)
         return None
     S = _tn_splits(M, N, K)
     part = torch.empty(S, N * K, device=g2.device, dtype=torch.float32)

@@ -1,0 +1,43 @@
+"""CPU checks of bench.py's bookkeeping (no GPU): the algorithmic-byte formulas against SURVEY.md §8d, the strong-split
+shard workload, the per-step median and the baseline metric string."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from singa_amd import dp, graph as G  # noqa: E402
+
+
+def test_kernel_bytes_follow_the_survey_formulas():
+    """k10 forward E (KR HV 4 + heads 4 + frame) + N K HV 4 + (N + 1) 4 with the 36-byte frame replaced by
+    the streamed reduced Wigner rows (WSZ 4 bytes: 36 / 116 / 236 floats at L = 2 / 4 / 6)."""
+    E, N = 1000, 300
+    for L, K, KR, WSZ in ((2, 9, 9, 36), (4, 25, 19, 116), (6, 49, 29, 236)):
+        want = E * (KR * 112 * 4 + 7 * 4 + WSZ * 4) + N * K * 112 * 4 + (N + 1) * 4
+        assert bench.kernel_bytes("k10_fwd", E, N, L) == want
+        # the survey's literal figures differ only by the frame term
+        survey = {2: E * 4100 + N * 4032, 4: E * 8580 + N * 11200, 6: E * 13060 + N * 21952}[L]
+        assert bench.kernel_bytes("k10_fwd", E, N, L) - survey == E * (WSZ * 4 - 36 - 4) + (N + 1) * 4
+    assert bench.kernel_bytes("k4_fwd", E, N, 6) == 2 * N * 49 * 16 * 4 + E * (29 * 32 * 4 + 576 * 4 + 236 * 4 + 8)
+
+
+def test_strong_split_shard_workload():
+    """cfg4_shard_r0of8 = the graphs rank 0 of dp.shard_ranges_by_cost owns of the config-3 batch."""
+    L, kw, ids, n_parent = G.resolve_workload("cfg4_shard_r0of8")
+    Lp, kwp, idsp, n = G.resolve_workload("cfg3_b128_l4")
+    assert (L, kw, n_parent) == (Lp, kwp, n) and n == 128 and idsp == list(range(128))
+    costs = [G.graph_cost(G.graph_sizes(i, **kwp)) for i in idsp]
+    ranges = dp.shard_ranges_by_cost(costs, 8)
+    assert ids == list(range(*ranges[0]))
+    assert ranges[0][0] == 0 and ranges[-1][1] == 128 and all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))
+    shard_costs = [sum(costs[lo:hi]) for lo, hi in ranges]
+    assert max(shard_costs) < 1.15 * sum(costs) / 8                     # balanced by edge count, not by graph count
+
+
+def test_median_and_metric_string():
+    assert bench.median([3.0, 1.0, 2.0]) == 2.0 and bench.median([4.0, 1.0, 2.0, 3.0]) == 2.5 and bench.median([]) is None
+    with open(os.path.join(ROOT, "BASELINE.json")) as f:
+        assert bench.baseline_metric() == json.load(f)["metric"]
+    assert bench.host_cores() >= 1
