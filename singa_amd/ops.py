@@ -1646,6 +1646,9 @@ def linear_nn(x, w):
     return linear(x, w.t())
 
 
+DW_QUEUE = True       # batch the weight-gradient products of a backward pass (tools/lab/ab_bench.py times both settings)
+
+
 def _tn_grad(g2, x2, param):
     """dW[N, K] = g2^T x2 (reduction over the rows, split over workgroups) as partial slabs -> param_colsum: returns the
     gradient shaped like `param`, or None when it was queued into param.grad.  With the step engine's gradient sink on, the
@@ -1653,7 +1656,7 @@ def _tn_grad(g2, x2, param):
     shapes - go out as ONE launch of the GEMM (`_GradSink.flush_dw`), since nothing in the backward pass waits for them."""
     M, N = g2.shape
     K = x2.shape[1]
-    if M > 0 and _GradSink.takes(param):
+    if M > 0 and DW_QUEUE and _GradSink.takes(param):
         # one queue per stream: the backward pass of the ligand encoder runs on a side stream, and a product may only be
         # launched on the stream that made its operands (mid-pass flushes) or after the pass has joined its streams (the
         # final flush)
