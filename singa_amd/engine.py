@@ -196,7 +196,7 @@ class TrainStep:
             elif sink.found is not None:
                 self._sink_params = list(sink.found.values())
         finally:
-            sink.on, sink.found, sink.jobs, sink.dw = False, None, [], {}
+            sink.on, sink.found, sink.jobs = False, None, []
         return loss
 
     def _update(self):

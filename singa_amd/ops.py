@@ -938,33 +938,6 @@ class _GradSink:
     on = False
     found = None       # a dict while the engine records which parameters are produced by sink-aware backward functions
     jobs = []          # (src [M, n] kept alive until the flush, [(col0, flat .grad view)])
-    dw = {}            # stream -> queued weight-gradient products (g [M, N], x [M, K], parameter [N, K]): see _tn_grad
-
-    @staticmethod
-    def flush_dw(key=None):
-        """The queued dW = g^T x products (of one stream's queue, or of all) as multi-problem launches (split reduction) +
-        one column-sum job each."""
-        if key is None:
-            for k in list(_GradSink.dw):
-                _GradSink.flush_dw(k)
-            return
-        q = _GradSink.dw.pop(key, [])
-        if not q:
-            return
-        rmax = max(g.shape[0] for g, _, _ in q)
-        S = max(1, min(32, rmax // 2048))
-        sizes = [g.shape[1] * x.shape[1] for g, x, _ in q]
-        tot = sum(sizes)
-        part = torch.empty(S, tot, device=q[0][0].device, dtype=torch.float32)
-        items, off = [], 0
-        for (g, x, _), sz in zip(q, sizes):
-            items.append(dict(a=g.data_ptr(), lda=g.stride(0), b=x.data_ptr(), ldb=x.stride(0), c=part.data_ptr() + 4 * off,
-                              ldc=x.shape[1], I=g.shape[1], J=x.shape[1], R=g.shape[0], c_split_stride=tot))
-            off += sz
-        _gemm(items, False, False, S)
-        offs = [sum(sizes[:i]) for i in range(len(sizes))]
-        _GradSink.jobs.append((part, [(o, p.grad) for o, (_, _, p) in zip(offs, q)]))
-
     @staticmethod
     def takes(*params):
         """True when every given parameter can receive its gradient directly."""
@@ -981,7 +954,6 @@ class _GradSink:
 
     @staticmethod
     def flush():
-        _GradSink.flush_dw()
         jobs, _GradSink.jobs = _GradSink.jobs, []
         jobs = [j for j in jobs if j[0].shape[0] > 0 and j[0].shape[1] > 0]
         if not jobs:
@@ -1646,29 +1618,13 @@ def linear_nn(x, w):
     return linear(x, w.t())
 
 
-DW_QUEUE = True       # batch the weight-gradient products of a backward pass (tools/lab/ab_bench.py times both settings)
-
-
 def _tn_grad(g2, x2, param):
     """dW[N, K] = g2^T x2 (reduction over the rows, split over workgroups) as partial slabs -> param_colsum: returns the
-    gradient shaped like `param`, or None when it was queued into param.grad.  With the step engine's gradient sink on, the
-    product itself is queued too: up to 12 weight gradients - whatever backward functions finished meanwhile, of any
-    shapes - go out as ONE launch of the GEMM (`_GradSink.flush_dw`), since nothing in the backward pass waits for them."""
+    gradient shaped like `param`, or None when it was queued into param.grad.  (Tried and dropped in round 3: queueing the
+    products themselves and launching them 12 at a time - one split count and one tile shape for a mixed batch cost 12 ms
+    per step at config 3 and gained nothing on the 17-graph shard, tools/lab/ab_bench.py.)"""
     M, N = g2.shape
     K = x2.shape[1]
-    if M > 0 and DW_QUEUE and _GradSink.takes(param):
-        # one queue per stream: the backward pass of the ligand encoder runs on a side stream, and a product may only be
-        # launched on the stream that made its operands (mid-pass flushes) or after the pass has joined its streams (the
-        # final flush)
-        key = torch.cuda.current_stream().cuda_stream
-        q = _GradSink.dw.setdefault(key, [])
-        if any(p is param for _, _, p in q):                # a weight used twice per step: its products go to different launches
-            _GradSink.flush_dw(key)
-            q = _GradSink.dw.setdefault(key, [])
-        q.append((g2, x2, param))
-        if len(q) >= 12:
-            _GradSink.flush_dw(key)
-        return None
     S = _tn_splits(M, N, K)
     part = torch.empty(S, N * K, device=g2.device, dtype=torch.float32)
     _gemm([dict(a=g2.data_ptr(), lda=g2.stride(0), b=x2.data_ptr(), ldb=x2.stride(0), c=part.data_ptr(), ldc=K,

@@ -155,7 +155,7 @@ def test_direct_parameter_gradients_equal_autograd_accumulation():
             assert abs(a - b) < 2e-4 * abs(b), (got, base)
         for a, b in zip(e1.norms, e0.norms):
             assert abs(a - b) < 2e-3 * abs(b), (e1.norms, e0.norms)
-    assert ops._GradSink.on is False and not ops._GradSink.jobs and not ops._GradSink.dw
+    assert ops._GradSink.on is False and not ops._GradSink.jobs
 
 
 def test_fused_adam_matches_torch_adam():
