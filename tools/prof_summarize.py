@@ -95,6 +95,8 @@ if f:
     calls = collections.Counter()
     for r in csv.DictReader(open(f)):
         name = short(r.get("Kernel_Name", ""))
+        if "gemm_f32_kernel" in name:      # one name serves launches from 10 us to 3 ms: keep the grids apart
+            name += f" grid {r.get('Grid_Size', r.get('Grid_Size_X', ''))}"
         per[name][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
             calls[name] += 1
@@ -112,7 +114,7 @@ if f:
         w = csv.writer(o)
         w.writerow(["kernel", "dispatches", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F32", "GRBM_GUI_ACTIVE", "mfma_util"])
         w.writerows([(r[0], r[1], int(r[2]), int(r[3]), int(r[4]), round(r[5], 4)) for r in rows[:60]])
-    for r in rows[:12]:
+    for r in rows[:16]:
         mfma[r[0][:70]] = {"dispatches": r[1], "mfma_util": round(r[5], 4), "mops_f32": int(r[3])}
 
 import hashlib
