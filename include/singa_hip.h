@@ -310,8 +310,9 @@ typedef struct {
     int64_t a_group_ld, b_group_ld, c_group_ld;
     int64_t c_split_stride;                       /* floats between the partial slabs of consecutive splits */
     const float* mask;        /* NULL, or a tensor with c's (plain-row) layout: c is zeroed where mask <= 0 (ReLU gradient) */
-    const float* addend;      /* NULL, or a tensor with c's (plain-row) layout that is added to the product (a sum of two Linears'
-                                 outputs, CP:77,400: `centroid_lin(x) + aggr_msg`) */
+    const float* addend;      /* NULL, or a tensor with c's layout (same pitches / grouping) that is added to the product (a sum of two
+                                 Linears' outputs, CP:77,400: `centroid_lin(x) + aggr_msg`; the residual behind an SO3_LinearV2,
+                                 EF:1383-1384, 1405-1406) */
     int32_t relu;             /* != 0: c = max(c, 0) after bias and addend (nn.ReLU behind a Linear, CP:171,188) */
 } singa_gemm_t;
 int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_contig, int splits, void* stream);

@@ -3154,7 +3154,7 @@ struct GemmProb {
     float* C;
     const float* bias;
     const float* mask;      // same layout as C (plain rows): C is zeroed where mask <= 0
-    const float* addend;    // same layout as C (plain rows): added to the product (after the bias, before the ReLU)
+    const float* addend;    // same layout as C (plain or grouped rows): added to the product (after the bias, before the ReLU)
     long long lda, ldb, ldc, a_gld, b_gld, c_gld, c_split;
     int I, J, R, a_group, b_group, c_group, tiles_j, tile_begin, relu;
 };
@@ -4812,8 +4812,8 @@ int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_con
         if (splits > 1 && (q.c_group > 0 || q.ldc != q.J || q.bias || q.mask || q.addend || q.relu ||
                            q.c_split_stride < (long long)q.I * q.J))
             return fail(SINGA_E_SHAPE, "gemm_f32: split reductions write dense [I, J] partial slabs (c_split_stride apart), no epilogue options");
-        if ((q.mask || q.addend) && (q.c_group > 0 || ((uintptr_t)q.mask & 15) || ((uintptr_t)q.addend & 15)))
-            return fail(SINGA_E_SHAPE, "gemm_f32: mask / addend have the result's plain-row layout and are 16-byte aligned");
+        if ((q.mask && q.c_group > 0) || ((uintptr_t)q.mask & 15) || ((uintptr_t)q.addend & 15))
+            return fail(SINGA_E_SHAPE, "gemm_f32: mask / addend have the result's layout (a mask: plain rows only) and are 16-byte aligned");
         P.A = q.a; P.B = q.b; P.C = q.c; P.bias = q.bias; P.mask = q.mask; P.addend = q.addend; P.relu = q.relu;
         P.lda = q.lda; P.ldb = q.ldb; P.ldc = q.ldc;
         P.a_group = q.a_group > 0 ? q.a_group : (1 << 30);

@@ -196,8 +196,8 @@ class SO3_LinearV2(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_features, device=device))
         self._deg = None
 
-    def apply_tensor(self, x: Tensor) -> Tensor:
-        return ops.so3_linear(x, self.weight, self.bias, self.lmax)
+    def apply_tensor(self, x: Tensor, residual: Optional[Tensor] = None) -> Tensor:
+        return ops.so3_linear(x, self.weight, self.bias, self.lmax, residual)
 
     def forward(self, input_embedding: SO3_Embedding) -> SO3_Embedding:
         out = self.apply_tensor(input_embedding.embedding)
@@ -378,7 +378,9 @@ class SO2EquivariantGraphAttention(nn.Module):
         self.proj = SO3_LinearV2(num_heads * attn_value_channels, output_channels, lmax=lmax_list[0], device=device)
 
     def forward(self, x, atomic_numbers: Union[Tensor, Dict], edge_distance: Tensor, edge_index: Tensor, hetero: bool,
-                source_target: Optional[Tuple[str, str]] = None):
+                source_target: Optional[Tuple[str, str]] = None, residual: Optional[Tensor] = None):
+        """`residual` (not in the reference's signature): a tensor added to the result inside the output projection's launch
+        - TransBlockV2's `output + x_res` (EF:1383-1384)."""
         assert hetero is not None, "Please specify args: hetero"
         if isinstance(x, dict):
             x_src, x_dst = x[source_target[0]].embedding, x[source_target[1]].embedding
@@ -404,7 +406,7 @@ class SO2EquivariantGraphAttention(nn.Module):
         y0, y1, y2 = self.so2_conv_2(act)
         # k10: alpha * value, rotate back, sum over incoming edges
         agg = ops.rotate_back_scatter(y0, y1, y2, alpha, wr, es, heads, L, M)
-        out = self.proj.apply_tensor(agg)
+        out = self.proj.apply_tensor(agg, residual)
         return SO3_Embedding(0, self.lmax_list.copy(), self.output_channels, out.dtype, self.device, out)
 
 
@@ -423,12 +425,12 @@ class FeedForwardNetwork(nn.Module):
         self.gating_linear = Linear(sphere_channels, hidden_channels, device=device)
         self.so3_linear_2 = SO3_LinearV2(hidden_channels, output_channels, lmax=self.max_lmax, device=device)
 
-    def forward(self, input_embedding: SO3_Embedding) -> SO3_Embedding:
+    def forward(self, input_embedding: SO3_Embedding, residual: Optional[Tensor] = None) -> SO3_Embedding:
         x = input_embedding.embedding
         gate = self.gating_linear(x[:, 0])
         h = self.so3_linear_1.apply_tensor(x)
         h = ops.s2act_node(h, gate, self.max_lmax)
-        out = self.so3_linear_2.apply_tensor(h)
+        out = self.so3_linear_2.apply_tensor(h, residual)             # (+ x_res of EF:1405-1406 in the same launch)
         return SO3_Embedding(0, input_embedding.lmax_list.copy(), self.output_channels, out.dtype, self.device, out)
 
 
@@ -478,17 +480,15 @@ class TransBlockV2(nn.Module):
             assert hetero and source_target is not None
             x_res = x[source_target[1]].embedding
             self.renorm_only(x, source_target)
-            out = self.ga(x, atomic_numbers, edge_distance, edge_index, hetero, source_target)
+            out = self.ga(x, atomic_numbers, edge_distance, edge_index, hetero, source_target, residual=x_res)
         else:
             x_res = x.embedding
             x.embedding = self.norm_1(x.embedding)
-            out = self.ga(x, atomic_numbers, edge_distance, edge_index, hetero)
-        out.embedding = out.embedding + x_res
+            out = self.ga(x, atomic_numbers, edge_distance, edge_index, hetero, residual=x_res)
+        # (both residual sums of the block ride in the epilogue of the SO3 linear in front of them)
         x_res = out.embedding
         out.embedding = self.norm_2(out.embedding)
-        out = self.ffn(out)
-        out.embedding = out.embedding + x_res
-        return out
+        return self.ffn(out, residual=x_res)
 
 
 _frame_flags: Dict[str, Tensor] = {}      # device -> [min edge length, max |cos(edge, helper)|] seen under graph capture

@@ -1300,13 +1300,18 @@ class _SO3Linear(torch.autograd.Function):
     gradients.  No expanded [K, out, in] weight, no transposed copies."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, L):
+    def forward(ctx, x, weight, bias, L, addend=None):
         ctx.params = (weight, bias)
         x, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
         _dev(x, weight, bias)
         N, K, cin = x.shape
         cout = weight.shape[1]
         out = torch.empty(N, K, cout, device=x.device, dtype=torch.float32)
+        ctx.has_addend = addend is not None
+        if addend is not None:                    # a residual [N, K, cout] added in the GEMM's epilogue (MFMA path only)
+            addend = addend.contiguous()
+            _dev(addend)
+            assert addend.shape == out.shape and not (USE_SKINNY_SO3 and cin == 16 and cout == 512)
         if USE_SKINNY_SO3 and cin == 16 and cout == 512:
             # k11s: a 16-long contraction - VALU kernel, thread = output channel, whole 2 KB rows per store
             _chk(_lib.lib().singa_so3_skinny_expand(_p(x), _p(weight), cout * cin, cin, 1, _p(bias), _p(out), N, cout, L,
@@ -1318,7 +1323,9 @@ class _SO3Linear(torch.autograd.Function):
                 items.append(dict(a=x.data_ptr() + 4 * l * l * cin, lda=cin, a_group=n, a_group_ld=K * cin,
                                   b=weight.data_ptr() + 4 * l * cout * cin, ldb=cin,
                                   c=out.data_ptr() + 4 * l * l * cout, ldc=cout, c_group=n, c_group_ld=K * cout,
-                                  bias=bias.data_ptr() if l == 0 else None, I=N * n, J=cout, R=cin))
+                                  bias=bias.data_ptr() if l == 0 else None,
+                                  addend=(addend.data_ptr() + 4 * l * l * cout) if addend is not None else None,
+                                  I=N * n, J=cout, R=cin))
             if N > 0:
                 _gemm(items, True, True)
         ctx.save_for_backward(x, weight)
@@ -1368,7 +1375,7 @@ class _SO3Linear(torch.autograd.Function):
             else:
                 gw = param_colsum(part, [(0, wsz, ctx.params[0])])[0]
                 gb = param_colsum(g[:, 0, :], [(0, cout, ctx.params[1])])[0]
-            return gx, (gw.view(L + 1, cout, cin) if gw is not None else None), gb, None
+            return gx, (gw.view(L + 1, cout, cin) if gw is not None else None), gb, None, (g if ctx.has_addend else None)
         # dW_l = sum over the (node, row) pairs of degree l of g_row^T x_row
         sz = cout * cin
         S = _splits_for(N * (2 * L + 1))
@@ -1386,11 +1393,12 @@ class _SO3Linear(torch.autograd.Function):
                 gw = gw.view(L + 1, cout, cin)
         else:
             gw = torch.zeros(L + 1, cout, cin, device=x.device, dtype=torch.float32)
-        return gx, gw, param_colsum(g[:, 0, :], [(0, cout, ctx.params[1])])[0], None
+        return gx, gw, param_colsum(g[:, 0, :], [(0, cout, ctx.params[1])])[0], None, (g if ctx.has_addend else None)
 
 
-def so3_linear(x, weight, bias, L):
-    return _SO3Linear.apply(x, weight, bias, L)
+def so3_linear(x, weight, bias, L, addend=None):
+    """SO3_LinearV2 (EF:624-674); `addend` [N, K, out]: a residual added in the same launch (EF:1383-1384, 1405-1406)."""
+    return _SO3Linear.apply(x, weight, bias, L, addend)
 
 
 class _GroupedLinear(torch.autograd.Function):

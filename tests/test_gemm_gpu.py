@@ -259,3 +259,23 @@ def test_grouped_linear3_matches_torch(N):
     assert rel_err(hd.grad.cpu(), hr.grad) < 1e-5
     for a, r in zip(wd, wr):
         assert rel_err(a.grad.cpu(), r.grad) < 1e-5
+
+
+@pytest.mark.parametrize("L,cin,cout", [(4, 512, 16), (4, 112, 16), (6, 512, 16)])
+def test_so3_linear_with_residual(L, cin, cout):
+    """The residual of TransBlockV2 (EF:1383-1384, 1405-1406) added in the SO3 linear's own launch = the plain sum."""
+    from singa_amd import ops
+    N, K = 257, (L + 1) ** 2
+    g = torch.Generator().manual_seed(L * 100 + cin)
+    x = torch.randn(N, K, cin, generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn(L + 1, cout, cin, generator=g) / cin ** 0.5).to(DEV).requires_grad_(True)
+    b = torch.randn(cout, generator=g).to(DEV).requires_grad_(True)
+    r = torch.randn(N, K, cout, generator=g).to(DEV).requires_grad_(True)
+    gy = torch.randn(N, K, cout, generator=g).to(DEV)
+    want = ops.so3_linear(x, w, b, L) + r
+    grads_want = torch.autograd.grad(want, [x, w, b, r], gy)
+    got = ops.so3_linear(x, w, b, L, r)
+    assert rel_err(got.detach().cpu(), want.detach().cpu()) < 1e-6
+    grads_got = torch.autograd.grad(got, [x, w, b, r], gy)
+    for a, c in zip(grads_got, grads_want):
+        assert rel_err(a.cpu(), c.cpu()) < 1e-6

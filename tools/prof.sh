@@ -17,10 +17,14 @@ echo "trace done" > $out/progress.txt
 if [ ! -s $out/bench_under_rocprof.json ]; then echo "the profiled bench run printed no result line:"; tail -30 $out/trace.log; exit 1; fi
 if [ "$TRACE_ONLY" = "1" ]; then python3 tools/prof_summarize.py $raw $out $wl; ls -la $out; exit 0; fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  SINGA_CALIB=1 timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $raw/pmc_$c -- python3 bench.py --workload $wl --eager --steps 2 --warmup 1 --roofline-steps 1 --no-cpu-baseline > $out/pmc_$c.log 2>&1 || echo "pmc $c run failed"
+  if ! SINGA_CALIB=1 timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $raw/pmc_$c -- python3 bench.py --workload $wl --eager --steps 2 --warmup 1 --roofline-steps 1 --no-cpu-baseline --proxy-steps 0 > $out/pmc_$c.log 2>&1; then
+    echo "pmc $c run failed:"; tail -30 $out/pmc_$c.log; exit 1
+  fi
   echo "pmc $c done" >> $out/progress.txt
 done
-timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $raw/pmc_MFMA -- python3 bench.py --workload $wl --eager --steps 2 --warmup 1 --roofline-steps 0 --no-cpu-baseline > $out/pmc_MFMA.log 2>&1 || echo "pmc MFMA run failed"
+if ! timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $raw/pmc_MFMA -- python3 bench.py --workload $wl --eager --steps 2 --warmup 1 --roofline-steps 0 --no-cpu-baseline --proxy-steps 0 > $out/pmc_MFMA.log 2>&1; then
+  echo "pmc MFMA run failed:"; tail -30 $out/pmc_MFMA.log; exit 1
+fi
 echo "pmc MFMA done" >> $out/progress.txt
 python3 tools/prof_summarize.py $raw $out $wl
 ls -la $out
