@@ -111,4 +111,4 @@ def test_step_matches_oracle(case):
     err = float((c(logits).double() - ref.detach().double()).norm() / ref.detach().double().norm())
     assert err < 1e-4, err
     assert abs(float(loss) - float(ref_loss)) < 1e-4 * float(ref_loss)
-    assert abs(gn - ref_gn) < 2e-3 * ref_gn, (gn, ref_gn)
+    assert abs(gn - ref_gn) < 1e-4 * ref_gn, (gn, ref_gn)

@@ -44,7 +44,7 @@ def test_graph_replay_matches_eager():
     # the total gradient norm (clip_grad_norm_'s return value, train.py:126) is finite and the same replayed and eager;
     # first step: the golden's own total norm
     z = golden("singa_L2_B3.npz")
-    assert abs(eng.norms[0] - float(z["grad_total"])) < 1e-3 * float(z["grad_total"]), eng.norms
+    assert abs(eng.norms[0] - float(z["grad_total"])) < 1e-4 * float(z["grad_total"]), eng.norms
     for a, b in zip(eng.norms, e_eng.norms):
         assert a == a and abs(a - b) < 2e-3 * abs(b), (eng.norms, e_eng.norms)
 

@@ -96,7 +96,7 @@ def test_singa_step_matches_reference(L):
     assert abs(float(loss) - float(z["loss"])) < 1e-4 * float(z["loss"])
     loss.backward()
     tot = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
-    assert abs(tot - float(z["grad_total"])) < 1e-3 * float(z["grad_total"])
+    assert abs(tot - float(z["grad_total"])) < 1e-4 * float(z["grad_total"])      # measured: 1e-6 .. 1e-5 (tools/lab/grad_err_probe.py)
     params = dict(model.named_parameters())
     bad = []
     for n, ref in zip(z["grad_names"], z["grad_norms"]):
