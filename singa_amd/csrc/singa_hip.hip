@@ -2190,6 +2190,7 @@ struct ColsumJob {
     int M, n, R, slabs;
     int blk1, blk2;       // first block of this job in pass 1 / pass 2
     int seg0, nseg;
+    int vec, pad_;        // vec: four columns per thread (float4 loads): n, ld, every segment start % 4 == 0, 16-byte aligned bases
 };
 struct ColsumSeg {
     float* dst;
@@ -2211,19 +2212,56 @@ __device__ inline void colsum_multi_emit(const ColsumBatch& b, const ColsumJob& 
     *d += v;
 }
 
+__device__ inline void colsum_multi_emit4(const ColsumBatch& b, const ColsumJob& jb, int j, float4 v) {
+    int s = jb.seg0;
+    for (int k = 1; k < jb.nseg; ++k)
+        if (j >= b.seg[jb.seg0 + k].col0) s = jb.seg0 + k;
+    float4* d = reinterpret_cast<float4*>(b.seg[s].dst + (j - b.seg[s].col0));
+    float4 o = *d;
+    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+    *d = o;
+}
+
 __global__ void __launch_bounds__(256) colsum_multi_pass1_kernel(const ColsumBatch b) {
     int k = 0;
     for (int q = 1; q < b.n_jobs; ++q)
         if ((int)blockIdx.x >= b.job[q].blk1) k = q;
     const ColsumJob& jb = b.job[k];
     const long long t = (long long)((int)blockIdx.x - jb.blk1) * 256 + threadIdx.x;
+    const float* __restrict__ x = jb.x;
+    const long long ld = jb.ld;
+    if (jb.vec) {                       // the partial slabs of the weight-gradient GEMMs: 16 bytes per lane
+        const int n4 = jb.n >> 2;
+        if (t >= (long long)jb.slabs * n4) return;
+        const int slab = (int)(t / n4);
+        const int j = 4 * (int)(t - (long long)slab * n4);
+        const long long r0 = (long long)slab * jb.R;
+        const long long r1 = r0 + jb.R < jb.M ? r0 + jb.R : jb.M;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        long long i = r0;
+        for (; i + 3 < r1; i += 4) {
+            const float4 v0 = *reinterpret_cast<const float4*>(x + i * ld + j), v1 = *reinterpret_cast<const float4*>(x + (i + 1) * ld + j);
+            const float4 v2 = *reinterpret_cast<const float4*>(x + (i + 2) * ld + j), v3 = *reinterpret_cast<const float4*>(x + (i + 3) * ld + j);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+            a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+            a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        }
+        for (; i < r1; ++i) {
+            const float4 v0 = *reinterpret_cast<const float4*>(x + i * ld + j);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        }
+        const float4 v = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                                     (a0.w + a1.w) + (a2.w + a3.w));
+        if (jb.slabs == 1) colsum_multi_emit4(b, jb, j, v);
+        else *reinterpret_cast<float4*>(jb.work + (long long)slab * jb.n + j) = v;
+        return;
+    }
     if (t >= (long long)jb.slabs * jb.n) return;
     const int slab = (int)(t / jb.n);
     const int j = (int)(t - (long long)slab * jb.n);
     const long long r0 = (long long)slab * jb.R;
     const long long r1 = r0 + jb.R < jb.M ? r0 + jb.R : jb.M;
-    const float* __restrict__ x = jb.x;
-    const long long ld = jb.ld;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
     long long i = r0;
     for (; i + 7 < r1; i += 8) {
@@ -2250,9 +2288,27 @@ __global__ void __launch_bounds__(256) colsum_multi_pass2_kernel(const ColsumBat
         if ((int)blockIdx.x >= b.job[q].blk2) k = q;
     const ColsumJob& jb = b.job[k];
     if (jb.slabs == 1) return;
+    const float* __restrict__ w = jb.work;
+    if (jb.vec) {
+        const int j = 4 * (((int)blockIdx.x - jb.blk2) * 256 + threadIdx.x);
+        if (j >= jb.n) return;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        int s = 0;
+        for (; s + 1 < jb.slabs; s += 2) {
+            const float4 v0 = *reinterpret_cast<const float4*>(w + (long long)s * jb.n + j);
+            const float4 v1 = *reinterpret_cast<const float4*>(w + (long long)(s + 1) * jb.n + j);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+        }
+        for (; s < jb.slabs; ++s) {
+            const float4 v0 = *reinterpret_cast<const float4*>(w + (long long)s * jb.n + j);
+            a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+        }
+        colsum_multi_emit4(b, jb, j, make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w));
+        return;
+    }
     const int j = ((int)blockIdx.x - jb.blk2) * 256 + threadIdx.x;
     if (j >= jb.n) return;
-    const float* __restrict__ w = jb.work;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int s = 0;
     for (; s + 3 < jb.slabs; s += 4) {
@@ -5151,22 +5207,27 @@ int singa_colsum_multi(int n_jobs, const float* const* x, const long long* ld, c
             jb.blk2 = blk2;
             jb.seg0 = ns;
             jb.nseg = s1 - s0;
+            bool vec = n[k] % 4 == 0 && ld[k] % 4 == 0 && !((uintptr_t)x[k] & 15) && n[k] >= 1024;
             for (int q = s0; q < s1; ++q) {
                 if (!seg_dst[q] || seg_col0[q] < 0 || seg_col0[q] >= n[k] || (q > s0 && seg_col0[q] <= seg_col0[q - 1]) ||
                     (q == s0 && seg_col0[q] != 0))
                     return fail(SINGA_E_SHAPE, "colsum_multi: segments must start at column 0 and ascend");
                 b.seg[ns].dst = seg_dst[q];
                 b.seg[ns].col0 = seg_col0[q];
+                vec = vec && seg_col0[q] % 4 == 0 && !((uintptr_t)seg_dst[q] & 15);
                 ++ns;
             }
             if (jb.slabs > 1) {
                 const long long need = (long long)jb.slabs * jb.n;
                 if (!work || woff + need > work_floats) return fail(SINGA_E_SHAPE, "colsum_multi: workspace too small");
+                vec = vec && woff % 4 == 0 && !((uintptr_t)work & 15);
                 jb.work = work + woff;
                 woff += need;
-                blk2 += (jb.n + 255) / 256;
             }
-            blk1 += (int)(((long long)jb.slabs * jb.n + 255) / 256);
+            jb.vec = vec ? 1 : 0;
+            const int per = vec ? jb.n / 4 : jb.n;                 // threads per slab
+            if (jb.slabs > 1) blk2 += (per + 255) / 256;
+            blk1 += (int)(((long long)jb.slabs * per + 255) / 256);
             ++nj;
             ++k;
         }

@@ -301,10 +301,14 @@ def test_colsum_multi(emul):
     rs = np.random.RandomState(3)
     shapes = [(1, 5, 5), (17, 3, 3), (700, 33, 40), (5000, 300, 300), (40000, 7, 9), (0, 4, 4)] + \
              [(int(rs.randint(1, 3000)), int(rs.randint(1, 70)), 80) for _ in range(90)]
+    # wide jobs whose segments start at multiples of 4: the float4 path (the partial slabs of the weight-gradient GEMMs)
+    vec_cuts = {(49, 4096, 4096): [0, 1024, 3072], (64, 2048, 2048): [0], (300, 1024, 1028): [0, 512], (16, 1536, 1536): [0, 4]}
+    shapes += list(vec_cuts)
     xs, dsts, refs, segs = [], [], [], []
     for M, n, ld in shapes:
         x = rs.randn(M, ld).astype(np.float32)
         cuts = sorted(set([0] + ([int(c) for c in rs.randint(1, n, size=rs.randint(0, 3))] if n > 1 else [])))
+        cuts = vec_cuts.get((M, n, ld), cuts)
         d = [rs.randn(b - a).astype(np.float32) for a, b in zip(cuts, cuts[1:] + [n])]
         tot = x[:, :n].astype(np.float64).sum(0)
         refs.append([di.astype(np.float64) + tot[a:a + di.size] for di, a in zip(d, cuts)])
