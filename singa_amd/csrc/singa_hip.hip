@@ -2070,15 +2070,32 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) dk[r] = 0.f, dv0[r] = 0.f, dv1[r] = 0.f;
     float4 qn[4], gn[8];
+    // per-query softmax statistics (row maximum, 1 / row sum, D = rowsum(dO . O)) of the tile's 32 queries: fetched one tile
+    // ahead, one query per lane (coalesced), and handed to the 16 accumulator rows through a wave-private LDS image - the
+    // 48 per-register global loads they replaced sat between the two MFMA phases with their full latency exposed (one
+    // wavefront per SIMD at this kernel's register count: MFMA-busy 0.27)
+    __shared__ float sstat[4][96];
+    float* ss = sstat[threadIdx.x >> 6];
+    float sn0 = 0.f, sn1 = 0.f;
+    const bool mask_per_key = mst == 0;                            // a padding mask: one byte per key serves every query
+    const bool mkey = mask_per_key ? (mb[0] != 0) : false;
     auto fetch = [&](int t0) {
         const int ta = t0 + i < T ? t0 + i : T - 1;                // query row this lane supplies as A operand
 #pragma unroll
         for (int m4 = 0; m4 < 4; ++m4) qn[m4] = *reinterpret_cast<const float4*>(qb + (long long)ta * A.qs + 16 * half + 4 * m4);
 #pragma unroll
         for (int m4 = 0; m4 < 8; ++m4) gn[m4] = *reinterpret_cast<const float4*>(gob + (long long)ta * A.os + 32 * half + 4 * m4);
+        if (half == 0) {
+            const float2 st = *reinterpret_cast<const float2*>(lse + ((long long)bh * T + ta) * 2);
+            sn0 = st.x, sn1 = st.y;
+        } else {
+            sn0 = dsum[(long long)bh * T + ta];
+        }
     };
     fetch(0);
     for (int t0 = 0; t0 < T; t0 += 32) {
+        if (half == 0) ss[i] = sn0, ss[32 + i] = sn1;
+        else ss[64 + i] = sn0;
         float qa[16], ga[32], ad[16][3];
 #pragma unroll
         for (int m4 = 0; m4 < 4; ++m4) qa[4 * m4] = qn[m4].x, qa[4 * m4 + 1] = qn[m4].y, qa[4 * m4 + 2] = qn[m4].z, qa[4 * m4 + 3] = qn[m4].w;
@@ -2101,15 +2118,15 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
         floatx16 pr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int tr = t0 + 8 * (r >> 2) + 4 * half + (r & 3);     // query of register r
+            const int tl = 8 * (r >> 2) + 4 * half + (r & 3);          // query of register r inside the tile
+            const int tr = t0 + tl;
             const bool in = tr < T && kin;
             const int trc = tr < T ? tr : T - 1;
-            const bool msk = in && mb[(long long)trc * mst];
+            const bool msk = in && (mask_per_key ? mkey : mb[(long long)trc * mst] != 0);
             const float val = msk ? -1e9f : sc[r] * scale;
-            const float* st = lse + ((long long)bh * T + trc) * 2;
-            const float p = in ? __expf(val - st[0]) * st[1] : 0.f;
+            const float p = in ? __expf(val - ss[tl]) * ss[32 + tl] : 0.f;
             pr[r] = p;
-            sc[r] = msk ? 0.f : p * (dp[r] - dsum[(long long)bh * T + trc]) * scale;      // dS
+            sc[r] = msk ? 0.f : p * (dp[r] - ss[64 + tl]) * scale;          // dS
         }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
