@@ -25,6 +25,9 @@ struct float4 {
     float x, y, z, w;
 };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+struct float2 {
+    float x, y;
+};
 struct float3 {
     float x, y, z;
 };
