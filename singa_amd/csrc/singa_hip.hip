@@ -2339,7 +2339,10 @@ __global__ void __launch_bounds__(256) colsum_multi_pass2_kernel(const ColsumBat
 }
 
 // rows per slab of one job: a power of two >= 16 that leaves at most COLSUM_R slabs
-static inline int colsum_multi_r(long long M) {
+// (wide jobs of at most COLSUM_R rows - the partial slabs of the split weight-gradient GEMMs - take ONE slab: a thread adds
+// up all rows of its columns, nothing is written to and read back from the workspace, and no second pass runs)
+static inline int colsum_multi_r(long long M, int n) {
+    if (M <= COLSUM_R && n >= 2048) return COLSUM_R;
     long long r = 16;
     while ((M + r - 1) / r > COLSUM_R) r <<= 1;
     return (int)r;
@@ -5190,9 +5193,9 @@ int singa_colsum(const float* x, long long ld, long long M, int n, float* work, 
 
 long long singa_colsum_multi_work(long long M, int n) {
     if (M <= 0 || n <= 0) return 0;
-    const int r = colsum_multi_r(M);
+    const int r = colsum_multi_r(M, n);
     const long long slabs = (M + r - 1) / r;
-    return slabs > 1 ? slabs * (long long)n : 0;
+    return slabs > 1 ? slabs * (long long)n + 4 : 0;       // (+ 4: every job's partials start 16-byte aligned)
 }
 
 int singa_colsum_multi(int n_jobs, const float* const* x, const long long* ld, const long long* M, const int* n,
@@ -5218,7 +5221,7 @@ int singa_colsum_multi(int n_jobs, const float* const* x, const long long* ld, c
             jb.ld = ld[k];
             jb.M = (int)M[k];
             jb.n = n[k];
-            jb.R = colsum_multi_r(M[k]);
+            jb.R = colsum_multi_r(M[k], n[k]);
             jb.slabs = (int)((M[k] + jb.R - 1) / jb.R);
             jb.blk1 = blk1;
             jb.blk2 = blk2;
@@ -5236,8 +5239,9 @@ int singa_colsum_multi(int n_jobs, const float* const* x, const long long* ld, c
             }
             if (jb.slabs > 1) {
                 const long long need = (long long)jb.slabs * jb.n;
+                woff = (woff + 3) & ~3LL;
                 if (!work || woff + need > work_floats) return fail(SINGA_E_SHAPE, "colsum_multi: workspace too small");
-                vec = vec && woff % 4 == 0 && !((uintptr_t)work & 15);
+                vec = vec && !((uintptr_t)work & 15);
                 jb.work = work + woff;
                 woff += need;
             }

@@ -331,7 +331,7 @@ def test_colsum_multi(emul):
     for d, r in zip(dsts, refs):
         for di, ri in zip(d, r):
             assert np.abs(di - ri).max() < 2e-3
-    assert emul.singa_colsum_multi(nj, X, LD, MM, NN, S0, ns, C0, D, ptr(w), work - 1, None) == -3     # workspace too small
+    assert emul.singa_colsum_multi(nj, X, LD, MM, NN, S0, ns, C0, D, ptr(w), work // 2, None) == -3    # workspace too small
 
 
 @pytest.mark.parametrize("L,edge", [(2, True), (4, True), (6, True), (2, False), (4, False), (6, False)])
