@@ -2036,7 +2036,8 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
     }
 }
 
-__global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k,
+// (one wavefront per SIMD by design: asked for two, the compiler parks the prefetched rows in scratch and waits for them)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) attn_bwd_dkv_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                            const float* __restrict__ v, const unsigned char* __restrict__ mask,
                                                            long long msb, long long mst, const float* __restrict__ lse,
                                                            const float* __restrict__ dsum, const float* __restrict__ go,
@@ -2069,60 +2070,82 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
     floatx16 dk, dv0, dv1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dk[r] = 0.f, dv0[r] = 0.f, dv1[r] = 0.f;
-    float4 qn[4], gn[8];
-    // per-query softmax statistics (row maximum, 1 / row sum, D = rowsum(dO . O)) of the tile's 32 queries: fetched one tile
-    // ahead, one query per lane (coalesced), and handed to the 16 accumulator rows through a wave-private LDS image - the
-    // 48 per-register global loads they replaced sat between the two MFMA phases with their full latency exposed (one
-    // wavefront per SIMD at this kernel's register count: MFMA-busy 0.27)
+    float4 qn0, qn1, qn2, qn3, gn0, gn1, gn2, gn3, gn4, gn5, gn6, gn7;        // (scalars, not arrays: the compiler moved arrays to LDS / scratch)
+    // The tile's 32 query rows (q: 32 floats, dO: 64 floats) travel global -> registers (one tile ahead, coalesced float4
+    // rows) -> a wave-private LDS image [query][100], from which BOTH operand layouts are read right in front of their MFMAs:
+    // [query on the lane] for s^T = K Q^T and dP^T = V dO^T, [query in the register index] for dV^T += dO^T P and
+    // dK^T += Q^T dS.  (Round 2 fetched the second layout with 48 more global loads per tile and held both in registers:
+    // 352 registers = one wavefront per SIMD, the compiler sank those loads to right in front of their MFMAs - vmcnt(47..0)
+    // one by one - and a branch around the prefetch cost a vmcnt(0) per tile: MFMA-busy 0.27.)  The per-query softmax
+    // statistics (row maximum, 1 / row sum, D = rowsum(dO . O)) ride along: one query per lane, read back per register row.
+    constexpr int QS = 100;                                        // row pitch (floats): 16-byte aligned rows, q at 0, dO at 32
+    __shared__ __attribute__((aligned(16))) float qimg[4][32 * QS];
     __shared__ float sstat[4][96];
+    float* lw = qimg[threadIdx.x >> 6];
     float* ss = sstat[threadIdx.x >> 6];
-    float sn0 = 0.f, sn1 = 0.f;
-    const bool mask_per_key = mst == 0;                            // a padding mask: one byte per key serves every query
-    const bool mkey = mask_per_key ? (mb[0] != 0) : false;
-    auto fetch = [&](int t0) {
-        const int ta = t0 + i < T ? t0 + i : T - 1;                // query row this lane supplies as A operand
-#pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) qn[m4] = *reinterpret_cast<const float4*>(qb + (long long)ta * A.qs + 16 * half + 4 * m4);
-#pragma unroll
-        for (int m4 = 0; m4 < 8; ++m4) gn[m4] = *reinterpret_cast<const float4*>(gob + (long long)ta * A.os + 32 * half + 4 * m4);
-        if (half == 0) {
-            const float2 st = *reinterpret_cast<const float2*>(lse + ((long long)bh * T + ta) * 2);
-            sn0 = st.x, sn1 = st.y;
-        } else {
-            sn0 = dsum[(long long)bh * T + ta];
-        }
-    };
-    fetch(0);
+    float sn0 = 0.f, sn1 = 0.f, sn2 = 0.f;
+    unsigned char mraw[16];
+#define SINGA_DKV_FETCH(T0)                                                                                                     \
+    do {                                                                                                                        \
+        const int ta_ = (T0) + i < T ? (T0) + i : T - 1; /* query row this lane supplies */                                     \
+        const float* qr_ = qb + (long long)ta_ * A.qs + 16 * half;                                                               \
+        const float* gr_ = gob + (long long)ta_ * A.os + 32 * half;                                                              \
+        qn0 = *reinterpret_cast<const float4*>(qr_), qn1 = *reinterpret_cast<const float4*>(qr_ + 4);                            \
+        qn2 = *reinterpret_cast<const float4*>(qr_ + 8), qn3 = *reinterpret_cast<const float4*>(qr_ + 12);                       \
+        gn0 = *reinterpret_cast<const float4*>(gr_), gn1 = *reinterpret_cast<const float4*>(gr_ + 4);                            \
+        gn2 = *reinterpret_cast<const float4*>(gr_ + 8), gn3 = *reinterpret_cast<const float4*>(gr_ + 12);                       \
+        gn4 = *reinterpret_cast<const float4*>(gr_ + 16), gn5 = *reinterpret_cast<const float4*>(gr_ + 20);                      \
+        gn6 = *reinterpret_cast<const float4*>(gr_ + 24), gn7 = *reinterpret_cast<const float4*>(gr_ + 28);                      \
+        const float2 st_ = *reinterpret_cast<const float2*>(lse + ((long long)bh * T + ta_) * 2);                                \
+        sn0 = st_.x, sn1 = st_.y, sn2 = dsum[(long long)bh * T + ta_];                                                           \
+        _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) { /* mask bytes of the tile's 16 register rows (a padding mask: 16 x */ \
+            const int tr_ = (T0) + 8 * (r_ >> 2) + 4 * half + (r_ & 3);             /* the same byte), fetched with the rows */  \
+            mraw[r_] = mb[(long long)(tr_ < T ? tr_ : T - 1) * mst];                                                             \
+        }                                                                                                                        \
+    } while (0)
+    SINGA_DKV_FETCH(0);
     for (int t0 = 0; t0 < T; t0 += 32) {
-        if (half == 0) ss[i] = sn0, ss[32 + i] = sn1;
-        else ss[64 + i] = sn0;
-        float qa[16], ga[32], ad[16][3];
-#pragma unroll
-        for (int m4 = 0; m4 < 4; ++m4) qa[4 * m4] = qn[m4].x, qa[4 * m4 + 1] = qn[m4].y, qa[4 * m4 + 2] = qn[m4].z, qa[4 * m4 + 3] = qn[m4].w;
-#pragma unroll
-        for (int m4 = 0; m4 < 8; ++m4) ga[4 * m4] = gn[m4].x, ga[4 * m4 + 1] = gn[m4].y, ga[4 * m4 + 2] = gn[m4].z, ga[4 * m4 + 3] = gn[m4].w;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {                  // A operands of the dV / dK products, issued ahead of the 48 MFMAs before them
-            const int ts = t0 + 8 * (s >> 2) + 4 * half + (s & 3);
-            const long long tsc = ts < T ? ts : T - 1;
-            ad[s][0] = gob[tsc * A.os + i], ad[s][1] = gob[tsc * A.os + 32 + i], ad[s][2] = qb[tsc * A.qs + i];
+        if (half == 0) ss[i] = sn0, ss[32 + i] = sn1, ss[64 + i] = sn2;
+        {
+            float* qw = lw + i * QS + 16 * half;
+            float* gw = lw + i * QS + 32 + 32 * half;
+            *reinterpret_cast<float4*>(qw) = qn0, *reinterpret_cast<float4*>(qw + 4) = qn1;
+            *reinterpret_cast<float4*>(qw + 8) = qn2, *reinterpret_cast<float4*>(qw + 12) = qn3;
+            *reinterpret_cast<float4*>(gw) = gn0, *reinterpret_cast<float4*>(gw + 4) = gn1;
+            *reinterpret_cast<float4*>(gw + 8) = gn2, *reinterpret_cast<float4*>(gw + 12) = gn3;
+            *reinterpret_cast<float4*>(gw + 16) = gn4, *reinterpret_cast<float4*>(gw + 20) = gn5;
+            *reinterpret_cast<float4*>(gw + 24) = gn6, *reinterpret_cast<float4*>(gw + 28) = gn7;
         }
-        if (t0 + 32 < T) fetch(t0 + 32);
+        unsigned mbits = 0;                             // this tile's mask bits (fetched with its rows, one tile ago)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mbits |= (mraw[r] != 0 ? 1u : 0u) << r;
+        const int tnext = t0 + 32 < T ? t0 + 32 : t0;  // unconditional (the last tile re-reads its own rows): no branch, no vmcnt(0)
+        SINGA_DKV_FETCH(tnext);
         floatx16 sc, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = 0.f, dp[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) sc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], kreg[s], sc, 0, 0, 0);
+        for (int m4 = 0; m4 < 4; ++m4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(lw + i * QS + 16 * half + 4 * m4);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, kreg[4 * m4], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, kreg[4 * m4 + 1], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, kreg[4 * m4 + 2], sc, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, kreg[4 * m4 + 3], sc, 0, 0, 0);
+        }
 #pragma unroll
-        for (int s = 0; s < 32; ++s) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s], vreg[s], dp, 0, 0, 0);
+        for (int m4 = 0; m4 < 8; ++m4) {
+            const float4 a4 = *reinterpret_cast<const float4*>(lw + i * QS + 32 + 32 * half + 4 * m4);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, vreg[4 * m4], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, vreg[4 * m4 + 1], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, vreg[4 * m4 + 2], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, vreg[4 * m4 + 3], dp, 0, 0, 0);
+        }
         floatx16 pr;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int tl = 8 * (r >> 2) + 4 * half + (r & 3);          // query of register r inside the tile
-            const int tr = t0 + tl;
-            const bool in = tr < T && kin;
-            const int trc = tr < T ? tr : T - 1;
-            const bool msk = in && (mask_per_key ? mkey : mb[(long long)trc * mst] != 0);
+            const bool in = t0 + tl < T && kin;
+            const bool msk = in && ((mbits >> r) & 1u);
             const float val = msk ? -1e9f : sc[r] * scale;
             const float p = in ? __expf(val - ss[tl]) * ss[32 + tl] : 0.f;
             pr[r] = p;
@@ -2130,11 +2153,13 @@ __global__ void __launch_bounds__(256) attn_bwd_dkv_kernel(const float* __restri
         }
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[s][0], pr[s], dv0, 0, 0, 0);
-            dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[s][1], pr[s], dv1, 0, 0, 0);
-            dk = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[s][2], sc[s], dk, 0, 0, 0);
+            const float* row = lw + (8 * (s >> 2) + 4 * half + (s & 3)) * QS;      // query 8 (s / 4) + 4 half + s % 4 of the tile
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x2f32(row[32 + i], pr[s], dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x2f32(row[64 + i], pr[s], dv1, 0, 0, 0);
+            dk = __builtin_amdgcn_mfma_f32_32x32x2f32(row[i], sc[s], dk, 0, 0, 0);
         }
     }
+#undef SINGA_DKV_FETCH
     if (kin) {
         float* dkd = gk + A.kb + (long long)key * A.ks + 4 * half;
         float* dvd = gv + A.vb + (long long)key * A.vs + 4 * half;
