@@ -314,6 +314,9 @@ typedef struct {
                                  Linears' outputs, CP:77,400: `centroid_lin(x) + aggr_msg`; the residual behind an SO3_LinearV2,
                                  EF:1383-1384, 1405-1406) */
     int32_t relu;             /* != 0: c = max(c, 0) after bias and addend (nn.ReLU behind a Linear, CP:171,188) */
+    float* asum;              /* NULL, or ((0, 0) form only) asum[s * asum_stride + i] = sum over split s's reduction rows of A(r, i):
+                                 the bias gradient sum_m dy[m, n] computed while dW = dy^T x streams dy (no separate pass) */
+    int64_t asum_stride;      /* floats between the splits' rows of asum (>= I) */
 } singa_gemm_t;
 int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_contig, int splits, void* stream);
 /* tests only: force the 128 x 128 (0) or the 64 x 64 (3) tile shape wherever the automatic choice is between those two;

@@ -20,7 +20,7 @@ class Gemm(C.Structure):
     _fields_ = [("a", P), ("b", P), ("c", P), ("bias", P), ("lda", I64), ("ldb", I64), ("ldc", I64), ("I", C.c_int32),
                 ("J", C.c_int32), ("R", C.c_int32), ("a_group", C.c_int32), ("b_group", C.c_int32), ("c_group", C.c_int32),
                 ("a_group_ld", I64), ("b_group_ld", I64), ("c_group_ld", I64), ("c_split_stride", I64), ("mask", P),
-                ("addend", P), ("relu", C.c_int32)]
+                ("addend", P), ("relu", C.c_int32), ("asum", P), ("asum_stride", I64)]
 
 
 def gemm_probs(items):

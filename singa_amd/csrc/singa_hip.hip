@@ -3256,6 +3256,8 @@ struct GemmProb {
     const float* bias;
     const float* mask;      // same layout as C (plain rows): C is zeroed where mask <= 0
     const float* addend;    // same layout as C (plain or grouped rows): added to the product (after the bias, before the ReLU)
+    float* asum;            // (0, 0) form only: per split, sum over the reduction rows of A -> asum[split * asum_stride + i]
+    long long asum_stride;
     long long lda, ldb, ldc, a_gld, b_gld, c_gld, c_split;
     int I, J, R, a_group, b_group, c_group, tiles_j, tile_begin, relu;
 };
@@ -3415,7 +3417,22 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
         if (B_RC) load_rc(all_c, rb, mb, brow, P.B, NB, r0);
         else load_oc(all_c, rb, mb, P.B, P.ldb, P.b_group, P.b_gld, j0, P.J, NB, BN / 4, r0);
     };
+    // (0, 0) form with `asum`: the column sums of A over the reduction rows - the bias gradient sum_m g[m, n] next to the weight
+    // gradient g^T x - are taken from the registers on their way to LDS by the workgroups of the problem's first column tile:
+    // four columns per thread, reduced over the workgroup in front of the epilogue.  (The separate column-sum pass it
+    // replaces re-read every gradient tensor of the transformer's Linears: ~6 GB per step.)
+    const bool do_asum = !A_RC && P.asum != nullptr && j0 == 0;
+    const float asum_on = do_asum ? 1.f : 0.f;
+    float4 asum4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto store_ab = [&](const float4* ra, const float4* rb, unsigned ma, unsigned mb, int buf) __attribute__((always_inline)) {
+        if constexpr (!A_RC) {           // branch-free (a branch here would split the scheduled K step): weight 0 when not wanted
+#pragma unroll
+            for (int j = 0; j < NA; ++j) {
+                const float wj = ((ma >> j) & 1u) ? asum_on : 0.f;
+                asum4.x = fmaf(wj, ra[j].x, asum4.x); asum4.y = fmaf(wj, ra[j].y, asum4.y);
+                asum4.z = fmaf(wj, ra[j].z, asum4.z); asum4.w = fmaf(wj, ra[j].w, asum4.w);
+            }
+        }
         if (A_RC) store_rc(As0 + buf * SZA, ra, ma, NA);
         else store_oc(As0 + buf * SZA, ra, ma, LDA, NA, BM / 4);
         if (B_RC) store_rc(Bs0 + buf * SZB, rb, mb, NB);
@@ -3588,6 +3605,19 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
     // `full` tiles of ungrouped operands take the unpredicated loads
     if (full && P.a_group == (1 << 30) && P.b_group == (1 << 30)) k_loop(std::true_type{});
     else k_loop(std::false_type{});
+    if (!A_RC && do_asum) {          // workgroup-uniform: reduce the threads' column sums over the row groups, one slab row per split
+        constexpr int W4 = BM / 4, RG = 256 / W4;
+        float* red = smem;                                          // [RG][BM] (the K-loop buffers are free behind its last barrier)
+        *reinterpret_cast<float4*>(red + (tid / W4) * BM + 4 * (tid % W4)) = asum4;
+        __syncthreads();
+        if (tid < BM) {
+            float t = 0.f;
+#pragma unroll
+            for (int g2 = 0; g2 < RG; ++g2) t += red[g2 * BM + tid];
+            if (i0 + tid < P.I) P.asum[(long long)split * P.asum_stride + i0 + tid] = t;
+        }
+        __syncthreads();
+    }
     // ---- epilogue.  Accumulator register q of a 32 x 32 tile holds row (q & 3) + 8 (q >> 2) + 4 half, column lane & 31.
     // Every wavefront owns 32 x PE floats of LDS (all K-loop reads are behind the barrier above); one 32-row block at a time:
     // registers -> [row][col] image -> float4 rows -> global, bias added on the way.
@@ -4915,7 +4945,10 @@ int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_con
             return fail(SINGA_E_SHAPE, "gemm_f32: split reductions write dense [I, J] partial slabs (c_split_stride apart), no epilogue options");
         if ((q.mask && q.c_group > 0) || ((uintptr_t)q.mask & 15) || ((uintptr_t)q.addend & 15))
             return fail(SINGA_E_SHAPE, "gemm_f32: mask / addend have the result's layout (a mask: plain rows only) and are 16-byte aligned");
+        if (q.asum && (a_r_contig || q.a_group > 0 || q.asum_stride < q.I))
+            return fail(SINGA_E_SHAPE, "gemm_f32: asum goes with the (0, 0) form, plain A rows, a slab of at least I floats per split");
         P.A = q.a; P.B = q.b; P.C = q.c; P.bias = q.bias; P.mask = q.mask; P.addend = q.addend; P.relu = q.relu;
+        P.asum = q.asum; P.asum_stride = q.asum_stride;
         P.lda = q.lda; P.ldb = q.ldb; P.ldc = q.ldc;
         P.a_group = q.a_group > 0 ? q.a_group : (1 << 30);
         P.b_group = q.b_group > 0 ? q.b_group : (1 << 30);

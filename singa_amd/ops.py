@@ -1269,22 +1269,25 @@ class _SO2Linear3(torch.autograd.Function):
         # dW_blk = g_blk^T X_blk: reduction over the edges, split over workgroups into dense partial slabs
         sizes = [o * k for o, k in zip(outs, ins)]
         tot = sum(sizes)
+        row = tot + outs[0]                      # + the m = 0 bias gradient: column sums of g0, taken inside the same launch
         S = _splits_for(E)
-        part = torch.empty(S, tot, device=X.device, dtype=torch.float32)
+        part = torch.empty(S, row, device=X.device, dtype=torch.float32)
         items, ai, off = [], 0, 0
-        for g, k, o, sz in zip(gs, ins, outs, sizes):
+        for n, (g, k, o, sz) in enumerate(zip(gs, ins, outs, sizes)):
             items.append(dict(a=g.data_ptr(), lda=g.stride(0), b=X.data_ptr() + 4 * ai, ldb=X.stride(0),
-                              c=part.data_ptr() + 4 * off, ldc=k, I=o, J=k, R=E, c_split_stride=tot))
+                              c=part.data_ptr() + 4 * off, ldc=k, I=o, J=k, R=E, c_split_stride=row,
+                              asum=(part.data_ptr() + 4 * tot) if n == 0 else None, asum_stride=row))
             ai, off = ai + k, off + sz
         pw = ctx.params[:3]
         if E > 0:
             _gemm(items, False, False, S)
             offs = [0, sizes[0], sizes[0] + sizes[1]]
-            gws = param_colsum(part, [(off, sz, p) for off, sz, p in zip(offs, sizes, pw)])
+            res = param_colsum(part, [(off, sz, p) for off, sz, p in zip(offs, sizes, pw)] + [(tot, outs[0], ctx.params[3])])
+            gws, gb = res[:3], res[3]
         else:
             gws = list(torch.zeros(tot, device=X.device, dtype=torch.float32).split(sizes))
+            gb = torch.zeros(outs[0], device=X.device, dtype=torch.float32)
         gws = [g.view(o, k) if g is not None else None for g, o, k in zip(gws, outs, ins)]
-        gb = param_colsum(gs[0], [(0, outs[0], ctx.params[3])])[0]
         return gX, gws[0], gb, gws[1], gws[2], None, None
 
 
@@ -1576,10 +1579,13 @@ class _LinearOwn(torch.autograd.Function):
             _gemm([dict(a=g2.data_ptr(), lda=g2.stride(0), b=w2.data_ptr(), ldb=w2.stride(0), c=gx.data_ptr(), ldc=K,
                         I=M, J=K, R=N)], True, False)
             gx = gx.view(ctx.xshape)
-        if ctx.needs_input_grad[1]:
-            gw = _tn_grad(g2, x2, wp)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = param_colsum(g2, [(0, N, bp)])[0]
+        if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2] and M > 0:
+            gw, gb = _tn_grad(g2, x2, wp, bp)                         # the bias gradient rides in the weight gradient's launch
+        else:
+            if ctx.needs_input_grad[1]:
+                gw = _tn_grad(g2, x2, wp)
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                gb = param_colsum(g2, [(0, N, bp)])[0]
         ga = g.reshape(ctx.ashape) if ctx.ashape is not None and ctx.needs_input_grad[3] else None
         return gx, gw, gb, ga
 
@@ -1626,7 +1632,7 @@ def linear_nn(x, w):
     return linear(x, w.t())
 
 
-def _tn_grad(g2, x2, param):
+def _tn_grad(g2, x2, param, bias=None):
     """dW[N, K] = g2^T x2 (reduction over the rows, split over workgroups) as partial slabs -> param_colsum: returns the
     gradient shaped like `param`, or None when it was queued into param.grad.  (Tried and dropped in round 3: queueing the
     products themselves and launching them 12 at a time - one split count and one tile shape for a mixed batch cost 12 ms
@@ -1634,9 +1640,14 @@ def _tn_grad(g2, x2, param):
     M, N = g2.shape
     K = x2.shape[1]
     S = _tn_splits(M, N, K)
-    part = torch.empty(S, N * K, device=g2.device, dtype=torch.float32)
+    row = N * K + (N if bias is not None else 0)         # the bias gradient's per-split column sums of g ride behind the slab
+    part = torch.empty(S, row, device=g2.device, dtype=torch.float32)
     _gemm([dict(a=g2.data_ptr(), lda=g2.stride(0), b=x2.data_ptr(), ldb=x2.stride(0), c=part.data_ptr(), ldc=K,
-                I=N, J=K, R=M, c_split_stride=N * K)], False, False, S)
+                I=N, J=K, R=M, c_split_stride=row, asum=(part.data_ptr() + 4 * N * K) if bias is not None else None,
+                asum_stride=row)], False, False, S)
+    if bias is not None:
+        gw, gb = param_colsum(part, [(0, N * K, param), (N * K, N, bias)])
+        return (gw.view(param.shape) if gw is not None else None), gb
     gw = param_colsum(part, [(0, N * K, param)])[0]
     return gw.view(param.shape) if gw is not None else None
 
@@ -1712,19 +1723,19 @@ class _LinearMulti(torch.autograd.Function):
             gx = gx.view(ctx.xshape)
         sizes = [n * K for n in ns]
         S = _tn_splits(M, max(ns), K)
-        part = torch.empty(S, tot * K, device=x2.device, dtype=torch.float32)
+        row = tot * K + tot                       # weight-gradient slabs + the bias gradients (column sums of G, same launch)
+        part = torch.empty(S, row, device=x2.device, dtype=torch.float32)
         items, off, poff = [], 0, 0
         for n, sz in zip(ns, sizes):
             items.append(dict(a=gp + 4 * off, lda=ldg, b=x2.data_ptr(), ldb=x2.stride(0), c=part.data_ptr() + 4 * poff, ldc=K,
-                              I=n, J=K, R=M, c_split_stride=tot * K))
+                              I=n, J=K, R=M, c_split_stride=row, asum=part.data_ptr() + 4 * (tot * K + off), asum_stride=row))
             off, poff = off + n, poff + sz
         _gemm(items, False, False, S)
         offs = [sum(sizes[:i]) for i in range(len(sizes))]
-        gws = param_colsum(part, [(o, sz, w) for o, sz, w in zip(offs, sizes, ws)])
-        gws = [gw.view(w.shape) if gw is not None else None for gw, w in zip(gws, ws)]
-        Gv = torch.as_strided(G, (M, tot), (ldg, 1))
-        coff = [sum(ns[:i]) for i in range(len(ns))]
-        gbs = param_colsum(Gv, [(o, n, b) for o, n, b in zip(coff, ns, bs)]) if all(b is not None for b in bs) else [None] * len(ns)
+        coff = [tot * K + sum(ns[:i]) for i in range(len(ns))]
+        res = param_colsum(part, [(o, sz, w) for o, sz, w in zip(offs, sizes, ws)] + [(o, n, b) for o, n, b in zip(coff, ns, bs)])
+        gws = [gw.view(w.shape) if gw is not None else None for gw, w in zip(res[:len(ns)], ws)]
+        gbs = res[len(ns):]
         out = [gx]
         for gw, gb in zip(gws, gbs):
             out += [gw, gb]
@@ -1789,10 +1800,8 @@ class _PosFFN(torch.autograd.Function):
             _gemm([dict(a=dh.data_ptr(), lda=H, b=a1.data_ptr(), ldb=a1.stride(0), c=gx.data_ptr(), ldc=K, I=M, J=K, R=H)],
                   True, False)
             gx = gx.view(ctx.xshape)
-        gw2 = _tn_grad(g2, h, w2)
-        gw1 = _tn_grad(dh, x2, w1)
-        gb2 = param_colsum(g2, [(0, N, b2)])[0]
-        gb1 = param_colsum(dh, [(0, H, b1)])[0]
+        gw2, gb2 = _tn_grad(g2, h, w2, b2)
+        gw1, gb1 = _tn_grad(dh, x2, w1, b1)
         return gx, gw1, gb1, gw2, gb2
 
 

@@ -49,11 +49,14 @@ def test_gemm_nt_nn_tn_against_float64(M, N, K, tile_shape):
         assert float((_f64(dx) - ref).abs().max()) <= tol * float(ref.abs().max()) + (0 if kind == "int" else 1e-6)
         for S in (1, 3):
             part = torch.full((S, N * K), float("nan"), device=DEV)
+            asum = torch.full((S, N), float("nan"), device=DEV)        # column sums of dy per split (the bias gradient)
             ops._gemm([dict(a=dyd.data_ptr(), lda=N, b=xd.data_ptr(), ldb=K, c=part.data_ptr(), ldc=K, I=N, J=K, R=M,
-                            c_split_stride=N * K)], False, False, S)
+                            c_split_stride=N * K, asum=asum.data_ptr(), asum_stride=N)], False, False, S)
             ref = _f64(dy).t() @ _f64(x)
             got = _f64(part).sum(0).view(N, K)
             assert float((got - ref).abs().max()) <= tol * float(ref.abs().max()) + (0 if kind == "int" else 2e-6 * M ** 0.5)
+            refb = _f64(dy).sum(0)
+            assert float((_f64(asum).sum(0) - refb).abs().max()) <= (0 if kind == "int" else 2e-6 * M ** 0.5 + 1e-6 * float(refb.abs().max()))
 
 
 def test_gemm_argument_errors():
@@ -130,7 +133,7 @@ def test_so2_convolution_matches_oracle(L, cin, cout, extra):
                                         (6, 512, 16)])
 def test_so3_linear_matches_oracle(L, cin, cout):
     """ops.so3_linear vs oracle.so3_linear (EF:655-671): output, d input, d weight per degree, d bias; N = 333 nodes (ragged
-    tiles, several reduction splits / partial rows).  Three evaluations: the VALU kernels k11s for the 16 <-> 512 shapes,
+    tiles, several reduction splits / partial rows).  Four evaluations: the k11s kernels for the 16 <-> 512 shapes (matrix-core and lane-broadcast variants),
     the MFMA kernel k11 (one grouped-row problem per degree), the BLAS libraries."""
     from singa_amd import ops
     N, K = 333, (L + 1) ** 2
@@ -143,8 +146,10 @@ def test_so3_linear_matches_oracle(L, cin, cout):
     gy = torch.randn(want.shape, generator=g)
     (want * gy).sum().backward()
     from tests.lib_gemm import _SO3LinearLib
-    for own, skinny in ((True, True), (True, False), (False, False)):
+    from singa_amd import _lib
+    for own, skinny, valu in ((True, True, 0), (True, True, 1), (True, False, 0), (False, False, 0)):
         ops._GEMM_SPLIT_ROWS, ops.USE_SKINNY_SO3 = 500, skinny
+        _lib.lib().singa_so3_skinny_variant(valu)
         so3 = ops.so3_linear if own else _SO3LinearLib.apply
         try:
             xd = x.to(DEV).requires_grad_(True)
@@ -157,6 +162,7 @@ def test_so3_linear_matches_oracle(L, cin, cout):
             assert rel_err(b.grad.cpu(), sdo["p.bias"].grad) < 1e-5
         finally:
             ops._GEMM_SPLIT_ROWS, ops.USE_SKINNY_SO3 = 2048, True
+            _lib.lib().singa_so3_skinny_variant(0)
 
 
 def test_so2_and_so3_linear_on_empty_inputs():

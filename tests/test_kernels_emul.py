@@ -26,6 +26,7 @@ def emul(tmp_path_factory):
     lib = _capi.bind(out)
     jd = np.ascontiguousarray(so3.jd_flat(6))
     assert lib.singa_init(jd.ctypes.data_as(ctypes.c_void_p), 6) == 0
+    assert lib.singa_so3_skinny_variant(1) == 0     # the lane-broadcast k11s kernels (the matrix-core ones run on the GPU only)
     return lib
 
 
