@@ -1507,28 +1507,48 @@ __device__ __forceinline__ float ssp_fast(float x) {
 }
 
 // one net on one 32-edge tile.  asel[s] = attr[edge][32 * half + s] (GEMM 1 pairs input channel s of the lower lane half
-// with channel 32 + s of the upper half in k-step s, so each half reads one contiguous 128-byte half row); w1t/w2t/b1/b2 in
-// LDS; T = H / 32 hidden tiles
+// with channel 32 + s of the upper half in k-step s, so each half reads one contiguous 128-byte half row).  The weights sit
+// in LDS as nn.Linear stores them, [out][in], with a row pitch of in + 4 floats: lane i then finds the A operands of FOUR
+// consecutive k-steps in one 16-byte read (row i, four consecutive input channels; pitches 68 and 36 are conflict-free for
+// ds_read_b128's 16-lane groups), and the read for the next four steps is issued ahead of the current four MFMAs.
+// T = H / 32 hidden tiles.
+constexpr int EMLP_P1 = 68;                                    // pitch of a [.][64] weight image
+template <int H> struct EmlpP2 { static constexpr int v = H + 4; };   // pitch of a [.][H] weight image
+
 template <int H>
-__device__ __forceinline__ void edge_mlp_tile(const float (&asel)[32], const float* __restrict__ w1t, const float* __restrict__ b1,
-                                              const float* __restrict__ w2t, const float* __restrict__ b2, int lane,
+__device__ __forceinline__ void edge_mlp_tile(const float (&asel)[32], const float* __restrict__ w1, const float* __restrict__ b1,
+                                              const float* __restrict__ w2, const float* __restrict__ b2, int lane,
                                               floatx16 (&out)[H / 32]) {
-    constexpr int T = H / 32;
+    constexpr int T = H / 32, P2 = EmlpP2<H>::v;
     const int i = lane & 31, half = lane >> 5;
     floatx16 hacc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) hacc[t][r] = b1[32 * t + 8 * (r >> 2) + 4 * half + (r & 3)];
+    {
+        const float* a1 = w1 + i * EMLP_P1 + 32 * half;
+        float4 fa[2][T];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-#pragma unroll
-        for (int t = 0; t < T; ++t)
-            hacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1t[(32 * half + s) * H + 32 * t + i], asel[s], hacc[t], 0, 0, 0);
-        // keep the A-operand reads next to their MFMAs: T LDS reads, then T MFMAs (otherwise all 64 / 128 reads of the
-        // unrolled loop are hoisted to the top and the kernel spills)
+        for (int t = 0; t < T; ++t) fa[0][t] = *reinterpret_cast<const float4*>(a1 + 32 * t * EMLP_P1);
         __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, T, 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (q + 1 < 8) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) fa[(q + 1) & 1][t] = *reinterpret_cast<const float4*>(a1 + 32 * t * EMLP_P1 + 4 * (q + 1));
+                __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float4 f = fa[q & 1][t];
+                    const float av = j == 0 ? f.x : j == 1 ? f.y : j == 2 ? f.z : f.w;
+                    hacc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, asel[4 * q + j], hacc[t], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * T, 0);
+        }
     }
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -1538,17 +1558,49 @@ __device__ __forceinline__ void edge_mlp_tile(const float (&asel)[32], const flo
     for (int u = 0; u < T; ++u)
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[u][r] = b2[32 * u + 8 * (r >> 2) + 4 * half + (r & 3)];
+    {
+        // k-step (t, s) takes hidden unit 32 t + 8 (s / 4) + 4 half + s % 4 (the unit register s of this lane half holds):
+        // steps 4 g .. 4 g + 3 of tile t are four consecutive columns of W2
+        const float* a2 = w2 + i * P2 + 4 * half;
+        float4 fb[2][T];
 #pragma unroll
-    for (int t = 0; t < T; ++t) {
+        for (int u = 0; u < T; ++u) fb[0][u] = *reinterpret_cast<const float4*>(a2 + 32 * u * P2);
+        __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int k = 32 * t + 8 * (s >> 2) + 4 * half + (s & 3);     // the hidden unit register s of this lane half holds
+        for (int g = 0; g < 4 * T; ++g) {
+            if (g + 1 < 4 * T) {
 #pragma unroll
-            for (int u = 0; u < T; ++u)
-                out[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(w2t[k * H + 32 * u + i], hacc[t][s], out[u], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, T, 0);
+                for (int u = 0; u < T; ++u)
+                    fb[(g + 1) & 1][u] = *reinterpret_cast<const float4*>(a2 + 32 * u * P2 + 32 * ((g + 1) >> 2) + 8 * ((g + 1) & 3));
+                __builtin_amdgcn_sched_group_barrier(0x100, T, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int u = 0; u < T; ++u) {
+                    const float4 f = fb[g & 1][u];
+                    const float av = j == 0 ? f.x : j == 1 ? f.y : j == 2 ? f.z : f.w;
+                    out[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, hacc[g >> 2][4 * (g & 3) + j], out[u], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * T, 0);
         }
+    }
+}
+
+// stage a weight matrix w[rows][cols] (as stored) into an LDS image of row pitch cols + 4, in two phases so that a
+// workgroup's loads of all its matrices are in flight together (one load - wait - write per element costs a memory round
+// trip each: ~25 us per workgroup for the 44 elements a thread stages in the forward kernel)
+template <int ROWS, int COLS>
+__device__ __forceinline__ void emlp_stage_load(float (&v)[ROWS * COLS / 256], const float* __restrict__ w) {
+#pragma unroll
+    for (int k = 0; k < ROWS * COLS / 256; ++k) v[k] = w[threadIdx.x + 256 * k];
+}
+template <int ROWS, int COLS>
+__device__ __forceinline__ void emlp_stage_store(float* __restrict__ img, const float (&v)[ROWS * COLS / 256]) {
+#pragma unroll
+    for (int k = 0; k < ROWS * COLS / 256; ++k) {
+        const int t = threadIdx.x + 256 * k;
+        img[(t / COLS) * (COLS + 4) + (t % COLS)] = v[k];
     }
 }
 
@@ -1558,19 +1610,28 @@ __global__ void __launch_bounds__(256, 2) edge_mlp_mfma_fwd_kernel(const float* 
                                                                 const float* __restrict__ b1v, const float* __restrict__ w2tv,
                                                                 const float* __restrict__ b2v, float* __restrict__ wk,
                                                                 float* __restrict__ wv, int E) {
-    __shared__ float lw1k[64 * 32], lw2k[32 * 32], lw1v[64 * 64], lw2v[64 * 64], lb[32 + 32 + 64 + 64];
-    // LDS images are the TRANSPOSED weights ([in][out]); the parameters arrive in nn.Linear's own [out][in] layout
-    for (int t = threadIdx.x; t < 64 * 32; t += 256) lw1k[t] = w1tk[(t & 31) * 64 + (t >> 5)];
-    for (int t = threadIdx.x; t < 32 * 32; t += 256) lw2k[t] = w2tk[(t & 31) * 32 + (t >> 5)];
-    for (int t = threadIdx.x; t < 64 * 64; t += 256) lw1v[t] = w1tv[(t & 63) * 64 + (t >> 6)], lw2v[t] = w2tv[(t & 63) * 64 + (t >> 6)];
-    if (threadIdx.x < 32) lb[threadIdx.x] = b1k[threadIdx.x], lb[32 + threadIdx.x] = b2k[threadIdx.x];
-    if (threadIdx.x < 64) lb[64 + threadIdx.x] = b1v[threadIdx.x], lb[128 + threadIdx.x] = b2v[threadIdx.x];
+    __shared__ __attribute__((aligned(16))) float lw1k[32 * EMLP_P1], lw2k[32 * 36], lw1v[64 * EMLP_P1], lw2v[64 * 68];
+    __shared__ float lb[32 + 32 + 64 + 64];
+    {                                                      // the parameters arrive in nn.Linear's own [out][in] layout
+        float s1k[8], s2k[4], s1v[16], s2v[16];
+        emlp_stage_load<32, 64>(s1k, w1tk);
+        emlp_stage_load<32, 32>(s2k, w2tk);
+        emlp_stage_load<64, 64>(s1v, w1tv);
+        emlp_stage_load<64, 64>(s2v, w2tv);
+        const int tb = threadIdx.x & 63;
+        const float bias = threadIdx.x < 64 ? (tb < 32 ? b1k[tb] : b2k[tb - 32]) : threadIdx.x < 128 ? b1v[tb] : threadIdx.x < 192 ? b2v[tb] : 0.f;
+        emlp_stage_store<32, 64>(lw1k, s1k);
+        emlp_stage_store<32, 32>(lw2k, s2k);
+        emlp_stage_store<64, 64>(lw1v, s1v);
+        emlp_stage_store<64, 64>(lw2v, s2v);
+        if (threadIdx.x < 192) lb[threadIdx.x] = bias;     // [b1k | b2k | b1v | b2v]
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
     const long long tiles = ((long long)E + 31) / 32, stride = (long long)gridDim.x * 4;
     long long tile = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     float4 nxt[8];
-    auto fetch = [&](long long tl) {                       // this lane's half row of its edge of tile tl
+    auto fetch = [&](long long tl) __attribute__((always_inline)) {      // this lane's half row of its edge of tile tl
         long long ee = tl * 32 + i;
         const float* row = attr + (ee < E ? ee : (long long)E - 1) * 64 + 32 * half;
 #pragma unroll
@@ -1612,11 +1673,23 @@ __global__ void __launch_bounds__(256, 2) edge_mlp_mfma_fwd_kernel(const float* 
 
 // Backward of one net (H hidden = H output units).  Per 32-edge tile, all on the MFMA:
 //   pre^T = W1 . attr^T (recomputed, as forward), gh^T = W2^T . g_out^T  -> both [hidden x edge] accumulators (edge on the
-//   lane), so h = ssp(pre), g_pre = gh * sigmoid(pre) are register-wise; the two tiles go to a wave-private LDS image
-//   [edge][hidden] from which the weight-gradient products read them with the edge as k index:
-//   dW2[o][j] += g_out[e][o] h[e][j],  dW1[j][c] += g_pre[e][j] attr[e][c]  (A/B operands straight from global memory for
-//   g_out / attr: 32 consecutive floats of one edge row per lane half, all issued at the top of the tile so that they
-//   arrive behind the first ~50 MFMAs).  db2 / db1 are column sums of g_out / g_pre.
+//   lane), so h = ssp(pre), g_pre = gh * sigmoid(pre) are register-wise.  The weight-gradient products run over the EDGE as
+//   k index (k-step s takes edge s in the lower lanes, 16 + s in the upper):
+//     dW2[o][j] += g_out[e][o] h[e][j]       A = g_out rows, column on the lane;  B = h^T, four k-steps per 16-byte read
+//     dW1[j][c] += g_pre[e][j] attr[e][c]    A = g_pre^T likewise;                B = attr rows, column on the lane
+//   db2 / db1 are column sums of g_out / g_pre.
+// Every operand of those products comes from a wave-private LDS region that is filled from REGISTERS: each lane holds its
+// own edge's attr / g_out half rows anyway (the B operands of the two recompute chains), so it writes them out as the row
+// images [edge][64 + 4] / [edge][H + 4] (16-byte writes, conflict-free with that pitch) and the products read them back with
+// the column on the lane (4-byte reads of consecutive addresses, base + immediate).  The first version took these operands
+// from global memory - 64 more 4-byte loads per tile and wavefront of rows that were cache hits, but ablation (tools/lab/
+// emlp_ablate.py) put 1/3 of the kernel's time on them and on the exposed row loads.  The region holds {h^T, g_out rows}
+// for the dW2 products and {g_pre^T, attr rows} for the dW1 products, one after the other (LDS operations of one wavefront
+// complete in order): 13.3 KB per wavefront, so that two workgroups still share a CU.  The attr rows go out first (the
+// pre chain is their last use in registers), which frees those registers for the rows of tile t + 1: loaded right after
+// the pre chain of tile t, with the remaining 96 MFMAs of the tile as cover.  A ragged
+// last tile is moved back to end at row E - 1 and masks the rows the tile before it has taken, rows before row 0 (fewer
+// than 32 edges in all) are clamped and masked - all loads are in range without a per-row branch.
 // A workgroup handles ONE tile of 32 hidden units (blockIdx.y): the 64-unit value net runs as two such slices, which
 // halves the accumulator registers (two wavefronts per SIMD instead of one) at no extra matrix work.
 // The gradients accumulate in registers over all tiles of a wavefront; the four wavefronts of a workgroup are summed
@@ -1627,18 +1700,34 @@ template <int H>
 __global__ void __launch_bounds__(256, 2) edge_mlp_mfma_bwd_kernel(const float* __restrict__ attr, const float* __restrict__ g_out,
                                                                    const float* __restrict__ w1t, const float* __restrict__ b1,
                                                                    const float* __restrict__ w2, float* __restrict__ part, int E) {
-    constexpr int TO = H / 32, LD = 33, HH = H / 2;
+    constexpr int TO = H / 32, LD = 36, HH = H / 2, P2 = H + 4;
     constexpr int PSZ = 32 * 64 + 32 + H * 32 + H;
-    __shared__ float lw1[64 * 32], lw2[H * 32], lb1[32], tiles[4 * 2 * 32 * LD];
-    static_assert(4 * 2 * 32 * LD >= PSZ, "the tile images double as the reduction buffer");
+    constexpr int REG = 32 * LD + 32 * EMLP_P1;         // a wavefront's region: [32][LD] transposed tile + [32][68] row image
+    __shared__ __attribute__((aligned(16))) float lw1[32 * EMLP_P1], lw2[32 * P2], tiles[4 * REG];
+    __shared__ float lb1[32];
+    static_assert(4 * REG >= PSZ, "the tile images double as the reduction buffer");
     const int ht = blockIdx.y;                          // hidden units [32 ht, 32 ht + 32)
-    for (int t = threadIdx.x; t < 64 * 32; t += 256) lw1[t] = w1t[(long long)(32 * ht + (t & 31)) * 64 + (t >> 5)];   // w1 [H][64] as stored
-    for (int t = threadIdx.x; t < H * 32; t += 256) lw2[t] = w2[(t >> 5) * H + 32 * ht + (t & 31)];
-    if (threadIdx.x < 32) lb1[threadIdx.x] = b1[32 * ht + threadIdx.x];
+    {
+        float s1[8], s2[H / 8];
+        emlp_stage_load<32, 64>(s1, w1t + (long long)32 * ht * 64);                      // rows 32 ht .. of W1 [H][64]
+#pragma unroll
+        for (int k = 0; k < H / 8; ++k) {                                                // columns 32 ht .. of W2 [H][H]
+            const int t = threadIdx.x + 256 * k;
+            s2[k] = w2[(t >> 5) * H + 32 * ht + (t & 31)];
+        }
+        const float bias = b1[32 * ht + (threadIdx.x & 31)];
+        emlp_stage_store<32, 64>(lw1, s1);
+#pragma unroll
+        for (int k = 0; k < H / 8; ++k) {                                                // ... as rows of W2^T
+            const int t = threadIdx.x + 256 * k;
+            lw2[(t & 31) * P2 + (t >> 5)] = s2[k];
+        }
+        if (threadIdx.x < 32) lb1[threadIdx.x] = bias;
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, half = lane >> 5;
-    float* th = tiles + wave * 2 * 32 * LD;             // h image   [32 edges][LD]
-    float* tg = th + 32 * LD;                           // g_pre image
+    float* tt = tiles + wave * REG;                     // h^T, then g_pre^T: [32 hidden][LD], edge along the row
+    float* rimg = tt + 32 * LD;                         // g_out rows [32 edges][P2], then attr rows [32 edges][68]
     floatx16 dw2[TO], dw1[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -1649,79 +1738,134 @@ __global__ void __launch_bounds__(256, 2) edge_mlp_mfma_bwd_kernel(const float* 
     float db1p = 0.f, db2p[TO];
 #pragma unroll
     for (int a = 0; a < TO; ++a) db2p[a] = 0.f;
-    const long long tilesN = ((long long)E + 31) / 32;
-    for (long long tile = (long long)blockIdx.x * 4 + wave; tile < tilesN; tile += (long long)gridDim.x * 4) {
-        const long long e0 = tile * 32, e = e0 + i;
-        const bool ok = e < E;
-        const long long er = ok ? e : (long long)E - 1;
-        // operands of the weight-gradient products (k = edge: step s takes edge 2s in the lower lanes, 2s + 1 in the upper)
-        float ga[16][TO], ab[16][2];
+    const long long tilesN = ((long long)E + 31) / 32, stride = (long long)gridDim.x * 4;
+    long long tile = (long long)blockIdx.x * 4 + wave;
+    float4 asel4[8], grow4[HH / 4], nasel4[8], ngrow4[HH / 4];
+    auto first_row = [&](long long tl) __attribute__((always_inline)) { return tl * 32 + 32 <= E ? tl * 32 : (long long)E - 32; };
+    auto fetch = [&](long long tl) __attribute__((always_inline)) {      // this lane's half rows of its edge of tile tl
+        const long long ee = first_row(tl) + i, er = ee > 0 ? ee : 0;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const long long ek = e0 + 2 * s + half;
-            const bool okk = ek < E;
-            const long long ekr = okk ? ek : (long long)E - 1;
+        for (int m = 0; m < 8; ++m) nasel4[m] = *reinterpret_cast<const float4*>(attr + er * 64 + 32 * half + 4 * m);
 #pragma unroll
-            for (int a = 0; a < TO; ++a) ga[s][a] = okk ? g_out[ekr * H + 32 * a + i] : 0.f;
-            ab[s][0] = okk ? attr[ekr * 64 + i] : 0.f;
-            ab[s][1] = okk ? attr[ekr * 64 + 32 + i] : 0.f;
-        }
-        float asel[32], grow[HH];
+        for (int m = 0; m < HH / 4; ++m) ngrow4[m] = *reinterpret_cast<const float4*>(g_out + er * H + HH * half + 4 * m);
+    };
+    if (tile < tilesN) fetch(tile);
+    for (; tile < tilesN; tile += stride) {
+        const long long e0 = tile * 32;
+        const bool ok = first_row(tile) + i >= e0;          // false: a row the previous tile has taken (or a row before row 0)
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const float4 v = *reinterpret_cast<const float4*>(attr + er * 64 + 32 * half + 4 * m);
-            asel[4 * m] = v.x, asel[4 * m + 1] = v.y, asel[4 * m + 2] = v.z, asel[4 * m + 3] = v.w;
-        }
+        for (int m = 0; m < 8; ++m) asel4[m] = nasel4[m];
 #pragma unroll
-        for (int m = 0; m < HH / 4; ++m) {
-            const float4 v = *reinterpret_cast<const float4*>(g_out + er * H + HH * half + 4 * m);
-            grow[4 * m] = v.x, grow[4 * m + 1] = v.y, grow[4 * m + 2] = v.z, grow[4 * m + 3] = v.w;
-        }
+        for (int m = 0; m < HH / 4; ++m) grow4[m] = ok ? ngrow4[m] : make_float4(0.f, 0.f, 0.f, 0.f);
+        // region = {g_pre^T (after the activation), attr rows (now)}
+#pragma unroll
+        for (int m = 0; m < 8; ++m) *reinterpret_cast<float4*>(rimg + i * EMLP_P1 + 32 * half + 4 * m) = asel4[m];
         floatx16 pacc, gacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             pacc[r] = lb1[8 * (r >> 2) + 4 * half + (r & 3)];
             gacc[r] = 0.f;
         }
-#pragma unroll
-        for (int s = 0; s < 32; ++s) {
-            pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(lw1[(32 * half + s) * 32 + i], asel[s], pacc, 0, 0, 0);
+        {
+            const float* a1 = lw1 + i * EMLP_P1 + 32 * half;
+            float4 fa[2];
+            fa[0] = *reinterpret_cast<const float4*>(a1);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        }
 #pragma unroll
-        for (int s = 0; s < HH; ++s) {                  // k-step s: output unit s (lower lanes) / HH + s (upper lanes)
-            gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(lw2[(HH * half + s) * 32 + i], grow[s], gacc, 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            for (int q = 0; q < 8; ++q) {
+                if (q + 1 < 8) {
+                    fa[(q + 1) & 1] = *reinterpret_cast<const float4*>(a1 + 4 * (q + 1));
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                const float4 f = fa[q & 1], b = asel4[q];
+                pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.x, b.x, pacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.y, b.y, pacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.z, b.z, pacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w, b.w, pacc, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tile + stride < tilesN) fetch(tile + stride);   // the attr registers are free now; 96 MFMAs of cover
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float* a2 = lw2 + i * P2 + HH * half;     // k-step s: output unit s (lower lanes) / HH + s (upper lanes)
+            float4 fa[2];
+            fa[0] = *reinterpret_cast<const float4*>(a2);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+            for (int q = 0; q < HH / 4; ++q) {
+                if (q + 1 < HH / 4) {
+                    fa[(q + 1) & 1] = *reinterpret_cast<const float4*>(a2 + 4 * (q + 1));
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                const float4 f = fa[q & 1], b = grow4[q];
+                gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.x, b.x, gacc, 0, 0, 0);
+                gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.y, b.y, gacc, 0, 0, 0);
+                gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.z, b.z, gacc, 0, 0, 0);
+                gacc = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w, b.w, gacc, 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
+        }
+        // ---- dW1: g_pre^T joins the attr rows; h stays in the registers of pre
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = 8 * (r >> 2) + 4 * half + (r & 3);
+            // h = ssp(p) = max(p, 0) + log(1 + t) - ln 2 and sigmoid(p) = (p >= 0 ? 1 : t) / (1 + t) share t = exp(-|p|)
             const float p = pacc[r];
-            const float sg = SINGA_RCP(1.f + __expf(-p));
-            th[i * LD + j] = ok ? ssp_fast(p) : 0.f;
-            tg[i * LD + j] = ok ? gacc[r] * sg : 0.f;
+            const float tq = __expf(-fabsf(p)), u = 1.f + tq;
+            const float sg = (p >= 0.f ? 1.f : tq) * SINGA_RCP(u);
+            tt[j * LD + i] = ok ? gacc[r] * sg : 0.f;
+            pacc[r] = ok ? fmaxf(p, 0.f) + __logf(u) - 0.69314718055994530942f : 0.f;
         }
-        __builtin_amdgcn_wave_barrier();
         if (lane < 32) {
             float c = 0.f;
-#pragma unroll 8
-            for (int row = 0; row < 32; ++row) c += tg[row * LD + lane];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const float4 v = *reinterpret_cast<const float4*>(tt + lane * LD + 4 * m);
+                c += (v.x + v.y) + (v.z + v.w);
+            }
             db1p += c;
         }
+        {
+            const float* prow = tt + i * LD + 16 * half;
+            const float* arows = rimg + 16 * half * EMLP_P1 + i;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const float hb = th[(2 * s + half) * LD + i], pa = tg[(2 * s + half) * LD + i];
+            for (int q = 0; q < 4; ++q) {
+                const float4 pa = *reinterpret_cast<const float4*>(prow + 4 * q);
 #pragma unroll
-            for (int a = 0; a < TO; ++a) {
-                db2p[a] += ga[s][a];
-                dw2[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[s][a], hb, dw2[a], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const int s = 4 * q + j;
+                    const float pv = j == 0 ? pa.x : j == 1 ? pa.y : j == 2 ? pa.z : pa.w;
+                    dw1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, arows[s * EMLP_P1], dw1[0], 0, 0, 0);
+                    dw1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pv, arows[s * EMLP_P1 + 32], dw1[1], 0, 0, 0);
+                }
             }
-            dw1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, ab[s][0], dw1[0], 0, 0, 0);
-            dw1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(pa, ab[s][1], dw1[1], 0, 0, 0);
         }
-        __builtin_amdgcn_wave_barrier();
+        // ---- dW2: region = {h^T, g_out rows (zero rows for masked edges)}
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tt[(8 * (r >> 2) + 4 * half + (r & 3)) * LD + i] = pacc[r];
+#pragma unroll
+        for (int m = 0; m < HH / 4; ++m) *reinterpret_cast<float4*>(rimg + i * P2 + HH * half + 4 * m) = grow4[m];
+        {
+            const float* hrow = tt + i * LD + 16 * half;
+            const float* grows = rimg + 16 * half * P2 + i;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 hb = *reinterpret_cast<const float4*>(hrow + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int s = 4 * q + j;
+                    const float hv = j == 0 ? hb.x : j == 1 ? hb.y : j == 2 ? hb.z : hb.w;
+#pragma unroll
+                    for (int a = 0; a < TO; ++a) {
+                        const float gv = grows[s * P2 + 32 * a];
+                        db2p[a] += gv;
+                        dw2[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv, hv, dw2[a], 0, 0, 0);
+                    }
+                }
+            }
+        }
     }
     // workgroup reduction through LDS (the tile images are free now), then one partial row per workgroup and slice
     __syncthreads();
