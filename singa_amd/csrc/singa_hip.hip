@@ -1990,6 +1990,38 @@ __device__ __forceinline__ AttnLay attn_lay(int bh, int heads, int T, int S, int
     return a;
 }
 
+// The 16 mask bytes a lane needs for one 32-key tile sit in four runs of four consecutive keys (k0 + 8 g + 4 half + 0..3, the
+// key order of the score accumulator): each run is ONE 4-byte load (any byte alignment - the target allows it), clamped so
+// that it never reaches past the row (a ragged last tile reads the row's last four bytes; attn_mask_bit shifts when the word
+// is USED - shifting at fetch time would make the prefetch wait for its own loads).  Runs that start at or past S are never
+// looked at.  Rows shorter than 4 bytes: byte loads.
+__device__ __forceinline__ void attn_mask_fetch(const unsigned char* __restrict__ mrow, int k0, int half, int S, unsigned (&w)[4]) {
+    if (S >= 4) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int kr = k0 + 8 * g + 4 * half, ks = kr < S - 4 ? kr : S - 4;
+            __builtin_memcpy(&w[g], mrow + ks, 4);
+        }
+    } else {
+#pragma unroll 1
+        for (int g = 0; g < 4; ++g) {
+            unsigned v = 0;
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                const int kr = k0 + 8 * g + 4 * half + j;
+                v |= (unsigned)mrow[kr < S ? kr : S - 1] << (8 * j);
+            }
+            w[g] = v;
+        }
+    }
+}
+// mask byte of accumulator register r (key k0 + 8 (r / 4) + 4 half + r % 4 < S) from the words attn_mask_fetch(k0) loaded
+__device__ __forceinline__ bool attn_mask_bit(const unsigned (&w)[4], int k0, int half, int S, int r) {
+    const int kr = k0 + 8 * (r >> 2) + 4 * half;
+    const int sh = 8 * ((S >= 4 && kr > S - 4 ? kr - (S - 4) : 0) + (r & 3));
+    return (sh < 32) & (((w[r >> 2] >> (sh & 31)) & 0xffu) != 0u);      // no short circuit: no branch per key
+}
+
 __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                        const float* __restrict__ v, const unsigned char* __restrict__ mask,
                                                        long long msb, long long mst, float* __restrict__ ctx,
@@ -2017,17 +2049,24 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
     for (int r = 0; r < 16; ++r) o0[r] = 0.f, o1[r] = 0.f;
     float mrun = -INFINITY, lrun = 0.f;
     float4 knext[4];
-    auto fetch_k = [&](int k0) {
+    unsigned mnext[4];
+    // the next tile's key rows AND this query's 16 mask bytes of that tile (key order of the score accumulator): read inside
+    // the softmax loop they were 16 branch - load - vmcnt(0) round trips per tile, each also waiting for the prefetched rows
+    auto fetch_k = [&](int k0) __attribute__((always_inline)) {
         const int ka = k0 + i < S ? k0 + i : S - 1;
 #pragma unroll
         for (int m4 = 0; m4 < 4; ++m4) knext[m4] = *reinterpret_cast<const float4*>(kb + (long long)ka * A.ks + 16 * half + 4 * m4);
+        attn_mask_fetch(mrow, k0, half, S, mnext);
     };
     fetch_k(0);
     for (int k0 = 0; k0 < S; k0 += 32) {
         float kreg[16], vreg[32];
+        unsigned mb[4];
 #pragma unroll
         for (int m4 = 0; m4 < 4; ++m4)
             kreg[4 * m4] = knext[m4].x, kreg[4 * m4 + 1] = knext[m4].y, kreg[4 * m4 + 2] = knext[m4].z, kreg[4 * m4 + 3] = knext[m4].w;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mb[g] = mnext[g];
         // this tile's value operands and the next tile's key rows travel while the score MFMAs and the softmax run
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
@@ -2035,7 +2074,8 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
             const float* vr = vb + (long long)(ks < S ? ks : S - 1) * A.vs + i;
             vreg[2 * s] = vr[0], vreg[2 * s + 1] = vr[32];
         }
-        if (k0 + 32 < S) fetch_k(k0 + 32);
+        fetch_k(k0 + 32 < S ? k0 + 32 : k0);      // unconditional (the last tile re-reads itself): behind a branch the
+                                                   // compiler's vmcnt counts assume the shorter path and wait for the prefetch
         floatx16 sc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = 0.f;
@@ -2045,7 +2085,9 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int kr = k0 + 8 * (r >> 2) + 4 * half + (r & 3);
-            const float val = kr < S ? (mrow[kr] ? -1e9f : sc[r] * scale) : -INFINITY;
+            const bool bit = attn_mask_bit(mb, k0, half, S, r);
+            const float vin = bit ? -1e9f : sc[r] * scale;
+            const float val = kr < S ? vin : -INFINITY;
             sc[r] = val;
             mx = fmaxf(mx, val);
         }
@@ -2093,7 +2135,7 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(const float* __restrict__
 //     dQ^T[dk x query] += K^T . dS^T takes dS^T as B operand;
 //   pass B (a wavefront = 32 keys, lane = key): s[query x key] = Q . K^T and dP = dO . V^T with the key on the lane and 16
 //     queries in registers, then dV^T[dv x key] += dO^T . P and dK^T[dk x key] += Q^T . dS with P / dS as B operands.
-__global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) attn_bwd_dq_kernel(const float* __restrict__ q, const float* __restrict__ k,
                                                           const float* __restrict__ v, const unsigned char* __restrict__ mask,
                                                           long long msb, long long mst, const float* __restrict__ ctx,
                                                           const float* __restrict__ lse, const float* __restrict__ go,
@@ -2133,16 +2175,21 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[r] = 0.f;
     float4 kn[4], vn[8];
-    auto fetch = [&](int k0) {
+    unsigned mnext[4];
+    auto fetch = [&](int k0) __attribute__((always_inline)) {    // key / value rows and the 16 mask bytes of the next tile (see attn_fwd_kernel)
         const int ka = k0 + i < S ? k0 + i : S - 1;
 #pragma unroll
         for (int m4 = 0; m4 < 4; ++m4) kn[m4] = *reinterpret_cast<const float4*>(kb + (long long)ka * A.ks + 16 * half + 4 * m4);
 #pragma unroll
         for (int m4 = 0; m4 < 8; ++m4) vn[m4] = *reinterpret_cast<const float4*>(vb + (long long)ka * A.vs + 32 * half + 4 * m4);
+        attn_mask_fetch(mrow, k0, half, S, mnext);
     };
     fetch(0);
     for (int k0 = 0; k0 < S; k0 += 32) {
         float kreg[16], vreg[32], kd[16];
+        unsigned mb[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mb[g] = mnext[g];
 #pragma unroll
         for (int m4 = 0; m4 < 4; ++m4) kreg[4 * m4] = kn[m4].x, kreg[4 * m4 + 1] = kn[m4].y, kreg[4 * m4 + 2] = kn[m4].z, kreg[4 * m4 + 3] = kn[m4].w;
 #pragma unroll
@@ -2152,7 +2199,7 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
             const int ks = k0 + 8 * (s >> 2) + 4 * half + (s & 3);
             kd[s] = kb[(long long)(ks < S ? ks : S - 1) * A.ks + i];
         }
-        if (k0 + 32 < S) fetch(k0 + 32);
+        fetch(k0 + 32 < S ? k0 + 32 : k0);        // unconditional, as in attn_fwd_kernel
         floatx16 sc, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = 0.f, dp[r] = 0.f;
@@ -2164,9 +2211,9 @@ __global__ void __launch_bounds__(256) attn_bwd_dq_kernel(const float* __restric
         for (int r = 0; r < 16; ++r) {
             const int kr = k0 + 8 * (r >> 2) + 4 * half + (r & 3);
             const bool in = kr < S;
-            const bool msk = in && mrow[kr];
+            const bool msk = in & attn_mask_bit(mb, k0, half, S, r);
             const float val = msk ? -1e9f : sc[r] * scale;
-            const float pr = in ? __expf(val - m_i) * linv_i : 0.f;
+            const float pr = __expf((in ? val : -INFINITY) - m_i) * linv_i;     // exp(-inf) = 0 past the row end, no branch
             sc[r] = msk ? 0.f : pr * (dp[r] - dq_i) * scale;        // dS^T
         }
 #pragma unroll

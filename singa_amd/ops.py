@@ -1200,8 +1200,21 @@ def _gemm(items, a_rc, b_rc, splits=1):
     _chk(_lib.lib().singa_gemm_f32(arr, n, int(a_rc), int(b_rc), int(splits), _stream()), "singa_gemm_f32")
 
 
-def _splits_for(rows):
-    return max(1, min(64, -(-rows // _GEMM_SPLIT_ROWS)))
+def _splits_for(rows, tiles=None):
+    """Split count of a weight-gradient launch over `rows` rows: one split per _GEMM_SPLIT_ROWS rows.  With `tiles` (128 x 128
+    output tiles of all problems) given and only 2-8 rounds of workgroups over the 256 CUs, the count is moved (up to 2x,
+    at least 512 rows per split) to the one whose last round is fullest: 117 tiles x 9 splits = 4.11 rounds run as 5
+    (656 us for the 16.5 k-edge shard of config 4, 566 us with 13 splits = 5.94 rounds; tools/lab/conv_split_probe.py)."""
+    base = max(1, min(64, -(-rows // _GEMM_SPLIT_ROWS)))
+    if not tiles or not 512 <= tiles * base < 2048:
+        return base
+    best, best_fill = base, 0.0
+    for S in range(base, max(base, min(64, rows // 512, 2 * base)) + 1):
+        w = tiles * S
+        fill = w / (-(-w // 256) * 256)
+        if fill > best_fill + 0.02:
+            best, best_fill = S, fill
+    return best
 
 
 def gemm_nt(x, w, bias=None, out=None):
@@ -1270,7 +1283,7 @@ class _SO2Linear3(torch.autograd.Function):
         sizes = [o * k for o, k in zip(outs, ins)]
         tot = sum(sizes)
         row = tot + outs[0]                      # + the m = 0 bias gradient: column sums of g0, taken inside the same launch
-        S = _splits_for(E)
+        S = _splits_for(E, sum(-(-o // 128) * -(-k // 128) for o, k in zip(outs, ins)))
         part = torch.empty(S, row, device=X.device, dtype=torch.float32)
         items, ai, off = [], 0, 0
         for n, (g, k, o, sz) in enumerate(zip(gs, ins, outs, sizes)):
