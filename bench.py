@@ -46,6 +46,9 @@ def parse():
                     help="N = 1, default workload only: also time the shard one rank of the 8-GPU strong split owns")
     ap.add_argument("--proxy-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-allreduce-overlap", action="store_true",
+                    help="one backward pass, all buckets reduced after it (default with several ranks: two-phase backward, the "
+                         "transformer's buckets travel while the embedding's backward pass computes)")
     ap.add_argument("--eager", action="store_true", help="run the step eagerly instead of replaying HIP graphs")
     ap.add_argument("--no-prefetch", action="store_true",
                     help="build each batch's graph structure inside its own step instead of on a second stream during the previous one")
@@ -394,7 +397,7 @@ def main():
     torch.manual_seed(cfg.train.seed)                     # same-seed init on every rank (no broadcast)
     model = SINGA(cfg, device=dev)
     model.train()
-    reducer = dp.GradAllReducer(model, always=selftest)
+    reducer = dp.GradAllReducer(model, always=selftest, phases=False if args.no_allreduce_overlap else None)
     reducer.check_same_init()
     use_graph = not args.eager
     from singa_amd.optim import Adam
@@ -638,7 +641,12 @@ def main():
                                      if bucket_mode and not args.lap_pe_resident else
                                      "carried by the batches from generation time; lap_pe_ms = graph.laplacian_pe_batched timed on its own"),
                           "graph_captures": engine.captures,
-                          "grad_allreduce_bytes": reducer.payload_bytes},
+                          "grad_allreduce_bytes": reducer.payload_bytes,
+                          "grad_allreduce": (("two-phase backward: the transformer's buckets ("
+                                              + str(sum(f.numel() * 4 for f, k in zip(reducer.flat, reducer.bucket_phase) if k == 0))
+                                              + " bytes) are reduced while the embedding's backward pass computes, the embedding's after it")
+                                             if getattr(engine, "two_phase", False) else
+                                             "after the backward pass" if (multi or selftest) else "none (one rank)")},
                "final_loss": round(final_loss, 5), "roofline": roof}
         if weak is not None:
             out["weak"] = weak

@@ -4,16 +4,26 @@ the generator's gradients per step over RCCL/xGMI (torch.distributed backend "nc
 The reference has no distributed code; the path shards by graph with no other exchange
 (SURVEY.md §8e).  Parameters that never receive a gradient (Q10: 90 tensors) are excluded statically from the
 buckets after the first backward, so no unused-parameter scan runs per step.  Buckets follow reverse execution
-order (decoder -> encoders -> equivariant blocks) and are launched asynchronously so that the first reductions
-overlap the flattening of the later ones.
+order (decoder -> encoders -> equivariant blocks) and are launched asynchronously.  With `phases` (the step engine's
+two-phase backward: transformer first, equivariant embedding second) no bucket mixes parameters of two phases, and the
+buckets of phase 0 are reduced while phase 1 of the backward pass still computes.
 """
 import torch
 import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, module, bucket_mb=32.0, group=None, always=False):
+    def __init__(self, module, bucket_mb=32.0, group=None, always=False, phases=None):
+        """phases: lists of parameters in the order their gradients become final during the backward pass; flatten / launch
+        take a phase index.  Default: module.backward_phases() if the module has one, else one phase; False: one phase."""
         self.module, self.group = module, group
+        if phases is None and hasattr(module, "backward_phases"):
+            phases = module.backward_phases()                    # SINGA: [transformer, embedding]
+        self.phases = [list(ps) for ps in phases] if phases else None
+        if self.phases is not None:
+            ids = [id(p) for ps in self.phases for p in ps]
+            assert len(ids) == len(set(ids)) and set(ids) == {id(p) for p in module.parameters()}, \
+                "phases must partition the module's parameters"
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.buckets = None
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -21,17 +31,30 @@ class GradAllReducer:
         self.active = self.world > 1 or (always and dist.is_initialized())
 
     def _build(self):
-        params = [p for p in reversed(list(self.module.parameters())) if p.grad is not None]
-        self.buckets, cur, size = [], [], 0
-        for p in params:
-            cur.append(p)
-            size += p.numel() * p.element_size()
-            if size >= self.bucket_bytes:
+        """Buckets of every phase, from the parameters that own a gradient NOW (call it after a complete backward pass)."""
+        groups = self.phases if self.phases is not None else [list(self.module.parameters())]
+        self.buckets, self.bucket_phase = [], []
+        for k, group in enumerate(groups):
+            cur, size = [], 0
+            for p in reversed(group):
+                if p.grad is None:
+                    continue
+                cur.append(p)
+                size += p.numel() * p.element_size()
+                if size >= self.bucket_bytes:
+                    self.buckets.append(cur)
+                    self.bucket_phase.append(k)
+                    cur, size = [], 0
+            if cur:
                 self.buckets.append(cur)
-                cur, size = [], 0
-        if cur:
-            self.buckets.append(cur)
+                self.bucket_phase.append(k)
         self.flat = [torch.empty(sum(p.numel() for p in b), dtype=b[0].dtype, device=b[0].device) for b in self.buckets]
+        self._views = [list(flat.split([p.numel() for p in bucket])) for flat, bucket in zip(self.flat, self.buckets)]
+        self._grads = [None] * len(self.buckets)
+        self._grads_for = [None] * len(self.buckets)
+
+    def _of(self, phase):
+        return [i for i, k in enumerate(self.bucket_phase) if phase is None or k == phase]
 
     def check_same_init(self):
         """Same-seed initialisation replaces a parameter broadcast; verify it with one checksum exchange."""
@@ -75,44 +98,64 @@ class GradAllReducer:
 
     weight = None
 
-    def reduce(self):
+    def reduce(self, skip_flatten_of=()):
         """Combine .grad over ranks in place: the mean over ranks, or - after `set_shard_weight` - the token-weighted sum.
-        Call after backward(), before the optimizer step."""
-        if not self.active:
-            return
-        self.flatten()
-        self.allreduce()
-        self.unflatten()
-
-    # The three phases of reduce().  The step engine captures flatten() at the end of its forward+backward HIP graph and
-    # unflatten() at the start of its optimizer graph, so that only the RCCL calls themselves run between the two replays.
-    def flatten(self, fresh=False):
-        """gradients -> flat bucket buffers, scaled by the combination weight.  fresh: look the .grad tensors up again."""
+        Call after backward(), before the optimizer step.  skip_flatten_of: phases whose buckets were flattened and
+        launched already (the engine's two-phase backward)."""
         if not self.active:
             return
         if self.buckets is None:
+            self._build()                                        # reduce() follows a complete backward pass
+        nph = len(self.phases) if self.phases is not None else 1
+        for k in range(nph):
+            if k not in skip_flatten_of:
+                self.flatten(phase=k)
+                self.launch(phase=k)
+        self.wait()
+        self.unflatten()
+
+    # The phases of reduce().  The step engine captures flatten() at the end of its backward HIP graph(s) and unflatten() at
+    # the start of its optimizer graph, so that only the RCCL calls themselves run between the replays.
+    def flatten(self, fresh=False, phase=None):
+        """gradients -> flat bucket buffers (of one phase, or all), scaled by the combination weight.  fresh: look the .grad
+        tensors up again."""
+        if not self.active:
+            return
+        if self.buckets is None:
+            assert phase is None, "the buckets are built from the gradients of a COMPLETE backward pass: flatten everything first"
             self._build()
         pre = self.weight if self.weight is not None else 1.0 / self.world
         # the per-tensor views of the flat buffers never change; the list of .grad tensors is rebuilt unless the caller
         # vouches (grads_token) that they are the same objects as last time - building two 634-element lists per bucket
         # cost 2 ms of host time per step
-        if self._views is None:
-            self._views = [list(flat.split([p.numel() for p in bucket])) for flat, bucket in zip(self.flat, self.buckets)]
-        if fresh or self.grads_token is None or self.grads_token != self._grads_for:
-            self._grads = [[p.grad.reshape(-1) for p in bucket] for bucket in self.buckets]
-            self._grads_for = None if fresh else self.grads_token
-        for flat, views, grads in zip(self.flat, self._views, self._grads):
-            torch._foreach_copy_(views, grads)
+        for i in self._of(phase):
+            if fresh or self.grads_token is None or self.grads_token != self._grads_for[i] or self._grads[i] is None:
+                self._grads[i] = [p.grad.reshape(-1) for p in self.buckets[i]]
+                self._grads_for[i] = None if fresh else self.grads_token
+            torch._foreach_copy_(self._views[i], self._grads[i])
             if pre != 1.0:
-                flat.mul_(pre)
+                self.flat[i].mul_(pre)
 
-    def allreduce(self):
-        """SUM all-reduce of the flat buffers (asynchronous launches, then the current stream waits for all of them)."""
+    def launch(self, phase=None):
+        """SUM all-reduce of the flat buffers of one phase (or all): asynchronous - on RCCL the collectives run on the
+        process group's own stream behind the work already queued on the current stream, and whatever is queued on the
+        current stream next (the rest of the backward pass) runs beside them.  `wait` joins them."""
         if not self.active:
             return
-        works = [dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for flat in self.flat]
+        self._works = self._works + [dist.all_reduce(self.flat[i], op=dist.ReduceOp.SUM, group=self.group, async_op=True) for i in self._of(phase)]
+
+    def wait(self):
+        """The current stream waits for every launched collective."""
+        works, self._works = self._works, []
         for w in works:
             w.wait()
+
+    def allreduce(self):
+        """launch + wait of all buckets."""
+        if not self.active:
+            return
+        self.launch()
+        self.wait()
 
     def unflatten(self):
         """flat bucket buffers -> the .grad tensors flatten() read."""
@@ -125,6 +168,7 @@ class GradAllReducer:
     # step engine: one token per captured graph); None = look them up every time
     grads_token = None
     _views = _grads = _grads_for = None
+    _works = []
 
     @property
     def payload_bytes(self):

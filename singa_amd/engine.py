@@ -106,6 +106,8 @@ class TrainStep:
         self._sink_params = None           # parameters whose gradients are accumulated in place (found in the first step)
         self._opt_gen = None               # optimizer.generation the current captures were made with
         self._pinned_table = None
+        self.g_b = None                    # two-phase backward: the second graph (embedding backward)
+        self.prefetch_priority = -1        # priority of the prefetch stream (see `prefetch`)
 
     # ------------------------------------------------------------------------------------------------ size classes
     def _class_caps(self, sizes):
@@ -169,12 +171,22 @@ class TrainStep:
         return pb
 
     # ------------------------------------------------------------------------------------------------ eager pieces
-    def _fwd_bwd(self, batch):
-        """Forward, CrossEntropy, backward.  Parameter gradients that are column sums (biases, affine parameters,
-        split-reduction weight gradients) or small transposed products are accumulated straight into `.grad` buffers
-        (ops._GradSink): the first call only records which parameters are produced that way; afterwards their buffers
-        are zeroed in one multi-tensor launch, the backward functions queue / accumulate into them and one launch pair
-        reduces the whole queue (instead of two reductions and an add per parameter)."""
+    @property
+    def two_phase(self):
+        """Several ranks with a reducer built for it (GradAllReducer(phases=[transformer, embedding])): the backward pass
+        runs in two parts - loss -> transformer parameters and the embedding's OUTPUTS, then embedding outputs -> embedding
+        parameters - and the all-reduce of the transformer's gradients (70 % of the bytes) is in flight while the second
+        part computes.  Same arithmetic as one backward() call.  The first pass ever is single-phase: the
+        reducer lays out its buckets from the gradients a complete backward pass leaves."""
+        r = self.reducer
+        return r is not None and r.active and r.phases is not None and r.buckets is not None
+
+    def _sink_begin(self):
+        """Parameter gradients that are column sums (biases, affine parameters, split-reduction weight gradients) or small
+        transposed products are accumulated straight into `.grad` buffers (ops._GradSink): the first call only records
+        which parameters are produced that way; afterwards their buffers are zeroed in one multi-tensor launch, the
+        backward functions queue / accumulate into them and one launch pair per backward phase reduces the whole queue
+        (instead of two reductions and an add per parameter)."""
         sink = ops._GradSink
         if not self.direct_grads:
             sink.on, sink.found = False, None
@@ -187,17 +199,53 @@ class TrainStep:
             if self._sink_params:
                 torch._foreach_zero_([p.grad for p in self._sink_params])
             sink.on, sink.found = True, None
+
+    @staticmethod
+    def _sink_end(ok=True):
+        sink = ops._GradSink
+        found = sink.found if ok and not sink.on else None
+        sink.on, sink.found, sink.jobs = False, None, []
+        return found
+
+    def _phase_a(self, batch, split):
+        """Forward, CrossEntropy and the backward pass down to the parameters of the transformer and - when `split` - to the
+        embedding's outputs (returned as (output, detached twin holding the gradient) pairs)."""
+        boundary = [] if split else None
+        logits = self.model(batch, boundary=boundary) if split else self.model(batch)
+        loss = self.crit(logits, batch["ligand_data"]["smiIndices_tgt"].reshape(-1))
+        loss.backward()
+        if ops._GradSink.on:
+            ops._GradSink.flush()
+        return loss, boundary
+
+    @staticmethod
+    def _phase_b(boundary):
+        """The rest of the backward pass: embedding outputs -> embedding parameters."""
+        torch.autograd.backward([x for x, _ in boundary], [d.grad for _, d in boundary])
+        if ops._GradSink.on:
+            ops._GradSink.flush()
+
+    def _fwd_bwd(self, batch):
+        """Forward, CrossEntropy, backward (eager).  Two-phase mode: the transformer's buckets are flattened and their
+        all-reduce launched between the phases; the caller's reducer.reduce(skip_flatten_of=(0,)) does the rest."""
+        self._sink_begin()
+        ok = False
         try:
-            logits = self.model(batch)
-            loss = self.crit(logits, batch["ligand_data"]["smiIndices_tgt"].reshape(-1))
-            loss.backward()
-            if sink.on:
-                sink.flush()
-            elif sink.found is not None:
-                self._sink_params = list(sink.found.values())
+            split = self.two_phase
+            loss, boundary = self._phase_a(batch, split)
+            if split:
+                self.reducer.flatten(fresh=True, phase=0)
+                self.reducer.launch(phase=0)
+                self._phase_b(boundary)
+            self._phases_done = (0,) if split else ()
+            ok = True
         finally:
-            sink.on, sink.found, sink.jobs = False, None, []
+            found = self._sink_end(ok)
+            if found is not None:
+                self._sink_params = list(found.values())
         return loss
+
+    _phases_done = ()
 
     def _update(self):
         # clip_grad_norm_(parameters, max_norm) of train.py:126.  The norm comes from the library's own chunked
@@ -227,7 +275,12 @@ class TrainStep:
         host->device copy of the next batch does not queue behind the running step either).  `step` then finds the
         batch prepared and only waits for the event."""
         if self._aux is None:
-            self._aux = torch.cuda.Stream()
+            # HIGH priority: (a) the preparation is short and the next step cannot start without it; (b) HIP maps streams
+            # onto a few hardware queues and two streams of one priority can land on the SAME queue, where their work
+            # runs one after the other - with an RCCL communicator in the process the prefetch stream shared the compute
+            # stream's queue in some runs and the preparation (8 ms at config 3) ran behind the step instead of beside it
+            # (tools/lab/dp_timeline.py); priority levels have queues of their own
+            self._aux = torch.cuda.Stream(priority=self.prefetch_priority)
         with torch.cuda.stream(self._aux):
             if callable(batch):
                 batch = batch()
@@ -273,7 +326,7 @@ class TrainStep:
         loss = self._fwd_bwd(batch)
         if self.reducer is not None:
             self.reducer.grads_token = None                          # fresh gradient tensors every eager step
-            self.reducer.reduce()
+            self.reducer.reduce(skip_flatten_of=self._phases_done)
         self._update()
         return loss
 
@@ -334,7 +387,7 @@ class TrainStep:
                 self._fwd_bwd(st)
                 if self.reducer is not None:
                     self.reducer.grads_token = None
-                    self.reducer.reduce()
+                    self.reducer.reduce(skip_flatten_of=self._phases_done)
                 self._update()
             if snap is not None:
                 self.opt.restore(snap)
@@ -343,14 +396,27 @@ class TrainStep:
         self.opt.zero_grad(set_to_none=True)
         torch.cuda.empty_cache()      # hand the warm-up's cached blocks back: the graph pool needs the same amount again
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # warm-up ran on the side stream
-        self.g_fb = torch.cuda.CUDAGraph()
-        # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
-        with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
-            self.static_loss = self._fwd_bwd(st)
-            if self.reducer is not None:
-                # the copy of this capture's gradients into the all-reduce buckets rides in the graph; between the two
-                # replays only the RCCL calls themselves are issued (GradAllReducer.flatten / allreduce / unflatten)
-                self.reducer.flatten(fresh=True)
+        self.g_fb, self.g_b = torch.cuda.CUDAGraph(), None
+        split = self.two_phase
+        try:
+            # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
+            with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
+                self._sink_begin()                                   # (allocates / zeroes the in-place gradient buffers: part of the graph)
+                self.static_loss, boundary = self._phase_a(st, split)
+                if self.reducer is not None:
+                    # the copy of this capture's gradients into the all-reduce buckets rides in the graph; between the
+                    # replays only the RCCL calls themselves are issued (GradAllReducer.flatten / launch / wait / unflatten)
+                    self.reducer.flatten(fresh=True, phase=0 if split else None)
+            if split:
+                # second graph, same memory pool (the embedding's saved activations live in it): the embedding's backward
+                # pass and its buckets; replayed while the transformer's all-reduce is in flight
+                self.g_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_b, pool=self.g_fb.pool(), capture_error_mode="thread_local"):
+                    self._phase_b(boundary)
+                    self.reducer.flatten(fresh=True, phase=1)
+                del boundary
+        finally:
+            self._sink_end(False)
         if hasattr(self.opt, "_grad_table"):
             # the .grad tensors now live in the graph pool: publish their addresses in a table of this capture's own (a
             # host->device copy, so it has to happen outside the capture; pinned until the capture is dropped)
@@ -366,7 +432,7 @@ class TrainStep:
         self._opt_gen = getattr(self.opt, "generation", 0)     # (the warm-up may have built the optimizer)
 
     # ------------------------------------------------------------------------------------------------ capture slots
-    _SLOT_FIELDS = ("static", "static_prep", "_sig", "g_fb", "g_opt", "static_loss")
+    _SLOT_FIELDS = ("static", "static_prep", "_sig", "g_fb", "g_b", "g_opt", "static_loss")
 
     def _activate(self, sig):
         """Make the capture of signature `sig` the current one (bucket mode): its static buffers, graphs and - because the
@@ -405,7 +471,7 @@ class TrainStep:
         if hasattr(self.opt, "unpin") and getattr(self.opt, "_built", False):
             self.opt.unpin()
         self._pinned_table = None
-        self.g_fb = self.g_opt = self.static = self.static_prep = self.static_loss = None
+        self.g_fb = self.g_b = self.g_opt = self.static = self.static_prep = self.static_loss = None
         EF_layers._edge_pinned.clear()
         self.opt.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
@@ -440,8 +506,13 @@ class TrainStep:
 
     def _replay(self):
         self.g_fb.replay()
-        if self.reducer is not None:
-            self.reducer.allreduce()                                # flatten / unflatten are inside the two graphs
+        if self.g_b is not None:
+            self.reducer.launch(phase=0)                            # the transformer's buckets travel ...
+            self.g_b.replay()                                       # ... while the embedding's backward pass computes
+            self.reducer.launch(phase=1)
+            self.reducer.wait()
+        elif self.reducer is not None:
+            self.reducer.allreduce()                                # flatten / unflatten are inside the graphs
         if hasattr(self.opt, "sync_hyper"):
             self.opt.sync_hyper()                            # scheduler-updated learning rate -> device scalar
         self.g_opt.replay()

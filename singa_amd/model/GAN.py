@@ -28,7 +28,16 @@ class SINGA(nn.Module):
         self.model = Transformer(config=self.config.model, protein_atom_feature_dim=self.config.model.featurizer_feat_dim,
                                  num_props=self.config.train.num_props, device=self.device)
 
-    def forward(self, g):
+    def backward_phases(self):
+        """Parameter groups in the order their gradients become final in a backward pass: the transformer (it consumes the
+        embedding's output), then the embedding.  The data-parallel step reduces the first group while the second is
+        still being computed (engine.TrainStep.two_phase)."""
+        return [list(self.model.parameters()), list(self.embedding.parameters())]
+
+    def forward(self, g, boundary=None):
+        """boundary: a list - the two embedding outputs are then cut out of the autograd graph where the transformer takes
+        them, and the list receives (output, detached twin) pairs: backward() of the loss fills the twins' .grad, and
+        torch.autograd.backward(outputs, twin gradients) continues through the embedding."""
         ld = g["ligand_data"]
         if self.config.train.num_props:
             cols = {"vina_score": torch.lt(ld["vina_score"], -7.5), "qed": torch.gt(ld["qed"], 0.6),
@@ -38,13 +47,18 @@ class SINGA(nn.Module):
             prop = None
         batch, batch_aa = g[PA]["batch"], g[LA]["batch"]
         embed = self.embedding(g)
+        xa, xl = embed[PA].embedding, embed[LA].embedding
+        if boundary is not None:
+            da, dl = xa.detach().requires_grad_(True), xl.detach().requires_grad_(True)
+            boundary += [(xa, da), (xl, dl)]
+            xa, xl = da, dl
         feat = self.config.model.featurizer_feat_dim
         knn = getattr(g, "extras", {}).get("knn", {})
         prep = getattr(g, "extras", {}).get("prepared")
         return self.model(
-            node_attr=embed[PA].embedding.reshape(-1, feat), pos=g[PA]["pos"], batch=batch,
+            node_attr=xa.reshape(-1, feat), pos=g[PA]["pos"], batch=batch,
             atom_laplacian=lap_pe(g, PA), smiles_index=ld["smiIndices_input"],
-            tgt_len=self.config.model.decoder.tgt_len, aa_node_attr=embed[LA].embedding.reshape(-1, feat),
+            tgt_len=self.config.model.decoder.tgt_len, aa_node_attr=xl.reshape(-1, feat),
             aa_pos=g[LA]["pos"], aa_batch=batch_aa, aa_laplacian=lap_pe(g, LA), prop=prop,
             knn=knn.get(PA), aa_knn=knn.get(LA), prep=prep)
 

@@ -257,3 +257,82 @@ def test_ranks_agree_on_padded_sizes(tmp_path):
     c0, caps0, c1, caps1 = a["class"]
     assert c0 == 0 and all(cap >= v for cap, v in zip(caps0, a["agreed"]))
     assert all(cap >= v for cap, v in zip(caps1, (5100, 410, 10900, 905, 1310)))
+
+
+class ToyTwoPart(torch.nn.Module):
+    """embedding -> head, with SINGA's backward_phases() contract (head first, then embedding)."""
+
+    def __init__(self):
+        super().__init__()
+        self.embedding = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 12))
+        self.model = torch.nn.Sequential(torch.nn.Linear(12, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3))
+        self.unused = torch.nn.Parameter(torch.zeros(3))
+
+    def backward_phases(self):
+        return [list(self.model.parameters()) + [self.unused], list(self.embedding.parameters())]
+
+    def forward(self, x, boundary=None):
+        e = self.embedding(x)
+        if boundary is not None:
+            d = e.detach().requires_grad_(True)
+            boundary.append((e, d))
+            e = d
+        return self.model(e)
+
+
+def _worker_phases(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    from singa_amd import dp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(7)
+    model = ToyTwoPart()
+    red = dp.GradAllReducer(model, bucket_mb=0.0001)
+    assert red.phases is not None and len(red.phases) == 2
+    data = torch.randn(10, 8, generator=torch.Generator().manual_seed(1))
+    tgt = torch.randn(10, 3, generator=torch.Generator().manual_seed(2))
+    lo, hi = dp.shard_range(10, rank, world)
+    for it in range(2):
+        model.zero_grad(set_to_none=True)
+        if it == 0:                                         # first pass: one backward, the buckets are laid out from it
+            ((model(data[lo:hi]) - tgt[lo:hi]) ** 2).mean().backward()
+            red.reduce()
+        else:                                               # the engine's two-phase order: head, launch, embedding, launch, wait
+            boundary = []
+            ((model(data[lo:hi], boundary=boundary) - tgt[lo:hi]) ** 2).mean().backward()
+            assert all(p.grad is None for p in model.embedding.parameters())
+            red.flatten(fresh=True, phase=0)
+            red.launch(phase=0)
+            torch.autograd.backward([x for x, _ in boundary], [d.grad for _, d in boundary])
+            red.reduce(skip_flatten_of=(0,))
+    if rank == 0:
+        torch.save({"grads": {n: p.grad for n, p in model.named_parameters()}, "phase": red.bucket_phase}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_phase_backward_reduces_the_same_gradients(tmp_path):
+    """GradAllReducer with phases: no bucket mixes the two parameter groups, and flatten / launch of phase 0 between the two
+    parts of the backward pass gives the gradients of one backward() + reduce()."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "p0.pt")
+    mp.spawn(_worker_phases, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    sys.path.insert(0, ROOT)
+    from singa_amd import dp
+    torch.manual_seed(7)
+    model = ToyTwoPart()
+    data = torch.randn(10, 8, generator=torch.Generator().manual_seed(1))
+    tgt = torch.randn(10, 3, generator=torch.Generator().manual_seed(2))
+    loss = sum(((model(data[slice(*dp.shard_range(10, r, 2))]) - tgt[slice(*dp.shard_range(10, r, 2))]) ** 2).mean()
+               for r in range(2)) / 2
+    loss.backward()
+    assert sorted(set(got["phase"])) == [0, 1] and got["phase"] == sorted(got["phase"])
+    for n, p in model.named_parameters():
+        if n == "unused":
+            assert got["grads"][n] is None
+        else:
+            assert torch.allclose(got["grads"][n], p.grad, atol=1e-6), n

@@ -159,3 +159,43 @@ def test_rccl_selftest_one_rank_bench():
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["final_loss"] == line["final_loss"]
     assert "RCCL self-test" in line["config"]["parallelism"]
     assert line["config"]["grad_allreduce_bytes"] > 60e6            # the L = 2 model's 64 MB of gradients went through RCCL
+
+
+def _train_one_rank(reducer_on, use_graph):
+    sys.path.insert(0, ROOT)
+    from singa_amd import dp, graph as G
+    from singa_amd.config import load_config
+    from singa_amd.engine import TrainStep
+    from singa_amd.model.GAN import SINGA
+    from singa_amd.optim import Adam
+    torch.manual_seed(11)
+    model = SINGA(load_config(lmax=2), device="cuda").eval()
+    reducer = dp.GradAllReducer(model, always=True) if reducer_on else None      # one-rank group: every collective still runs
+    eng = TrainStep(model, Adam(model.parameters(), lr=1e-4), reducer, use_graph=use_graph)
+    batch = G.synthetic_batch(3, ids=[100, 101, 102], **KW).to("cuda")
+    losses = [float(eng.step(batch).detach()) for _ in range(4)]
+    return losses, {n: p.detach().cpu().clone() for n, p in model.named_parameters()}, eng
+
+
+def test_two_phase_backward_equals_one_backward_call():
+    """engine.TrainStep with a reducer that has phases (SINGA.backward_phases): loss -> transformer parameters + embedding
+    outputs, all-reduce of the transformer's buckets launched, then embedding outputs -> embedding parameters (eager, and
+    as two HIP graphs sharing one pool).  Same parameters after four steps as the plain single-backward step."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        for use_graph in (False, True):
+            ref_l, ref_p, _ = _train_one_rank(False, use_graph)                  # one backward() call, no reducer
+            l, p, eng = _train_one_rank(True, use_graph)
+            assert eng.two_phase and eng.reducer.bucket_phase == sorted(eng.reducer.bucket_phase) and set(eng.reducer.bucket_phase) == {0, 1}
+            assert (eng.g_b is not None) == use_graph
+            for a, b in zip(l, ref_l):
+                assert abs(a - b) < 1e-6 * abs(b), (use_graph, l, ref_l)
+            worst = max(float((p[n] - ref_p[n]).norm() / (ref_p[n].norm() + 1e-12)) for n in ref_p)
+            assert worst < 1e-6, (use_graph, worst)
+    finally:
+        dist.destroy_process_group()
