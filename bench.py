@@ -46,6 +46,8 @@ def parse():
                     help="N = 1, default workload only: also time the shard one rank of the 8-GPU strong split owns")
     ap.add_argument("--proxy-steps", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prefetch-priority", choices=("high", "normal"), default="normal",
+                    help="priority of the stream the next batch is prepared on (TrainStep.prefetch_priority)")
     ap.add_argument("--no-allreduce-overlap", action="store_true",
                     help="one backward pass, all buckets reduced after it (default with several ranks: two-phase backward, the "
                          "transformer's buckets travel while the embedding's backward pass computes)")
@@ -446,6 +448,7 @@ def main():
     bucket = use_graph and D > 1
     engine = TrainStep(model, opt, reducer if multi else None, use_graph=use_graph,
                        max_grad_norm=float(cfg.train.max_grad_norm), bucket=bucket, growth=args.growth, max_cached=6)
+    engine.prefetch_priority = -1 if args.prefetch_priority == "high" else 0
     # the run's initial parameters, for the CPU oracle (and for the HIP path's own loss / gradient norm on the CPU sample,
     # computed at the very end of the run)
     hip_sample = state_file = None

@@ -81,6 +81,48 @@ def _prep_tensors(prep):
     return out
 
 
+def concurrent_stream(priority=0, tries=8, group=None):
+    """A stream whose work really runs BESIDE the current stream's.  HIP maps streams onto a few hardware queues (4 per
+    priority by default) and the work of two streams on one queue runs in order: which queue a new stream gets depends on
+    how many streams the process has created (graph captures, an RCCL communicator, ...).  A prefetch stream that shared
+    the compute stream's queue - or the queue of the process group's RCCL stream, whose all-reduce sits there waiting for the
+    backward pass - ran the batch preparation behind the step instead of beside it: 174-177 ms instead of 165-168 ms per
+    config-3 step in about half of the runs (profiles/r03z/dp_timeline.txt).  A high-priority stream is not the answer: the
+    step then took 178 ms and the 17-graph shard 47 ms instead of 32 (profiles/r03z/prefetch_priority_ab.txt).  So: probe.
+    A few ms of streaming work on the current stream, (with an RCCL `group`) a tiny all-reduce behind it, a tiny kernel on the
+    candidate: concurrent if the tiny kernel is done long before the long work.  Every rank tries all `tries` candidates
+    (the same number of collectives everywhere) and takes its first concurrent one, the last one if there is none."""
+    import torch.distributed as dist
+    rccl = group is not False and dist.is_available() and dist.is_initialized() and dist.get_backend(group) == "nccl"
+    cur = torch.cuda.current_stream()
+    big = torch.empty(64 << 20, device="cuda", dtype=torch.float32)           # 256 MB: ~0.1 ms per pass
+    small = torch.empty(1024, device="cuda", dtype=torch.float32)
+    tiny = torch.zeros(8, device="cuda", dtype=torch.float32)
+    big.zero_()
+    best = cand = None
+    for _ in range(tries):
+        cand = torch.cuda.Stream(priority=priority)
+        e0, e_long, e_small = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        torch.cuda.synchronize()
+        e0.record(cur)
+        for _ in range(40):
+            big.add_(1.0)
+        e_long.record(cur)
+        work = dist.all_reduce(tiny, group=group, async_op=True) if rccl else None    # waits on the RCCL stream for `big`
+        with torch.cuda.stream(cand):
+            small.fill_(1.0)
+            e_small.record(cand)
+        if work is not None:
+            work.wait()
+        torch.cuda.synchronize()
+        if best is None and e0.elapsed_time(e_small) < 0.5 * e0.elapsed_time(e_long):
+            best = cand
+            if not rccl:
+                break
+    del big, small, tiny
+    return best if best is not None else cand
+
+
 class TrainStep:
     """bucket=True (graph mode): ragged batches - every real CrossDocked batch has its own atom and edge counts - are
     padded with inert atoms / edges (graph.pad_batch) to the capacities of a geometric size class (x `growth` per class),
@@ -107,7 +149,7 @@ class TrainStep:
         self._opt_gen = None               # optimizer.generation the current captures were made with
         self._pinned_table = None
         self.g_b = None                    # two-phase backward: the second graph (embedding backward)
-        self.prefetch_priority = -1        # priority of the prefetch stream (see `prefetch`)
+        self.prefetch_priority = 0         # priority of the prefetch stream (see `concurrent_stream`)
 
     # ------------------------------------------------------------------------------------------------ size classes
     def _class_caps(self, sizes):
@@ -275,12 +317,8 @@ class TrainStep:
         host->device copy of the next batch does not queue behind the running step either).  `step` then finds the
         batch prepared and only waits for the event."""
         if self._aux is None:
-            # HIGH priority: (a) the preparation is short and the next step cannot start without it; (b) HIP maps streams
-            # onto a few hardware queues and two streams of one priority can land on the SAME queue, where their work
-            # runs one after the other - with an RCCL communicator in the process the prefetch stream shared the compute
-            # stream's queue in some runs and the preparation (8 ms at config 3) ran behind the step instead of beside it
-            # (tools/lab/dp_timeline.py); priority levels have queues of their own
-            self._aux = torch.cuda.Stream(priority=self.prefetch_priority)
+            r = self.reducer
+            self._aux = concurrent_stream(self.prefetch_priority, group=r.group if (r is not None and r.active) else False)
         with torch.cuda.stream(self._aux):
             if callable(batch):
                 batch = batch()
