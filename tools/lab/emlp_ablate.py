@@ -52,9 +52,9 @@ def sub(text, old, new, count=1):
 
 
 def no_act(t):
-    t = sub(t, "tt[j * LD + i] = ok ? gacc[r] * sg : 0.f;", "tt[j * LD + i] = gacc[r] + sg;")
-    return sub(t, "pacc[r] = ok ? ssp_fast(p) : 0.f;", "pacc[r] = p;").replace(
-        "const float sg = SINGA_RCP(1.f + __expf(-p));", "const float sg = p;")
+    t = sub(t, "const float tq = __expf(-fabsf(p)), u = 1.f + tq;", "const float tq = p, u = p;")
+    t = sub(t, "const float sg = (p >= 0.f ? 1.f : tq) * SINGA_RCP(u);", "const float sg = tq;")
+    return sub(t, "pacc[r] = ok ? fmaxf(p, 0.f) + __logf(u) - 0.69314718055994530942f : 0.f;", "pacc[r] = p + u;")
 
 
 def no_prefetch(t):       # bwd only: the in-loop fetch of the next tile (the first tile's rows are reused)
@@ -85,7 +85,22 @@ def coalesced_fetch_fwd(t):
                "for (int m = 0; m < 8; ++m) nxt[m] = *reinterpret_cast<const float4*>(attr + (tl * 32 < E - 32 ? tl * 32 : E - 32) * 64 + (m * 64 + lane) * 4 + 0 * (row - attr));")
 
 
-VARIANTS = [("full", lambda t: t), ("lane-linear row loads (bwd and fwd)", lambda t: coalesced_fetch_fwd(coalesced_fetch(t))), ("no activation math", no_act), ("no prefetch of the next tile", no_prefetch),
+def linear_stores_fwd(t):     # forward: same bytes stored, lane-linear addresses (1 KB contiguous per store instruction)
+    t = sub(t, "*reinterpret_cast<float4*>(wk + e * 32 + 8 * blk + 4 * half) =", "*reinterpret_cast<float4*>(wk + tile * 1024 + (blk * 64 + lane) * 4) =")
+    return sub(t, "*reinterpret_cast<float4*>(wv + e * 64 + 32 * u + 8 * blk + 4 * half) =", "*reinterpret_cast<float4*>(wv + tile * 2048 + ((u * 4 + blk) * 64 + lane) * 4) =")
+
+
+def no_stores_fwd(t):
+    t = sub(t, "*reinterpret_cast<float4*>(wk + e * 32 + 8 * blk + 4 * half) =", "if (out[0][4 * blk] == 123.456f) *reinterpret_cast<float4*>(wk + e * 32 + 8 * blk + 4 * half) =")
+    return sub(t, "*reinterpret_cast<float4*>(wv + e * 64 + 32 * u + 8 * blk + 4 * half) =", "if (out[u][4 * blk] == 123.456f) *reinterpret_cast<float4*>(wv + e * 64 + 32 * u + 8 * blk + 4 * half) =")
+
+
+def no_act_fwd(t):
+    return sub(t, "hacc[t][r] = ssp_fast(hacc[t][r]);", "hacc[t][r] = hacc[t][r] + 1.0f;")
+
+
+VARIANTS = [("full", lambda t: t), ("fwd: lane-linear stores", linear_stores_fwd), ("fwd: no stores", no_stores_fwd),
+            ("fwd: no activation math", no_act_fwd), ("fwd: no stores, no activation", lambda t: no_act_fwd(no_stores_fwd(t))), ("lane-linear row loads (bwd and fwd)", lambda t: coalesced_fetch_fwd(coalesced_fetch(t))), ("no activation math", no_act), ("no prefetch of the next tile", no_prefetch),
             ("no act + no prefetch", lambda t: no_prefetch(no_act(t))), ("no sched_barrier fences", no_fences),
             ("no bias-gradient sums", no_db)]
 os.makedirs("/tmp/emlp_abl", exist_ok=True)
