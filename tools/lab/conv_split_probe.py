@@ -65,7 +65,7 @@ for E in [int(a) for a in sys.argv[1:]] or [15000, 99302]:
         print(f"E={E} {name}: NT {t1:7.1f} us {flops / t1 / 1e6:6.1f} TF/s   NN {t2:7.1f} us {flops / t2 / 1e6:6.1f} TF/s   "
               f"TN tiles {tiles}, product S={ops._splits_for(E)}", flush=True)
         line = "    TN + column sum:"
-        for S in range(1, 33):
+        for S in (range(1, 33) if E < 40000 else (8, 12, 16, 20, 22, 24, 26, 28, 30, 32, 35, 38, 40, 44, 48, 52, 56, 59, 60, 64)):
             if S > max(1, E // 256):
                 break
             t = t_us(tn(S))
