@@ -3300,14 +3300,27 @@ __global__ void __launch_bounds__(64) rmsnorm_fwd_kernel(const float* __restrict
                                                          float eps) {
     constexpr int C = 16, K = (L + 1) * (L + 1), KC = K * C, NT = (KC + 63) / 64;
     const int lane = threadIdx.x;
-    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    float vn[NT];                                          // the next node's row, loaded while this one is reduced (see the backward kernel)
+    auto fetch = [&](int n) __attribute__((always_inline)) {
         const float* xi = x + (long long)n * KC;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int idx = lane + 64 * t;
+            vn[t] = xi[idx < KC ? idx : KC - 1];
+        }
+    };
+    if ((int)blockIdx.x < N) fetch(blockIdx.x);
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
         float v[NT];
         float s0 = 0.f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            int idx = lane + 64 * t;
-            v[t] = idx < KC ? xi[idx] : 0.f;
+            const int idx = lane + 64 * t;
+            v[t] = idx < KC ? vn[t] : 0.f;
+        }
+        {
+            const int nn = n + (int)gridDim.x;
+            fetch(nn < N ? nn : n);
         }
         if (lane < C) s0 = v[0];
         float mean0 = wave_sum(s0) * (1.0f / C);
@@ -3349,15 +3362,32 @@ __global__ void __launch_bounds__(64) rmsnorm_bwd_kernel(const float* __restrict
 #pragma unroll
     for (int t = 0; t < NT; ++t) gwp[t] = 0.f;
     float gbp = 0.f;
-    for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    // the rows of the wavefront's NEXT node travel while this node's three wave reductions run (a node is a chain load ->
+    // reduce -> reduce -> store: un-pipelined, 2,048 wavefronts moved 2.3 TB/s); every load is issued - from a clamped
+    // index - and the padding lanes are zeroed by a select, not by a branch around the load
+    float vn[NT], gn[NT];
+    auto fetch = [&](int n) __attribute__((always_inline)) {
         const float* xi = x + (long long)n * KC;
         const float* gi = gy + (long long)n * KC;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int idx = lane + 64 * t, ic = idx < KC ? idx : KC - 1;
+            vn[t] = xi[ic];
+            gn[t] = gi[ic];
+        }
+    };
+    if ((int)blockIdx.x < N) fetch(blockIdx.x);
+    for (int n = blockIdx.x; n < N; n += gridDim.x) {
         float v[NT], g[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            int idx = lane + 64 * t;
-            v[t] = idx < KC ? xi[idx] : 0.f;
-            g[t] = idx < KC ? gi[idx] : 0.f;
+            const int idx = lane + 64 * t;
+            v[t] = idx < KC ? vn[t] : 0.f;
+            g[t] = idx < KC ? gn[t] : 0.f;
+        }
+        {
+            const int nn = n + (int)gridDim.x;
+            fetch(nn < N ? nn : n);
         }
         float mean0 = wave_sum(lane < C ? v[0] : 0.f) * (1.0f / C);
         if (lane < C) v[0] -= mean0;
@@ -5257,7 +5287,7 @@ int singa_bias_ssp_bwd(const float* u, const float* b, const float* g, float* gu
 
 int singa_ln256_nparts(long long M) {
     long long blocks = (M + 3) / 4;
-    return (int)(blocks < 1 ? 1 : (blocks < 512 ? blocks : 512)) * 4;       // wavefronts = rows of the partial buffer
+    return (int)(blocks < 1 ? 1 : (blocks < 1024 ? blocks : 1024)) * 4;     // wavefronts = rows of the partial buffer
 }
 
 int singa_ln256_fwd(const float* a, const float* r, const float* gamma, const float* beta, float* y, long long M, int C,
@@ -5510,7 +5540,9 @@ int singa_colsum_multi(int n_jobs, const float* const* x, const long long* ld, c
     return check_launch("colsum_multi");
 }
 
-int singa_so3_rmsnorm_nparts(int N) { return grid_for(N, 2048); }
+// (one wavefront per partial row: 2,048 wavefronts = 2 per SIMD left the backward kernel - three dependent wave reductions per
+// node behind its loads - at 2.3 TB/s; the partial rows are only (L + 2) * 16 floats)
+int singa_so3_rmsnorm_nparts(int N) { return grid_for(N, 8192); }
 
 int singa_so3_rmsnorm_fwd(const float* x, const float* weight, const float* bias, float* y, int N, int C, int lmax,
                           float eps, void* stream) {
