@@ -105,6 +105,10 @@ int singa_alpha_logits_fwd(const float* h0, long long ld, const float* ln_w, con
                            int E, int heads, int A, float eps, void* stream);
 int singa_alpha_logits_bwd(const float* h0, long long ld, const float* ln_w, const float* ln_b, const float* dot,
                            const float* g_logits, float* g_x, float* part, int E, int heads, int A, float eps, void* stream);
+/* the same with a row stride for g_x (>= heads * A): the gradient lands in a column block of a wider tensor */
+int singa_alpha_logits_bwd_ld(const float* h0, long long ld, const float* ln_w, const float* ln_b, const float* dot,
+                              const float* g_logits, float* g_x, long long ld_gx, float* part, int E, int heads, int A, float eps,
+                              void* stream);
 
 /* k9 (softmax part) — torch_geometric.utils.softmax / torch_scatter.scatter_softmax over destination segments
  * (EF:1180; CP:66): out = exp(x - segmax) / (segsum + eps).  x, out: [E, H].  dense_segments != 0 (and H == 4) selects the
@@ -247,6 +251,12 @@ int singa_s2act_sep_fwd(const singa_seg_t* x, int nseg, const float* gate, int64
 int singa_s2act_sep_bwd(const singa_seg_t* x, int nseg, const float* gate, int64_t ldg, const float* P, const float* Q,
                         const float* A, const float* g_out, float* gx, float* g_gate, int E, int C, int lmax,
                         void* stream);
+/* the same with the input gradient written into `nseg` segments that mirror x's (rows equal, ld >= rows * C) and a row
+ * stride for g_gate (>= C): model/EF_layers.py:1148-1178 feeds this activation from column blocks of the three outputs of an
+ * SO(2) convolution, and the gradients of those outputs are assembled in place (no concatenation pass). */
+int singa_s2act_sep_bwd_seg(const singa_seg_t* x, int nseg, const float* gate, int64_t ldg, const float* P, const float* Q,
+                            const float* A, const float* g_out, const singa_seg_mut_t* gx, float* g_gate, int64_t ld_gg, int E,
+                            int C, int lmax, void* stream);
 
 /* k12 — EquivariantRMSNormArraySphericalHarmonicsV2 as instantiated by get_normalization_layer (EF:2155-2192, 2273):
  * x[N,K,C] -> y[N,K,C]; weight[L+1,C], bias[C]. */

@@ -46,6 +46,7 @@ _SIGS = {
     "singa_alpha_logits_nslots": ([I32], I32),
     "singa_alpha_logits_fwd": ([P, C.c_longlong, P, P, P, P, I32, I32, I32, F32, P], I32),
     "singa_alpha_logits_bwd": ([P, C.c_longlong, P, P, P, P, P, P, I32, I32, I32, F32, P], I32),
+    "singa_alpha_logits_bwd_ld": ([P, C.c_longlong, P, P, P, P, P, C.c_longlong, P, I32, I32, I32, F32, P], I32),
     "singa_segment_softmax_fwd": ([P, P, P, I32, I32, F32, I32, P], I32),
     "singa_segment_softmax_bwd": ([P, P, P, P, I32, I32, I32, P], I32),
     "singa_segment_wsum_fwd": ([P, P, P, P, I32, I32, I32, P], I32),
@@ -54,6 +55,7 @@ _SIGS = {
     "singa_s2act_bwd": ([C.POINTER(Seg), I32, P, I64, P, P, P, P, P, I32, I32, I32, I32, P], I32),
     "singa_s2act_sep_fwd": ([C.POINTER(Seg), I32, P, I64, P, P, P, P, I32, I32, I32, P], I32),
     "singa_s2act_sep_bwd": ([C.POINTER(Seg), I32, P, I64, P, P, P, P, P, P, I32, I32, I32, P], I32),
+    "singa_s2act_sep_bwd_seg": ([C.POINTER(Seg), I32, P, I64, P, P, P, P, C.POINTER(Seg), P, I64, I32, I32, I32, P], I32),
     "singa_so3_rmsnorm_nparts": ([I32], I32),
     "singa_so3_rmsnorm_fwd": ([P, P, P, P, I32, I32, I32, F32, P], I32),
     "singa_so3_rmsnorm_bwd": ([P, P, P, P, P, P, I32, I32, I32, F32, P], I32),

@@ -631,8 +631,8 @@ template <int HEADS>
 __global__ void __launch_bounds__(256) alpha_logits_bwd_kernel(const float* __restrict__ h0, long long ld,
                                                                const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                                const float* __restrict__ dot, const float* __restrict__ g_logits,
-                                                               float* __restrict__ g_x, float* __restrict__ part, int E,
-                                                               float eps) {
+                                                               float* __restrict__ g_x, long long ld_gx,
+                                                               float* __restrict__ part, int E, float eps) {
     const int k = threadIdx.x & 31;
     const long long slot = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
     const long long nslots = ((long long)gridDim.x * blockDim.x) >> 5;
@@ -658,7 +658,7 @@ __global__ void __launch_bounds__(256) alpha_logits_bwd_kernel(const float* __re
             const float dxh = da * w;
             const float m1 = half_sum(dxh) * (1.0f / 32.0f);
             const float m2 = half_sum(dxh * xh) * (1.0f / 32.0f);
-            g_x[e * (HEADS * 32) + h * 32 + k] = rstd * (dxh - m1 - xh * m2);
+            g_x[e * ld_gx + h * 32 + k] = rstd * (dxh - m1 - xh * m2);
         }
     }
     float* pp = part + slot * ((2 + HEADS) * 32) + k;
@@ -2909,7 +2909,7 @@ template <int L, bool EDGE, int C>
 __global__ void __launch_bounds__(256) s2act_sep_bwd_kernel(Segs x, const float* __restrict__ gate, long long ldg,
                                                             const float* __restrict__ P, const float* __restrict__ Q,
                                                             const float* __restrict__ A, const float* __restrict__ g_out,
-                                                            float* __restrict__ gx, float* __restrict__ g_gate,
+                                                            SegsMut gx, float* __restrict__ g_gate, long long ldgg,
                                                             long long EC) {
     using S = S2Sep<L, EDGE>;
     constexpr int KIN = S::KIN, NM = S::NM, RA = S::RA, MM = S::MM;
@@ -2969,10 +2969,18 @@ __global__ void __launch_bounds__(256) s2act_sep_bwd_kernel(Segs x, const float*
 #pragma unroll
         for (int i = 0; i < KIN; ++i) ga[i] = fmaf(Pb[i], S::par(i) ? vo[S::mc(i)] : ve[S::mc(i)], ga[i]);
     }
-    float* o = gx + e * KIN * C + c;
+    // the gradient goes out in the segments the caller names (e.g. straight into the column blocks of the gradient of the
+    // SO(2) convolution's three outputs - no concatenation afterwards)
+    float* o0 = gx.p[0] + e * gx.ld[0] + c;
+    float* o1 = EDGE ? gx.p[1] + e * gx.ld[1] + c : o0;
+    float* o2 = EDGE ? gx.p[2] + e * gx.ld[2] + c : o0;
 #pragma unroll
-    for (int i = 0; i < KIN; ++i) o[i * C] = ga[i];
-    g_gate[e * C + c] = gy[0] * silu_grad_fast(gate[e * ldg + c]);
+    for (int i = 0; i < KIN; ++i) {
+        if (i < r0) o0[i * C] = ga[i];
+        else if (i < r01) o1[(i - r0) * C] = ga[i];
+        else o2[(i - r01) * C] = ga[i];
+    }
+    g_gate[e * ldgg + c] = gy[0] * silu_grad_fast(gate[e * ldg + c]);
 }
 
 // ------------------------------------------------------------------------------------------------ k11s: skinny SO3 linears
@@ -4910,11 +4918,12 @@ int singa_s2act_sep_fwd(const singa_seg_t* x, int nseg, const float* gate, int64
     return check_launch("s2act_sep_fwd");
 }
 
-int singa_s2act_sep_bwd(const singa_seg_t* x, int nseg, const float* gate, int64_t ldg, const float* P, const float* Q,
-                        const float* A, const float* g_out, float* gx, float* g_gate, int E, int C, int lmax,
-                        void* stream) {
+int singa_s2act_sep_bwd_seg(const singa_seg_t* x, int nseg, const float* gate, int64_t ldg, const float* P, const float* Q,
+                            const float* A, const float* g_out, const singa_seg_mut_t* gx, float* g_gate, int64_t ld_gg, int E,
+                            int C, int lmax, void* stream) {
     Segs s;
-    if (!pack(x, nseg, &s) || !gate || !P || !Q || !A || !g_out || !gx || !g_gate)
+    SegsMut so;
+    if (!pack(x, nseg, &s) || !pack_mut(gx, nseg, &so) || !gate || !P || !Q || !A || !g_out || !g_gate)
         return fail(SINGA_E_NULL, "s2act_sep_bwd: null pointer");
     const bool edge = nseg == 3;
     if (!(edge && C == 128) && !(nseg == 1 && C == 512))
@@ -4922,14 +4931,34 @@ int singa_s2act_sep_bwd(const singa_seg_t* x, int nseg, const float* gate, int64
     if (edge && (s.rows[0] != lmax + 1 || s.rows[1] != 2 * lmax || s.rows[2] != 2 * (lmax - 1)))
         return fail(SINGA_E_SHAPE, "s2act_sep(edge): segment rows must be L+1, 2L, 2(L-1)");
     if (!edge && s.rows[0] != (lmax + 1) * (lmax + 1)) return fail(SINGA_E_SHAPE, "s2act_sep(node): rows must be (L+1)^2");
+    for (int i = 0; i < nseg; ++i)
+        if (so.rows[i] != s.rows[i] || so.ld[i] < (long long)s.rows[i] * C)
+            return fail(SINGA_E_SHAPE, "s2act_sep_bwd: gradient segments must mirror the input segments");
+    if (ld_gg < C) return fail(SINGA_E_SHAPE, "s2act_sep_bwd: row stride of g_gate below C");
     if (E <= 0) return SINGA_OK;
     long long EC = (long long)E * C;
     int blocks = (int)((EC + 255) / 256);
     const int tag = edge ? SINGA_PROF_S2_EDGE_BWD : SINGA_PROF_S2_NODE_BWD;
     SINGA_DISPATCH_S2SEP(lmax, edge, SINGA_LAUNCH(tag, E, 0, (s2act_sep_bwd_kernel<L_, EDGE_, C_>), dim3(blocks), dim3(256),
-                                                  (hipStream_t)stream, s, gate, (long long)ldg, P, Q, A, g_out, gx, g_gate,
-                                                  EC));
+                                                  (hipStream_t)stream, s, gate, (long long)ldg, P, Q, A, g_out, so, g_gate,
+                                                  (long long)ld_gg, EC));
     return check_launch("s2act_sep_bwd");
+}
+
+int singa_s2act_sep_bwd(const singa_seg_t* x, int nseg, const float* gate, int64_t ldg, const float* P, const float* Q,
+                        const float* A, const float* g_out, float* gx, float* g_gate, int E, int C, int lmax,
+                        void* stream) {
+    if (!x || nseg < 1 || nseg > 3 || !gx) return fail(SINGA_E_NULL, "s2act_sep_bwd: null pointer");
+    singa_seg_mut_t o[3];
+    long long kin = 0, at = 0;
+    for (int i = 0; i < nseg; ++i) kin += x[i].rows;
+    for (int i = 0; i < nseg; ++i) {                    // one contiguous [E, KIN, C] tensor
+        o[i].ptr = gx + at * C;
+        o[i].ld = kin * C;
+        o[i].rows = x[i].rows;
+        at += x[i].rows;
+    }
+    return singa_s2act_sep_bwd_seg(x, nseg, gate, ldg, P, Q, A, g_out, o, g_gate, C, E, C, lmax, stream);
 }
 
 
@@ -5228,15 +5257,22 @@ int singa_alpha_logits_fwd(const float* h0, long long ld, const float* ln_w, con
     return check_launch("alpha_logits_fwd");
 }
 
-int singa_alpha_logits_bwd(const float* h0, long long ld, const float* ln_w, const float* ln_b, const float* dot,
-                           const float* g_logits, float* g_x, float* part, int E, int heads, int A, float eps, void* stream) {
+int singa_alpha_logits_bwd_ld(const float* h0, long long ld, const float* ln_w, const float* ln_b, const float* dot,
+                              const float* g_logits, float* g_x, long long ld_gx, float* part, int E, int heads, int A, float eps,
+                              void* stream) {
     if (!h0 || !ln_w || !ln_b || !dot || !g_logits || !g_x || !part) return fail(SINGA_E_NULL, "alpha_logits_bwd: null pointer");
     if (heads != 7 || A != 32) return fail(SINGA_E_SHAPE, "alpha_logits: built for 7 heads x 32 alpha channels");
+    if (ld_gx < (long long)heads * A) return fail(SINGA_E_SHAPE, "alpha_logits_bwd: row stride of g_x below heads * A");
     if (E <= 0) return SINGA_OK;
     int blocks = singa_alpha_logits_nslots(E) / 8;
     hipLaunchKernelGGL((alpha_logits_bwd_kernel<7>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, h0, ld, ln_w, ln_b, dot,
-                       g_logits, g_x, part, E, eps);
+                       g_logits, g_x, ld_gx, part, E, eps);
     return check_launch("alpha_logits_bwd");
+}
+
+int singa_alpha_logits_bwd(const float* h0, long long ld, const float* ln_w, const float* ln_b, const float* dot,
+                           const float* g_logits, float* g_x, float* part, int E, int heads, int A, float eps, void* stream) {
+    return singa_alpha_logits_bwd_ld(h0, ld, ln_w, ln_b, dot, g_logits, g_x, (long long)heads * A, part, E, heads, A, eps, stream);
 }
 
 int singa_ln_silu_nparts(long long M) {

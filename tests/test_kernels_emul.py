@@ -383,6 +383,25 @@ def test_s2act_separable(emul, L, edge):
         want, want_g = x.grad, gt.grad
     assert np.abs(gx - want.numpy()).max() < 1e-4 * max(1.0, float(want.abs().max()))
     assert np.abs(gg - want_g.numpy()).max() < 1e-5
+    # the segmented form: the same gradient written into column blocks of wider tensors (what ops._EdgeHead uses to assemble
+    # the gradients of an SO(2) convolution's outputs in place) - bit-identical to the contiguous form
+    rows = [it[2] for it in items]
+    pad = 12
+    bufs = [np.full((E, pad + (C if k == 0 else 0) + r * C + 4), np.nan, np.float32) for k, r in enumerate(rows)]
+    gsegs, _ = _capi.segs([(iptr(b) + 4 * (pad + (C if k == 0 else 0)), b.shape[1], r) for k, (b, r) in enumerate(zip(bufs, rows))])
+    code = emul.singa_s2act_sep_bwd_seg(seg, n, gate_ptr, ldg, ptr(P), ptr(Q), ptr(A), ptr(g.numpy()), gsegs,
+                                        iptr(bufs[0]) + 4 * pad, bufs[0].shape[1], E, C, L, None)
+    assert code == 0, emul.singa_last_error_string()
+    at = 0
+    for k, (b, r) in enumerate(zip(bufs, rows)):
+        off = pad + (C if k == 0 else 0)
+        assert np.array_equal(b[:, off:off + r * C].reshape(E, r, C), gx[:, at:at + r])
+        assert np.isnan(b[:, :pad]).all() and np.isnan(b[:, off + r * C:]).all()
+        at += r
+    assert np.array_equal(bufs[0][:, pad:pad + C], gg)
+    short, _ = _capi.segs([(iptr(b), r * C - 1, r) for b, r in zip(bufs, rows)])
+    assert emul.singa_s2act_sep_bwd_seg(seg, n, gate_ptr, ldg, ptr(P), ptr(Q), ptr(A), ptr(g.numpy()), short,
+                                        iptr(bufs[0]), C, E, C, L, None) == -3
 
 
 @pytest.mark.parametrize("L,C", [(2, 512), (4, 512), (6, 512), (4, 112), (6, 112)])
