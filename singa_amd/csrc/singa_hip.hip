@@ -3933,7 +3933,9 @@ __global__ void __launch_bounds__(256) rowdot32_fwd_kernel(const float* __restri
     s += __shfl_xor(s, 4, 64);
     if (row < M && q == 0) out[row] = s * scale;
 }
-constexpr int ROWDOT_ROWS = 2048;       // rows per workgroup of the backward kernel
+// rows per workgroup of the backward kernel (2,048 at first: 91 workgroups for the 186 k (node, head) rows of config 3, each
+// streaming 512 KB in 64 dependent passes - 42 us for 48 MB; with 256 rows the partial buffer is 8x longer and still small)
+constexpr int ROWDOT_ROWS = 256;
 __global__ void __launch_bounds__(256) rowdot32_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ b,
                                                            float* __restrict__ gx, float* __restrict__ part, long long M, float scale) {
     __shared__ float red[32][33];

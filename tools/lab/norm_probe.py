@@ -38,3 +38,11 @@ for N in (49267, 6500):
     y2 = ops.layer_norm_residual(a, r, ln)
     f2 = lambda: torch.autograd.grad(y2, (a, r, ln.weight, ln.bias), g2, retain_graph=True)
     print(f"layer_norm_residual backward N={N}: {t_us(f2):7.1f} us (incl. the column sums of the partials)")
+
+for M in (186_000, 26_000):                                 # (node, head) rows of config 3 / of the 17-graph shard
+    x = torch.randn(M, 32, device="cuda", requires_grad=True)
+    b = torch.randn(32, device="cuda", requires_grad=True)
+    g = torch.randn(M, device="cuda")
+    y = ops.rowdot_bias(x, b, 0.25)
+    f = lambda: torch.autograd.grad(y, (x, b), g, retain_graph=True)
+    print(f"rowdot_bias backward M={M}: {t_us(f):7.1f} us (incl. the column sum of the partials)")
