@@ -5169,7 +5169,7 @@ int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_con
     if (cfg == 0) {
         long long t128 = 0;
         for (int k = 0; k < n; ++k) t128 += (long long)((probs[k].I + 127) / 128) * ((probs[k].J + 127) / 128);
-        if (t128 * splits < 384) cfg = 3;
+        if (t128 * splits < 384 || (imax <= 64 && jmax <= 64)) cfg = 3;      // (an output of at most 64 x 64 is one small tile)
         if (g_gemm_force_cfg == 0 || g_gemm_force_cfg == 3) cfg = g_gemm_force_cfg;      // tests: both tile shapes on every case
     }
     const int BM = cfg == 2 ? 32 : (cfg == 3 ? 64 : 128), BN = cfg == 1 ? 32 : (cfg == 3 ? 64 : 128);

@@ -1547,10 +1547,14 @@ def grouped_linear(h, w, heads=None):
 
 
 def _tn_splits(rows, out, cin):
-    """Split count of a weight-gradient GEMM dW[out, cin] = g^T x over `rows` rows: enough workgroups to fill the chip
-    (~512 tiles in all), at least 256 rows per split, at most 64 splits."""
+    """Split count of a weight-gradient GEMM dW[out, cin] = g^T x over `rows` rows (tools/lab/tn_split_probe.py): at most
+    4,096 rows per split; else enough workgroups to fill the chip (~512 tiles in all) but no more than 64 splits for outputs
+    of 128 x 128 and up - every split writes a partial slab - and proportionally more for smaller ones; at least 256 rows
+    per split.  (A flat cap of 64 used to sit on top: the gradient of a 20 -> 64 Linear over the 2.9 M kNN edges ran as 64
+    workgroups of 45 k rows, 1.6 ms instead of 0.3; a 32 -> 128 one over 186 k rows 101 us instead of 34.)"""
     tiles = -(-out // 128) * -(-cin // 128)
-    return max(1, min(64, max(-(-rows // 4096), -(-512 // tiles)), rows // 256))
+    fill = min(-(-512 // tiles), 64 * max(1, 16384 // max(1, out * cin)))
+    return max(1, min(1024, max(-(-rows // 4096), fill), rows // 256))
 
 
 def _own_linear_ok(x, w, b):

@@ -21,11 +21,13 @@ def t_us(fn, n=8):
     return a.elapsed_time(b) / n * 1e3
 
 
-for M in (49267, 25728, 6499, 3417):
-    for N, K in ((256, 256), (1024, 256), (256, 1024), (128, 256), (256, 400)):
+SHAPES = [(M, N, K) for M in (49267, 6499) for N, K in ((256, 256), (1024, 256), (256, 1024), (128, 256), (256, 400), (256, 8))]
+SHAPES += [(2_900_000, 64, 20), (2_900_000, 64, 64), (186_000, 128, 32), (374_000, 64, 20)]
+for M, N, K in SHAPES:
+    if True:
         g, x = torch.randn(M, N, device=dev), torch.randn(M, K, device=dev)
         line = f"M={M:6d} [{N:4d} x {K:4d}]  chosen S={ops._tn_splits(M, N, K):2d}:"
-        for S in (1, 2, 4, 8, 16, 32, 64):
+        for S in (8, 16, 32, 64, 128, 256, 512, 1024):
             if S > max(1, M // 256):
                 continue
             part = torch.empty(S, N * K, device=dev)
