@@ -16,7 +16,7 @@ want = ref()
 ctx, lse = torch.full((BH, T, 64), float("nan"), device="cuda"), torch.empty(BH, T, 2, device="cuda")
 lib = _lib.lib(); p = lambda t: ctypes.c_void_p(t.data_ptr()); st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 def run():
-    rc = lib.singa_attn_fwd(p(q), p(k), p(v), p(mask), mask.stride(0), 0, p(ctx), p(lse), BH, T, S, heads, 32, 64, 0, scale, st); assert rc == 0
+    rc = lib.singa_attn_fwd(p(q), p(k), p(v), p(mask), mask.stride(0), 0, p(ctx), p(lse), BH, T, S, heads, 32, 64, 0, 0, 0, 0, scale, st); assert rc == 0
 run(); torch.cuda.synchronize()
 print("ctx max abs err", float((ctx - want).abs().max()), "ref max", float(want.abs().max()), "nan", int(torch.isnan(ctx).sum()))
 sc = (torch.bmm(q, k.transpose(1, 2)) * scale).view(B, heads, T, S).masked_fill(mask.unsqueeze(1), -1e9).view(BH, T, S)
@@ -38,7 +38,7 @@ gq, gk, gv = torch.full_like(q, float("nan")), torch.full_like(k, float("nan")),
 dsum = torch.empty(BH, T, device="cuda")
 def runb():
     rc = lib.singa_attn_bwd(p(q), p(k), p(v), p(mask), mask.stride(0), 0, p(ctx), p(lse), p(go), p(gq), p(gk), p(gv), p(dsum),
-                            BH, T, S, heads, 32, 64, 0, scale, st); assert rc == 0
+                            BH, T, S, heads, 32, 64, 0, 0, 0, 0, scale, st); assert rc == 0
 run(); runb(); torch.cuda.synchronize()
 for nm, a, b in zip("qkv", (gq, gk, gv), ref_g):
     print(f"g_{nm}: rel err {float((a - b).norm() / b.norm()):.2e} nan {int(torch.isnan(a).sum())}")
