@@ -41,3 +41,30 @@ def test_median_and_metric_string():
     with open(os.path.join(ROOT, "BASELINE.json")) as f:
         assert bench.baseline_metric() == json.load(f)["metric"]
     assert bench.host_cores() >= 1
+
+
+def test_weight_gradient_split_policy():
+    """Host logic of the split-reduction launches (ops._tn_splits / ops._splits_for): never more than 4,096 rows per split
+    (the flat cap of 64 splits made a 20 -> 64 Linear over 2.9 M rows 64 workgroups of 45 k rows), at least 256 rows per
+    split, at most 64 splits for 128 x 128 outputs and up unless the row bound asks for more, and - for the conv launches - a
+    split count whose workgroups fill their last round over the 256 CUs."""
+    from singa_amd import ops
+    for rows, out, cin in ((2_900_000, 64, 20), (186_000, 128, 32), (49_267, 256, 256), (49_267, 1024, 256), (6_499, 256, 256),
+                           (300, 256, 256), (49_267, 256, 8)):
+        S = ops._tn_splits(rows, out, cin)
+        assert 1 <= S <= 1024
+        assert S == 1 or rows // S >= 256 or S == rows // 256, (rows, out, cin, S)
+        assert -(-rows // S) <= 4096 or S == 1024, (rows, out, cin, S)
+        if out * cin >= 128 * 128 and rows <= 64 * 4096:
+            assert S <= 64, (rows, out, cin, S)
+    assert ops._tn_splits(2_900_000, 64, 20) > 64 and ops._tn_splits(186_000, 128, 32) > 64
+    assert ops._tn_splits(49_267, 256, 256) == 64 and ops._tn_splits(49_267, 1024, 256) == 32
+    # conv weight gradients at the 17-graph shard: 117 tiles x 9 splits = 4.11 rounds -> 13 splits = 5.94 rounds
+    assert ops._splits_for(16_500) == 9 and ops._splits_for(16_500, 117) == 13
+    for rows, tiles in ((15_000, 117), (16_500, 117), (119_782, 117), (15_000, 44), (3_000, 117)):
+        S = ops._splits_for(rows, tiles)
+        base = ops._splits_for(rows)
+        assert base <= S <= max(base, 2 * base) and (S == base or rows // S >= 512)
+        if 512 <= tiles * base < 2048:
+            w, w0 = tiles * S, tiles * base
+            assert w / (-(-w // 256) * 256) >= w0 / (-(-w0 // 256) * 256)
