@@ -2903,6 +2903,121 @@ __global__ void __launch_bounds__(256) s2act_sep_fwd_kernel(Segs x, const float*
     for (int i = 1; i < KIN; ++i) o[i * C] = yv[i];
 }
 
+// Two channels per thread on packed f32 arithmetic (v_pk_fma_f32: two FMAs per lane and instruction).  The one-channel
+// kernel above issues its ~700 FMAs per ring pair one by one and sits at the scalar-FMA rate of the vector unit (edge grid:
+// 0.55 TB/s of traffic, ~72 TFLOP/s); the Legendre / Fourier coefficients are wave-uniform scalars, so every FMA pairs the
+// same coefficient with the two channels' values.  Same operations per channel in the same order: bit-identical results.
+// (The backward kernel keeps one channel per thread: two would need 264-280 registers.)
+#ifndef SINGA_V2F
+typedef float v2f __attribute__((ext_vector_type(2)));
+#else
+typedef SINGA_V2F v2f;
+#endif
+__device__ __forceinline__ v2f silu_fast2(v2f u) {
+    v2f r;
+    r[0] = silu_fast(u[0]);
+    r[1] = silu_fast(u[1]);
+    return r;
+}
+template <int RA, int MM>
+__device__ __forceinline__ void ring_to_grid2(const v2f (&v)[2 * MM + 1], v2f (&u)[RA]) {
+    constexpr auto T = make_four_tab<RA, MM>();
+    constexpr int HA = (RA - 1) / 2;
+    v2f e0 = v[MM];
+#pragma unroll
+    for (int k = 1; k <= MM; ++k) e0 = T.c[k][0] * v[MM + k] + e0;
+    u[0] = e0;
+#pragma unroll
+    for (int a = 1; a <= HA; ++a) {
+        v2f ev = v[MM], od = {0.f, 0.f};
+#pragma unroll
+        for (int k = 1; k <= MM; ++k) {
+            ev = T.c[k][a] * v[MM + k] + ev;
+            od = T.s[k][a] * v[MM - k] + od;
+        }
+        u[a] = ev + od;
+        u[RA - a] = ev - od;
+    }
+}
+template <int RA, int MM>
+__device__ __forceinline__ void ring_from_grid2(const v2f (&sv)[RA], v2f (&w)[2 * MM + 1]) {
+    constexpr auto T = make_four_tab<RA, MM>();
+    constexpr int HA = (RA - 1) / 2;
+    v2f sp[HA + 1], sm[HA + 1];
+    v2f tot = sv[0];
+#pragma unroll
+    for (int a = 1; a <= HA; ++a) {
+        sp[a] = sv[a] + sv[RA - a];
+        sm[a] = sv[a] - sv[RA - a];
+        tot += sp[a];
+    }
+    w[MM] = tot;
+#pragma unroll
+    for (int k = 1; k <= MM; ++k) {
+        v2f wc = T.c[k][0] * sv[0], ws = {0.f, 0.f};
+#pragma unroll
+        for (int a = 1; a <= HA; ++a) {
+            wc = T.c[k][a] * sp[a] + wc;
+            ws = T.s[k][a] * sm[a] + ws;
+        }
+        w[MM + k] = wc;
+        w[MM - k] = ws;
+    }
+}
+template <int L, bool EDGE, int C>
+__global__ void __launch_bounds__(256) s2act_sep_fwd2_kernel(Segs x, const float* __restrict__ gate, long long ldg,
+                                                             const float* __restrict__ P, const float* __restrict__ Q,
+                                                             float* __restrict__ out, long long EC2) {
+    using S = S2Sep<L, EDGE>;
+    constexpr int KIN = S::KIN, NM = S::NM, RA = S::RA, MM = S::MM, C2 = C / 2;
+    long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= EC2) return;
+    long long e = tid / C2;
+    int c = 2 * (int)(tid - e * C2);
+    constexpr int r0 = EDGE ? L + 1 : KIN, r01 = EDGE ? 3 * L + 1 : KIN;
+    const float* b0 = x.p[0] + e * x.ld[0] + c;
+    const float* b1 = EDGE ? x.p[1] + e * x.ld[1] + c : b0;
+    const float* b2 = EDGE ? x.p[2] + e * x.ld[2] + c : b0;
+    v2f xv[KIN], yv[KIN];
+#pragma unroll
+    for (int i = 0; i < KIN; ++i) {
+        xv[i] = *reinterpret_cast<const v2f*>(i < r0 ? b0 + i * C : (i < r01 ? b1 + (i - r0) * C : b2 + (i - r01) * C));
+        yv[i] = v2f{0.f, 0.f};
+    }
+    for (int b = 0; b < S::RB / 2; ++b) {
+        const float* Pb = P + b * KIN;
+        const float* Qb = Q + b * KIN;
+        v2f ve[NM], vo[NM];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) { ve[m] = v2f{0.f, 0.f}; vo[m] = v2f{0.f, 0.f}; }
+#pragma unroll
+        for (int i = 0; i < KIN; ++i) {
+            if (S::par(i)) vo[S::mc(i)] = Pb[i] * xv[i] + vo[S::mc(i)];
+            else ve[S::mc(i)] = Pb[i] * xv[i] + ve[S::mc(i)];
+        }
+        v2f v1[NM], v2[NM], w1[NM], w2[NM], u[RA];
+#pragma unroll
+        for (int m = 0; m < NM; ++m) { v1[m] = ve[m] + vo[m]; v2[m] = ve[m] - vo[m]; }
+        ring_to_grid2<RA, MM>(v1, u);
+#pragma unroll
+        for (int a = 0; a < RA; ++a) u[a] = silu_fast2(u[a]);
+        ring_from_grid2<RA, MM>(u, w1);
+        ring_to_grid2<RA, MM>(v2, u);
+#pragma unroll
+        for (int a = 0; a < RA; ++a) u[a] = silu_fast2(u[a]);
+        ring_from_grid2<RA, MM>(u, w2);
+#pragma unroll
+        for (int m = 0; m < NM; ++m) { ve[m] = w1[m] + w2[m]; vo[m] = w1[m] - w2[m]; }
+#pragma unroll
+        for (int i = 1; i < KIN; ++i) yv[i] = Qb[i] * (S::par(i) ? vo[S::mc(i)] : ve[S::mc(i)]) + yv[i];
+    }
+    float* o = out + e * KIN * C + c;
+    const v2f g2 = *reinterpret_cast<const v2f*>(gate + e * ldg + c);
+    *reinterpret_cast<v2f*>(o) = silu_fast2(g2);
+#pragma unroll
+    for (int i = 1; i < KIN; ++i) *reinterpret_cast<v2f*>(o + i * C) = yv[i];
+}
+
 // Backward (recompute), same pairing: per ring v = P x and gq = Q^T gy (rows i >= 1); per alpha u = A v,
 // t = SiLU'(u) * (A gq); acc = A^T t; gx_i += P[b, i] acc[m(i)].  g_gate = gy_0 * SiLU'(gate).
 template <int L, bool EDGE, int C>
@@ -4915,6 +5030,17 @@ int singa_s2act_sep_fwd(const singa_seg_t* x, int nseg, const float* gate, int64
     long long EC = (long long)E * C;
     int blocks = (int)((EC + 255) / 256);
     const int tag = edge ? SINGA_PROF_S2_EDGE_FWD : SINGA_PROF_S2_NODE_FWD;
+    // two channels per thread (packed f32) where every row start is 8-byte aligned and the registers allow it (not the
+    // L = 6 node grid: 167 registers per channel)
+    bool pair = (((uintptr_t)gate | (uintptr_t)out) & 7) == 0 && ldg % 2 == 0 && (edge || lmax <= 4);
+    for (int i = 0; i < nseg; ++i) pair = pair && ((uintptr_t)s.p[i] & 7) == 0 && s.ld[i] % 2 == 0;
+    if (pair) {
+        const long long EC2 = EC / 2;
+        blocks = (int)((EC2 + 255) / 256);
+        SINGA_DISPATCH_S2SEP(lmax, edge, SINGA_LAUNCH(tag, E, 0, (s2act_sep_fwd2_kernel<L_, EDGE_, C_>), dim3(blocks), dim3(256),
+                                                      (hipStream_t)stream, s, gate, (long long)ldg, P, Q, out, EC2));
+        return check_launch("s2act_sep_fwd");
+    }
     SINGA_DISPATCH_S2SEP(lmax, edge, SINGA_LAUNCH(tag, E, 0, (s2act_sep_fwd_kernel<L_, EDGE_, C_>), dim3(blocks), dim3(256),
                                                   (hipStream_t)stream, s, gate, (long long)ldg, P, Q, A, out, EC));
     return check_launch("s2act_sep_fwd");

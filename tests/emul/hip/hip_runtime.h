@@ -96,6 +96,10 @@ static inline floatx16_emul __builtin_amdgcn_mfma_f32_32x32x2f32(float, float, f
 
 struct floatx4_emul { float v[4]; float& operator[](int i) { return v[i]; } };
 #define SINGA_FLOATX4 floatx4_emul
+// two packed floats (the S2 activation's two-channel kernel): GCC's vector extension has the element-wise arithmetic, the
+// scalar broadcast and the subscripts the kernel uses
+typedef float v2f_emul __attribute__((vector_size(8)));
+#define SINGA_V2F v2f_emul
 static inline floatx4_emul __builtin_amdgcn_mfma_f32_16x16x4f32(float, float, floatx4_emul c, int, int, int) {
     fprintf(stderr, "emul: matrix-core kernel cannot be emulated sequentially\n");
     abort();
