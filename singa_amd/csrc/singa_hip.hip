@@ -2907,7 +2907,8 @@ __global__ void __launch_bounds__(256) s2act_sep_fwd_kernel(Segs x, const float*
 // kernel above issues its ~700 FMAs per ring pair one by one and sits at the scalar-FMA rate of the vector unit (edge grid:
 // 0.55 TB/s of traffic, ~72 TFLOP/s); the Legendre / Fourier coefficients are wave-uniform scalars, so every FMA pairs the
 // same coefficient with the two channels' values.  Same operations per channel in the same order: bit-identical results.
-// (The backward kernel keeps one channel per thread: two would need 264-280 registers.)
+// (The backward kernel keeps one channel per thread.  Its two-channel twin was built and measured: 255 registers + 76 bytes of
+// scratch at two wavefronts per SIMD for the L = 4 node grid, 2674 vs 2171 us at 49 k nodes; only the L = 2 grid gained, 9 %.)
 #ifndef SINGA_V2F
 typedef float v2f __attribute__((ext_vector_type(2)));
 #else
