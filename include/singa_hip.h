@@ -329,11 +329,6 @@ typedef struct {
     int64_t asum_stride;      /* floats between the splits' rows of asum (>= I) */
 } singa_gemm_t;
 int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_contig, int splits, void* stream);
-/* tests only: force the 128 x 128 (0) or the 64 x 64 (3) tile shape wherever the automatic choice is between those two;
- * -1 = automatic. */
-int singa_gemm_force_cfg(int cfg);
-/* resident workgroups per CU of one kernel variant (cfg 0: 128x128, 1: 128x32, 2: 32x128, 3: 64x64 tiles), for the lab probes */
-int singa_gemm_occupancy(int a_r_contig, int b_r_contig, int cfg);
 
 /* k11s - SO3_LinearV2 (model/EF_layers.py:655-671) between 16 and C = 512 channels (the feed-forward block, EF:232-262) or
  * C = 112 (the attention's output projection, EF:1201-1204; there only the backward maps 16 -> 112 channels), where
@@ -344,8 +339,6 @@ int singa_gemm_occupancy(int a_r_contig, int b_r_contig, int cfg);
  * [l][c][u] (out_cu != 0) or [l][u][c], = sum over the part's nodes and the rows k of degree l of small[n, k, u] * big[n, k, c];
  * the bias row is sum_n big[n, 0, c].  The caller adds the parts up (singa_colsum / singa_colsum_multi). */
 int singa_so3_skinny_nparts(int N, int lmax, int C);
-/* tests / lab only: 1 selects the VALU (lane-broadcast) form of the two kernels below, 0 (default) the matrix-core form */
-int singa_so3_skinny_variant(int valu);
 int singa_so3_skinny_expand(const float* small, const float* W, long long w_l, long long w_c, long long w_u, const float* bias,
                             float* big, int N, int C, int lmax, void* stream);
 int singa_so3_skinny_reduce(const float* small, const float* big, float* part, int N, int C, int lmax, int out_cu, int bias_row,
@@ -385,6 +378,15 @@ int singa_lap_pe(double* A, const int32_t* esrc, const int32_t* edst, const int3
 int singa_grad_norm(const float* const* g, const long long* sizes, const int32_t* chunk_tensor, const long long* chunk_off,
                     int nchunks, int chunk, float* partial, float* out, void* stream);
 
+/* n1 - kNN graphs of the CProMG encoders: torch_cluster.knn_graph(pos, k, batch, flow='target_to_source') at reference
+ * model/CProMG.py:293 (k = 48, protein atoms) and :330 (k = 30, ligand atoms).  pos [N, 3]; batch [N] molecule of every atom (ids outside
+ * [0, B) = atoms of no molecule: no neighbours); ptr [B + 1] first atom of every molecule (the atoms of a molecule are contiguous, as
+ * PyG's collate leaves them); max_nodes >= the largest molecule (<= 2048).  row / col [N * k] int64: row = centre atom, col = its
+ * neighbours in order of increasing distance (exact fp32 coordinate differences, ties to the lower index); -1 in both where a slot does
+ * not exist (molecules with fewer than k + 1 atoms). */
+int singa_knn_graph(const float* pos, const int32_t* batch, const long long* ptr, int B, int N, int k, int max_nodes, long long* row,
+                    long long* col, void* stream);
+
 /* Measurement helpers (bench.py): exact per-dispatch timing of the scatter-TP forward kernel with start/stop events
  * attached to the dispatch (hipExtLaunchKernelGGL) on the caller's stream, and a copy kernel with the segment kernels'
  * access shape for calibrating the PMC byte counters. */
@@ -406,7 +408,17 @@ int singa_prof_collect(float* ms, int* edges, int* nodes, int cap); /* after syn
 #define SINGA_PROF_S2_NODE_FWD 12   /* ... on the feed-forward grid (node rows, 512 channels) */
 #define SINGA_PROF_S2_NODE_BWD 13
 int singa_prof_collect_tagged(float* ms, int* tags, int* edges, int* nodes, int cap);
+/* Graph mode: per-dispatch timing INSIDE a replayed HIP graph.  (External event-record nodes are refused under stream capture by
+ * this ROCm build, so:) while a stamp buffer is set, a one-thread kernel in front of and behind every tagged launch writes the
+ * 100 MHz wall clock into the caller's device buffer `buf` (cap 64-bit words; 2 per tagged launch + 2) - plain kernel nodes,
+ * captured with the step and re-run by every replay.  Record 0 is a calibration pair with nothing in between (one dependent-
+ * launch gap + the stamp kernel's run time); singa_prof_read_stamps subtracts it.  NULL switches the mode off. */
+int singa_prof_stamps(unsigned long long* buf, int cap);
+int singa_prof_read_stamps(const unsigned long long* host_stamps, float* ms, int* tags, int* edges, int* nodes, int cap);
+int singa_prof_reset(void);
 int singa_calib_copy(const float* src, float* dst, long long n, void* stream);
+/* the same copy with 16 bytes per lane (n % 4 == 0, 16-byte aligned): the practical HBM ceiling bench.py reports */
+int singa_calib_copy16(const float* src, float* dst, long long n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -460,7 +460,7 @@ def singa_forward(sd, g, rots, L, knn_p, knn_l, lap_p, lap_l, M=2):
     emb = embedding_forward(sd, g, rots, L, M, pre="embedding.")
     K = (L + 1) ** 2
     C = emb[PA].shape[2]
-    pr = g["props"]
+    pr = g["props"].to(torch.float32)     # PyG's collate turns the per-graph Python floats into a float32 tensor
     prop = torch.stack([(pr[:, 0] < -7.5), (pr[:, 1] > 0.6), (pr[:, 2] < 4.0)], 1).to(torch.float32)  # GAN:38-42
     bp = torch.repeat_interleave(torch.arange(len(g["ptr_p"]) - 1), g["ptr_p"][1:] - g["ptr_p"][:-1])
     bl = torch.repeat_interleave(torch.arange(len(g["ptr_l"]) - 1), g["ptr_l"][1:] - g["ptr_l"][:-1])

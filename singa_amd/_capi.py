@@ -84,7 +84,6 @@ _SIGS = {
     "singa_colsum_work": ([C.c_longlong, I32], C.c_longlong),
     "singa_colsum": ([P, C.c_longlong, C.c_longlong, I32, P, P, P], I32),
     "singa_so3_skinny_nparts": ([I32, I32, I32], I32),
-    "singa_so3_skinny_variant": ([I32], I32),
     "singa_so3_skinny_expand": ([P, P, I64, I64, I64, P, P, I32, I32, I32, P], I32),
     "singa_so3_skinny_reduce": ([P, P, P, I32, I32, I32, I32, I32, P], I32),
     "singa_colsum_multi_work": ([C.c_longlong, I32], C.c_longlong),
@@ -99,22 +98,33 @@ _SIGS = {
     "singa_adam_step": ([P, P, P, P, P, P, P, I32, I32, P, P, F32, F32, F32, P], I32),
     "singa_grad_norm": ([P, P, P, P, I32, I32, P, P, P], I32),
     "singa_gemm_f32": ([C.POINTER(Gemm), I32, I32, I32, I32, P], I32),
-    "singa_gemm_occupancy": ([I32, I32, I32], I32),
-    "singa_gemm_force_cfg": ([I32], I32),
+    "singa_knn_graph": ([P, P, P, I32, I32, I32, I32, P, P, P], I32),
     "singa_prof_enable": ([I32], I32),
     "singa_prof_hint_edges": ([I32], I32),
     "singa_prof_collect": ([P, P, P, I32], I32),
     "singa_prof_collect_tagged": ([P, P, P, P, I32], I32),
+    "singa_prof_stamps": ([P, I32], I32),
+    "singa_prof_read_stamps": ([P, P, P, P, P, I32], I32),
+    "singa_prof_reset": ([], I32),
     "singa_calib_copy": ([P, P, C.c_longlong, P], I32),
+    "singa_calib_copy16": ([P, P, C.c_longlong, P], I32),
 }
 
 EXPORTS = tuple(_SIGS)
+
+# include/singa_hip_lab.h: test / lab switches, bound as well (tests/, tools/lab/ call them) but not part of the drop-in ABI
+_LAB_SIGS = {
+    "singa_so3_skinny_variant": ([I32], I32),
+    "singa_gemm_occupancy": ([I32, I32, I32], I32),
+    "singa_gemm_force_cfg": ([I32], I32),
+}
+LAB_EXPORTS = tuple(_LAB_SIGS)
 
 
 def bind(path):
     import torch  # noqa: F401  - the HIP runtime bundled with PyTorch must be the one this library resolves against
     lib = C.CDLL(path)
-    for name, (args, res) in _SIGS.items():
+    for name, (args, res) in list(_SIGS.items()) + list(_LAB_SIGS.items()):
         fn = getattr(lib, name)          # AttributeError if the library does not export a declared symbol
         fn.argtypes = args
         fn.restype = res

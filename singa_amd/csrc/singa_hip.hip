@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "../../include/singa_hip.h"
+#include "../../include/singa_hip_lab.h"
 #include "so3_index.h"
 
 namespace {
@@ -51,6 +52,13 @@ constexpr int PROF_CAP = 8192;
 ProfRec g_prof[PROF_CAP];
 int g_prof_n = 0;
 bool g_prof_on = false;
+// singa_prof_stamps(buf, cap): "graph mode" - instead of events (external event-record nodes are refused under stream capture by
+// this ROCm build) a one-thread kernel in front of and behind every tagged launch writes the 100 MHz wall clock into the caller's
+// buffer: plain kernel nodes, so they are captured with the step and re-run by every replay.  Record 0 is a calibration pair with
+// nothing in between (one dependent-launch gap + the stamp kernel's own run time), subtracted when the records are read.
+unsigned long long* g_stamp_buf = nullptr;
+int g_stamp_cap = 0;
+__global__ void stamp_kernel(unsigned long long* dst) { *dst = (unsigned long long)wall_clock64(); }
 int g_prof_edges_hint = 0;  // E of the next profiled launch (the kernel itself only needs row_ptr)
 
 // SINGA_KEEP_VGPR(x): an empty asm that pins x to its own vector register at that point (tests/emul defines it away)
@@ -70,6 +78,23 @@ int g_prof_edges_hint = 0;  // E of the next profiled launch (the kernel itself 
             r_.N = (N_);                                                                                          \
             r_.tag = (tag_);                                                                                      \
             hipExtLaunchKernelGGL(kern, grid, block, 0, (st), r_.a, r_.b, 0, __VA_ARGS__);                        \
+        } else if (g_stamp_buf && 2 * (g_prof_n + 2) <= g_stamp_cap && g_prof_n + 1 < PROF_CAP) {                 \
+            if (g_prof_n == 0) {                                                                                  \
+                g_prof[0].a = g_prof[0].b = nullptr;                                                              \
+                g_prof[0].E = g_prof[0].N = g_prof[0].tag = 0;                                                    \
+                hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (st), g_stamp_buf);                         \
+                hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (st), g_stamp_buf + 1);                     \
+                g_prof_n = 1;                                                                                     \
+            }                                                                                                     \
+            ProfRec& r_ = g_prof[g_prof_n];                                                                       \
+            r_.a = r_.b = nullptr;                                                                                \
+            r_.E = (E_);                                                                                          \
+            r_.N = (N_);                                                                                          \
+            r_.tag = (tag_);                                                                                      \
+            hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (st), g_stamp_buf + 2 * g_prof_n);              \
+            hipLaunchKernelGGL(kern, grid, block, 0, (st), __VA_ARGS__);                                          \
+            hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (st), g_stamp_buf + 2 * g_prof_n + 1);          \
+            ++g_prof_n;                                                                                           \
         } else                                                                                                    \
             hipLaunchKernelGGL(kern, grid, block, 0, (st), __VA_ARGS__);                                          \
     } while (0)
@@ -4615,6 +4640,67 @@ bool pack_mut(const singa_seg_mut_t* s, int nseg, SegsMut* out) {
         }                                                                               \
     } while (0)
 
+// ------------------------------------------------------------------------------------------------ n1: kNN graph
+// torch_cluster.knn_graph(pos, k, batch, flow='target_to_source') (reference model/CProMG.py:293,330): for every atom its k
+// nearest other atoms of the same molecule.  One wavefront per centre atom; the molecule's atoms (a contiguous index range
+// [ptr[g], ptr[g+1]) of the collated batch) are spread over the lanes, MAXC candidates per lane in registers.  Squared distances
+// are formed from exact fp32 coordinate differences, (dx*dx + dy*dy) + dz*dz without contraction, as torch_cluster's kernels
+// do - not through |a|^2 + |b|^2 - 2ab, which loses ~1e-4 A^2 at |a|^2 ~ 10^3 and flips near-ties of the k-th neighbour.
+// Selection: k rounds of a wave-wide minimum over 64-bit keys (distance bits << 32 | atom index: a non-negative float's bit
+// pattern orders like the float, ties go to the lower index); the winner's slot is retired.  Slots that do not exist (molecules
+// with fewer than k + 1 atoms, atoms of no molecule: the inert padding of graph.pad_batch) hold -1.  Output: row = centre,
+// col = neighbour, k consecutive entries per atom in order of increasing distance.
+template <int MAXC>
+__global__ __launch_bounds__(256) void knn_graph_kernel(const float* __restrict__ pos, const int* __restrict__ batch,
+                                                        const long long* __restrict__ ptr, int B, int N, int k,
+                                                        long long* __restrict__ row, long long* __restrict__ col) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= N) return;
+    const int g = batch[i];
+    long long* ro = row + (long long)i * k;
+    long long* co = col + (long long)i * k;
+    if (g < 0 || g >= B) {
+        for (int r = lane; r < k; r += 64) ro[r] = co[r] = -1;
+        return;
+    }
+    const int lo = (int)ptr[g], hi = (int)ptr[g + 1];
+    const float px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+    const unsigned long long NONE = ~0ull;
+    unsigned long long key[MAXC];
+#pragma unroll
+    for (int t = 0; t < MAXC; ++t) {
+        const int c = lo + lane + 64 * t;
+        key[t] = NONE;
+        if (c < hi && c != i) {
+            const float dx = __fsub_rn(px, pos[3 * c]), dy = __fsub_rn(py, pos[3 * c + 1]), dz = __fsub_rn(pz, pos[3 * c + 2]);
+            const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            key[t] = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)c;
+        }
+    }
+    for (int r = 0; r < k; ++r) {
+        unsigned long long best = key[0];
+#pragma unroll
+        for (int t = 1; t < MAXC; ++t) best = key[t] < best ? key[t] : best;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned blo = (unsigned)__shfl_xor((int)(unsigned)best, o, 64);
+            const unsigned bhi = (unsigned)__shfl_xor((int)(unsigned)(best >> 32), o, 64);
+            const unsigned long long other = ((unsigned long long)bhi << 32) | blo;
+            best = other < best ? other : best;
+        }
+        // the winner's slot is retired on the lane that owns it (keys are unique: the atom index is part of the key)
+#pragma unroll
+        for (int t = 0; t < MAXC; ++t)
+            if (key[t] == best) key[t] = NONE;
+        if (lane == 0) {
+            const bool have = best != NONE;
+            ro[r] = have ? (long long)i : -1;
+            co[r] = have ? (long long)(unsigned)best : -1;
+        }
+    }
+}
+
 // Calibration kernel for the PMC byte counters (MI355X_MICROARCH.md §HBM: FETCH_SIZE is only calibrated for 16-B
 // lanes): copies n floats with the access shape of the segment kernels (one dword per lane, 256 B per wave-instruction)
 // so that a known byte count can be compared with FETCH_SIZE / WRITE_SIZE.
@@ -4624,6 +4710,13 @@ __global__ void calib_copy_kernel(const float* __restrict__ src, float* __restri
     for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// The same with 16 bytes per lane (the guide's float4 copy): the practical HBM ceiling next to the 8 TB/s spec peak.
+__global__ void calib_copy16_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+
 }  // namespace
 
 // ================================================================================================= C ABI
@@ -4631,6 +4724,40 @@ extern "C" {
 
 int singa_prof_enable(int on) {
     g_prof_on = on != 0;
+    return SINGA_OK;
+}
+
+// Graph mode on (buf != NULL: a device buffer of cap 64-bit words owned by the caller, 2 per tagged launch + 2) / off (NULL).
+// While on, every tagged launch is bracketed by stamp kernels (see g_stamp_buf); the record table restarts.
+int singa_prof_stamps(unsigned long long* buf, int cap) {
+    g_stamp_buf = buf;
+    g_stamp_cap = buf ? cap : 0;
+    if (buf) {
+        g_prof_on = false;
+        g_prof_n = 0;
+    }
+    return SINGA_OK;
+}
+
+// The records of the stamped launches from a HOST copy of the stamp buffer (after a replay + synchronize): milliseconds between
+// the two stamps minus the calibration pair's, tag, E, N.  Does not change the table; singa_prof_reset forgets it.
+int singa_prof_read_stamps(const unsigned long long* host_stamps, float* ms, int* tags, int* edges, int* nodes, int cap) {
+    if (!host_stamps) return 0;
+    int n = 0;
+    double calib = (double)(host_stamps[1] - host_stamps[0]);
+    for (int i = 1; i < g_prof_n && n < cap; ++i) {
+        double ticks = (double)(host_stamps[2 * i + 1] - host_stamps[2 * i]) - calib;      // 100 MHz: 10 ns per tick
+        ms[n] = (float)(ticks * 1e-5);
+        tags[n] = g_prof[i].tag;
+        edges[n] = g_prof[i].E;
+        nodes[n] = g_prof[i].N;
+        ++n;
+    }
+    return n;
+}
+
+int singa_prof_reset(void) {
+    g_prof_n = 0;
     return SINGA_OK;
 }
 
@@ -4680,6 +4807,26 @@ int singa_calib_copy(const float* src, float* dst, long long n, void* stream) {
     if (!src || !dst) return fail(SINGA_E_NULL, "calib_copy: null pointer");
     hipLaunchKernelGGL(calib_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, src, dst, n);
     return check_launch("calib_copy");
+}
+
+int singa_knn_graph(const float* pos, const int32_t* batch, const long long* ptr, int B, int N, int k, int max_nodes, long long* row,
+                    long long* col, void* stream) {
+    if (!pos || !batch || !ptr || !row || !col) return fail(SINGA_E_NULL, "knn_graph: null pointer");
+    if (B < 0 || N < 0 || k <= 0 || max_nodes < 0 || max_nodes > 2048) return fail(SINGA_E_SHAPE, "knn_graph: k > 0 and at most 2048 atoms per molecule");
+    if (N == 0) return SINGA_OK;
+    const dim3 grid((unsigned)((N + 3) / 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (max_nodes <= 512) hipLaunchKernelGGL(knn_graph_kernel<8>, grid, block, 0, st, pos, batch, ptr, B, N, k, row, col);
+    else if (max_nodes <= 1024) hipLaunchKernelGGL(knn_graph_kernel<16>, grid, block, 0, st, pos, batch, ptr, B, N, k, row, col);
+    else hipLaunchKernelGGL(knn_graph_kernel<32>, grid, block, 0, st, pos, batch, ptr, B, N, k, row, col);
+    return check_launch("knn_graph");
+}
+
+int singa_calib_copy16(const float* src, float* dst, long long n, void* stream) {
+    if (!src || !dst) return fail(SINGA_E_NULL, "calib_copy16: null pointer");
+    if (n % 4 || ((uintptr_t)src | (uintptr_t)dst) % 16) return fail(SINGA_E_SHAPE, "calib_copy16: n % 4 == 0 and 16-byte aligned pointers");
+    hipLaunchKernelGGL(calib_copy16_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, n / 4);
+    return check_launch("calib_copy16");
 }
 
 int singa_version(void) { return 100; }

@@ -15,10 +15,14 @@ import torch.distributed as dist
 class GradAllReducer:
     def __init__(self, module, bucket_mb=32.0, group=None, always=False, phases=None):
         """phases: lists of parameters in the order their gradients become final during the backward pass; flatten / launch
-        take a phase index.  Default: module.backward_phases() if the module has one, else one phase; False: one phase."""
+        take a phase index.  True: module.backward_phases() (SINGA: [transformer, embedding] - the step engine's two-phase
+        backward with the first all-reduce in flight during the second part).  Default (None / False): ONE phase, all
+        buckets reduced after the backward pass - the overlapped order is opt-in (`bench.py / train.py
+        --allreduce-overlap`) until a run on several RCCL ranks has shown it to give the same parameters
+        (bench.py --gpus N measures and checks exactly that, `allreduce_overlap` in its line)."""
         self.module, self.group = module, group
-        if phases is None and hasattr(module, "backward_phases"):
-            phases = module.backward_phases()                    # SINGA: [transformer, embedding]
+        if phases is True:
+            phases = module.backward_phases()
         self.phases = [list(ps) for ps in phases] if phases else None
         if self.phases is not None:
             ids = [id(p) for ps in self.phases for p in ps]
@@ -52,6 +56,14 @@ class GradAllReducer:
         self._views = [list(flat.split([p.numel() for p in bucket])) for flat, bucket in zip(self.flat, self.buckets)]
         self._grads = [None] * len(self.buckets)
         self._grads_for = [None] * len(self.buckets)
+        # the combination weight lives in a one-element device tensor the (possibly captured) scaling reads: changing it
+        # after a capture - shards of a different size per batch - takes effect in every existing capture
+        self._w = torch.empty((), dtype=self.flat[0].dtype, device=self.flat[0].device) if self.flat else None
+        self._push_weight()
+
+    def _push_weight(self):
+        if getattr(self, "_w", None) is not None:
+            self._w.fill_(self.weight if self.weight is not None else 1.0 / self.world)
 
     def _of(self, phase):
         return [i for i, k in enumerate(self.bucket_phase) if phase is None or k == phase]
@@ -69,7 +81,10 @@ class GradAllReducer:
     def _side_group(self):
         """A gloo group for the small host-side agreements (no device synchronisation involved)."""
         if getattr(self, "_cpu_group", None) is None:
-            self._cpu_group = (self.group if dist.get_backend(self.group) == "gloo" else dist.new_group(backend="gloo"))
+            # short timeout: a rank that died while staging its batch must not leave the others blocked for the default 30 min
+            import datetime
+            self._cpu_group = (self.group if dist.get_backend(self.group) == "gloo" else
+                               dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=300)))
         return self._cpu_group
 
     def any_rank(self, flag):
@@ -95,8 +110,15 @@ class GradAllReducer:
         over ITS tokens, so the global-batch gradient is sum_r (tokens_r / tokens) grad_r, not the plain average.  All
         graphs carry the same number of target tokens (tgt_len), hence the weight n_local / n_global."""
         self.weight = float(n_local) / float(n_global)
+        self._push_weight()
+
+    def clear_shard_weight(self):
+        """Back to the plain mean over the ranks (equal shards)."""
+        self.weight = None
+        self._push_weight()
 
     weight = None
+    _w = None
 
     def reduce(self, skip_flatten_of=()):
         """Combine .grad over ranks in place: the mean over ranks, or - after `set_shard_weight` - the token-weighted sum.
@@ -124,7 +146,6 @@ class GradAllReducer:
         if self.buckets is None:
             assert phase is None, "the buckets are built from the gradients of a COMPLETE backward pass: flatten everything first"
             self._build()
-        pre = self.weight if self.weight is not None else 1.0 / self.world
         # the per-tensor views of the flat buffers never change; the list of .grad tensors is rebuilt unless the caller
         # vouches (grads_token) that they are the same objects as last time - building two 634-element lists per bucket
         # cost 2 ms of host time per step
@@ -133,8 +154,7 @@ class GradAllReducer:
                 self._grads[i] = [p.grad.reshape(-1) for p in self.buckets[i]]
                 self._grads_for[i] = None if fresh else self.grads_token
             torch._foreach_copy_(self._views[i], self._grads[i])
-            if pre != 1.0:
-                self.flat[i].mul_(pre)
+            self.flat[i].mul_(self._w)
 
     def launch(self, phase=None):
         """SUM all-reduce of the flat buffers of one phase (or all): asynchronous - on RCCL the collectives run on the

@@ -149,6 +149,9 @@ class TrainStep:
         self._opt_gen = None               # optimizer.generation the current captures were made with
         self._pinned_table = None
         self.g_b = None                    # two-phase backward: the second graph (embedding backward)
+        self.pre_capture_hook = None       # called right before the forward+backward graph is captured (bench.py: tagging on)
+        self.post_capture_hook = None      # ... right after the optimizer graph was captured
+        self.comm_events = None            # a list: every replayed step appends (backward done, all-reduce joined) events
         self.prefetch_priority = 0         # priority of the prefetch stream (see `concurrent_stream`)
 
     # ------------------------------------------------------------------------------------------------ size classes
@@ -169,35 +172,58 @@ class TrainStep:
         if "pad" in batch.extras and "sig" in batch.extras["pad"]:
             return batch
         B = batch.num_graphs
-        # the Laplacian positional encoding (reference: dgl.lap_pe inside forward, GAN.py:71,77): computed here, i.e. inside
-        # the step (on the prefetch stream when the batch was prefetched), for batches that do not carry one - and again on
-        # every arrival for batches marked `lap_pe_in_step` (bench.py: resident batches cycled through the timed steps must
-        # not keep the encoding of their previous visit)
-        for nt, et in ((PA, E_PP), (LA, E_LL)):
-            if "lap_pe" not in batch[nt] or batch.extras.get("lap_pe_in_step"):
-                batch[nt]["lap_pe"] = G.laplacian_pe_batched(batch[et]["edge_index"], batch[nt]["batch"], B,
-                                                             self.model.config.model.encoder.lap_dim)
         # Several ranks: sizes, layout widths and kNN edge counts are agreed with a MAX over the ranks (a few integers over
         # the gloo side group), so every rank derives the SAME size class, capacities and signature from them and the
         # ranks capture / replay in lockstep (ragged shards otherwise land in different classes on different ranks, and
-        # every new signature anywhere forces a collective re-capture everywhere).
+        # every new signature anywhere forces a collective re-capture everywhere).  Every exchange carries an error code
+        # in front: a rank whose batch fails to stage (any exception) makes ALL ranks raise together instead of leaving
+        # the others blocked in the next exchange.
         agree = self.reducer.max_ints if (self.reducer is not None and self.reducer.active) else (lambda v: list(v))
-        widths = torch.stack([(batch[nt]["ptr"][1:] - batch[nt]["ptr"][:-1]).max() for nt in (PA, LA)]).tolist()
-        agreed = agree(list(G.batch_sizes(batch)) + [int(w) for w in widths])
+
+        def together(err, values):
+            out = agree([0 if err is None else 1] + list(values))
+            if out[0]:
+                if err is not None:
+                    raise err
+                raise RuntimeError("TrainStep._stage: another rank failed while staging its batch")
+            return out[1:]
+
+        err, vals = None, [0] * 7
+        try:
+            # the Laplacian positional encoding (reference: dgl.lap_pe inside forward, GAN.py:71,77): computed here, i.e.
+            # inside the step (on the prefetch stream when the batch was prefetched), for batches that do not carry one -
+            # and again on every arrival for batches marked `lap_pe_in_step` (bench.py: resident batches cycled through the
+            # timed steps must not keep the encoding of their previous visit)
+            for nt, et in ((PA, E_PP), (LA, E_LL)):
+                if "lap_pe" not in batch[nt] or batch.extras.get("lap_pe_in_step"):
+                    batch[nt]["lap_pe"] = G.laplacian_pe_batched(batch[et]["edge_index"], batch[nt]["batch"], B,
+                                                                 self.model.config.model.encoder.lap_dim)
+            widths = torch.stack([(batch[nt]["ptr"][1:] - batch[nt]["ptr"][:-1]).max() for nt in (PA, LA)]).tolist()
+            vals = list(G.batch_sizes(batch)) + [int(w) for w in widths]
+        except Exception as e:                          # noqa: BLE001 - re-raised on every rank by `together`
+            err = e
+        agreed = together(err, vals)
         c, caps = self._class_caps(tuple(agreed[:5]))
         for nt, w in zip((PA, LA), agreed[5:]):
             self._mx[nt] = max(self._mx[nt], -(-int(w) // 16) * 16)
-        pb = G.pad_batch(batch, *caps)
+        try:
+            pb = G.pad_batch(batch, *caps)
+        except Exception as e:                          # noqa: BLE001
+            pb, err = None, e
         EF_layers._edge_cache.clear()
         for attempt in range(3):
             kp, kl = self._knn_cap.get((c, PA)), self._knn_cap.get((c, LA))
-            pb.extras["pad"].update(mx_p=self._mx[PA], mx_l=self._mx[LA], knn_p=kp, knn_l=kl)
-            pb.extras.pop("prepared", None)
-            try:
-                prep, over = self.model.prepare(pb), 0
-            except OverflowError:                       # a denser batch than the class has seen: forget, measure again
-                prep, over = None, 1
-            over, e_p, e_l = agree([over] + [prep[k]["edges"].n_edges if prep is not None else 0 for k in ("p", "l")])
+            prep, over = None, 0
+            if err is None:
+                pb.extras["pad"].update(mx_p=self._mx[PA], mx_l=self._mx[LA], knn_p=kp, knn_l=kl)
+                pb.extras.pop("prepared", None)
+                try:
+                    prep = self.model.prepare(pb)
+                except OverflowError:                   # a denser batch than the class has seen: forget, measure again
+                    over = 1
+                except Exception as e:                  # noqa: BLE001
+                    err = e
+            over, e_p, e_l = together(err, [over] + [prep[k]["edges"].n_edges if prep is not None else 0 for k in ("p", "l")])
             if over:
                 self._knn_cap.pop((c, PA), None)
                 self._knn_cap.pop((c, LA), None)
@@ -316,10 +342,7 @@ class TrainStep:
         a HeteroGraph whose tensors are complete, or a callable that makes one (run under the second stream, so a
         host->device copy of the next batch does not queue behind the running step either).  `step` then finds the
         batch prepared and only waits for the event."""
-        if self._aux is None:
-            r = self.reducer
-            self._aux = concurrent_stream(self.prefetch_priority, group=r.group if (r is not None and r.active) else False)
-        with torch.cuda.stream(self._aux):
+        with torch.cuda.stream(self.aux_stream()):
             if callable(batch):
                 batch = batch()
             if self.bucket:
@@ -332,6 +355,15 @@ class TrainStep:
             batch.extras["prefetched"] = torch.cuda.Event()
             batch.extras["prefetched"].record(self._aux)
         return batch
+
+    def aux_stream(self):
+        """The prefetch stream (found by the concurrency probe of `concurrent_stream`: 256 MB of scratch, a few device
+        synchronisations, with a reducer a few tiny all-reduces - every rank must call it at the same point).  `step`
+        creates it before its first step, so that it never falls into a timed steady-state region."""
+        if self._aux is None:
+            r = self.reducer
+            self._aux = concurrent_stream(self.prefetch_priority, group=r.group if (r is not None and r.active) else False)
+        return self._aux
 
     @staticmethod
     def _join_prefetch(batch):
@@ -436,6 +468,8 @@ class TrainStep:
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)   # warm-up ran on the side stream
         self.g_fb, self.g_b = torch.cuda.CUDAGraph(), None
         split = self.two_phase
+        if self.pre_capture_hook is not None:
+            self.pre_capture_hook()
         try:
             # thread_local: the RCCL watchdog thread may touch the HIP runtime while this thread captures
             with torch.cuda.graph(self.g_fb, capture_error_mode="thread_local"):
@@ -466,6 +500,8 @@ class TrainStep:
             if self.reducer is not None:
                 self.reducer.unflatten()
             self._update()
+        if self.post_capture_hook is not None:
+            self.post_capture_hook()
         self.captures += 1
         self._opt_gen = getattr(self.opt, "generation", 0)     # (the warm-up may have built the optimizer)
 
@@ -506,8 +542,8 @@ class TrainStep:
         """Drop the captured graphs and their private memory pool (e.g. before running large eager steps)."""
         self._slots.clear()
         self._active = None
-        if hasattr(self.opt, "unpin") and getattr(self.opt, "_built", False):
-            self.opt.unpin()
+        if hasattr(self.opt, "unpin_all") and getattr(self.opt, "_built", False):
+            self.opt.unpin_all()
         self._pinned_table = None
         self.g_fb = self.g_b = self.g_opt = self.static = self.static_prep = self.static_loss = None
         EF_layers._edge_pinned.clear()
@@ -521,6 +557,8 @@ class TrainStep:
         EF_layers.check_edge_frames()
 
     def step(self, batch):
+        if self._aux is None and batch[PA]["x"].is_cuda:
+            self.aux_stream()               # first step: the probe runs here, not inside somebody's timed region
         if not self.use_graph:
             return self.eager_step(batch)
         gen = getattr(self.opt, "generation", 0)
@@ -544,13 +582,23 @@ class TrainStep:
 
     def _replay(self):
         self.g_fb.replay()
+        ev = None
+        if self.comm_events is not None and self.reducer is not None and self.reducer.active:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         if self.g_b is not None:
             self.reducer.launch(phase=0)                            # the transformer's buckets travel ...
             self.g_b.replay()                                       # ... while the embedding's backward pass computes
+            if ev:
+                ev[0].record()                                      # the backward pass is done here ...
             self.reducer.launch(phase=1)
             self.reducer.wait()
         elif self.reducer is not None:
+            if ev:
+                ev[0].record()
             self.reducer.allreduce()                                # flatten / unflatten are inside the graphs
+        if ev:
+            ev[1].record()                                          # ... and every bucket has arrived here: the time between the
+            self.comm_events.append(ev)                             # two is what the all-reduce costs the step (exposed)
         if hasattr(self.opt, "sync_hyper"):
             self.opt.sync_hyper()                            # scheduler-updated learning rate -> device scalar
         self.g_opt.replay()

@@ -78,8 +78,10 @@ def collate(graphs):
     ld0 = graphs[0]["ligand_data"]
     for k in ld0:
         vals = [g["ligand_data"][k] for g in graphs]
+        # Python floats -> torch.tensor(list) = float32, as PyG's collate hands them to the reference (the thresholds of
+        # GAN:38-40 are therefore taken on float32 values)
         out.globals["ligand_data"][k] = torch.cat(vals, 0) if torch.is_tensor(vals[0]) else torch.tensor(
-            vals, dtype=torch.float64)
+            vals, dtype=torch.float32)
     for name in ("rot_rand", "edge_rot_mat"):
         if name in graphs[0].extras:
             out.extras[name] = {k: torch.cat([g.extras[name][k] for g in graphs], 0) for k in graphs[0].extras[name]}
@@ -90,19 +92,62 @@ def laplacian_pe(edge_index, n, k=8):
     """Deterministic Laplacian positional encoding of ONE graph: the k eigenvectors after the smallest of
     I - D^-1/2 A D^-1/2 (in-degree clipped at 1), symmetric eigensolver, sign fixed by making the entry of largest
     magnitude positive.  (dgl.lap_pe, reference model/CProMG.py:562-571, uses random signs on the whole batched
-    graph - not reproducible, so at our boundary the encoding is an input)"""
+    graph - not reproducible, so at our boundary the encoding is an input)
+
+    A bonded pocket graph has dozens of connected components, i.e. a many-fold zero eigenvalue (and further exact
+    repeats from isomorphic fragments), and LAPACK's basis of a repeated eigenvalue's subspace depends on its blocking -
+    on the BLAS thread count of the process (round 3's "8-graph discrepancy": bench.py's GPU process and its CPU-oracle
+    child computed different, equally valid encodings of the same graphs).  So every cluster of repeated eigenvalues gets
+    a canonical basis first: Gram-Schmidt over the columns of the cluster's projector V V^T - which does not depend on
+    the basis - in atom order."""
     a = np.zeros((n, n))
     ei = np.asarray(edge_index)
     a[ei[0], ei[1]] = 1.0
     dinv = np.clip(a.sum(0), 1, None) ** -0.5
     lap = np.eye(n) - dinv[:, None] * a * dinv[None, :]
-    _, v = np.linalg.eigh(0.5 * (lap + lap.T))
+    w, v = np.linalg.eigh(0.5 * (lap + lap.T))
+    v = _canonical_eigenbasis(w, v, k + 1)
     v = v[:, 1:k + 1]
     if v.shape[1] < k:
         v = np.concatenate([v, np.zeros((n, k - v.shape[1]))], 1)
     idx = np.argmax(np.abs(v), axis=0)
     sign = np.where(v[idx, np.arange(v.shape[1])] < 0, -1.0, 1.0)
     return torch.tensor(v * sign, dtype=torch.float32)
+
+
+def _canonical_eigenbasis(w, v, upto, tol=1e-9):
+    """Replace the eigenvectors of every cluster of (numerically) repeated eigenvalues that reaches into the first `upto`
+    columns by a basis that only depends on the cluster's SUBSPACE: the projector P = V V^T is the same for any basis, and
+    Gram-Schmidt over its columns P e_0, P e_1, ... (atom order, columns that add less than 1e-6 of new direction are
+    skipped) is a function of P alone."""
+    v = v.copy()
+    n = w.shape[0]
+    lo = 0
+    while lo < min(upto, n):
+        hi = lo + 1
+        while hi < n and w[hi] - w[hi - 1] <= tol:
+            hi += 1
+        m = hi - lo
+        if m > 1:
+            vc = v[:, lo:hi]
+            basis = np.zeros((n, m))
+            found = 0
+            for j in range(n):
+                r = vc @ vc[j]                                     # P e_j
+                if found:
+                    b = basis[:, :found]
+                    r = r - b @ (b.T @ r)
+                    r = r - b @ (b.T @ r)                          # twice: orthogonal to rounding
+                nr = np.linalg.norm(r)
+                if nr > 1e-6:
+                    basis[:, found] = r / nr
+                    found += 1
+                    if found == m:
+                        break
+            if found == m:
+                v[:, lo:hi] = basis
+        lo = hi
+    return v
 
 
 def from_arrays(d, with_lap=True):
@@ -152,11 +197,13 @@ def _closest_pairs(pa, pb, count, same):
     return flat // pb.shape[0], flat % pb.shape[0]
 
 
-def synthetic_graph(graph_id, n_protein=200, n_ligand=30, e_pp=1700, e_ll=64, e_x=118, tgt_len=200):
+def synthetic_graph(graph_id, n_protein=200, n_ligand=30, e_pp=1700, e_ll=64, e_x=118, tgt_len=200, with_lap=True):
     """One random protein-ligand hetero-graph with the bundled files' schema (SURVEY.md §8d 'Synthetic generator'):
     rng = default_rng(1000 + graph_id); protein atoms uniform in a cube of density 0.05 A^-3 with min pair distance
     1.0 A; ligand atoms inside a 6 A sphere at the centre; linked_to = the e/2 closest pairs in both directions;
-    interact_with = the e_x closest ligand-protein pairs, PL = LP mirrored in the same order (Q5)."""
+    interact_with = the e_x closest ligand-protein pairs, PL = LP mirrored in the same order (Q5).  with_lap=False leaves
+    the Laplacian encodings out (numpy's dense eigensolver is 90 % of the generation time; batches whose encodings are
+    computed inside the step - SINGA.prepare / TrainStep._stage - do not need them)."""
     rng = np.random.default_rng(1000 + graph_id)
     side = (n_protein / 0.05) ** (1.0 / 3.0)
 
@@ -208,7 +255,7 @@ def synthetic_graph(graph_id, n_protein=200, n_ligand=30, e_pp=1700, e_ll=64, e_
     tok_tgt[:n_tok], tok_tgt[n_tok] = body, END_TOKEN
     props = np.array([rng.uniform(-10, -5), rng.uniform(0.3, 0.9), rng.uniform(2, 6)])
     g = from_arrays(dict(x_p=x_p, pos_p=pos_p, z_p=z_p, x_l=x_l, pos_l=pos_l, z_l=z_l, ei_pp=ei_pp, ei_ll=ei_ll,
-                         ei_lp=ei_lp, ei_pl=ei_pl, props=props, tok_in=tok_in, tok_tgt=tok_tgt))
+                         ei_lp=ei_lp, ei_pl=ei_pl, props=props, tok_in=tok_in, tok_tgt=tok_tgt), with_lap)
     g.extras["rot_rand"] = {k: torch.tensor(rng.random((n, 3)), dtype=torch.float32)
                             for k, n in (("pp", ei_pp.shape[1]), ("ll", ei_ll.shape[1]), ("lp", ei_lp.shape[1]))}
     return g
@@ -264,9 +311,9 @@ def graph_cost(sizes):
     return sizes["e_pp"] + sizes["e_ll"] + 2 * sizes["e_x"]
 
 
-def synthetic_batch(n_graphs, first_id=0, ragged=None, ids=None, **kw):
+def synthetic_batch(n_graphs, first_id=0, ragged=None, ids=None, with_lap=True, **kw):
     ids = range(first_id, first_id + n_graphs) if ids is None else ids
-    return collate([synthetic_graph(i, **graph_sizes(i, ragged, **kw)) for i in ids])
+    return collate([synthetic_graph(i, with_lap=with_lap, **graph_sizes(i, ragged, **kw)) for i in ids])
 
 
 # ----------------------------------------------------------------------------------------------- padding to capacities

@@ -58,6 +58,7 @@ class DenseMap:
         self.B = batch_size
         self.mx = int(num.max()) if mx is None else int(mx)
         start = num.cumsum(0) - num
+        self.ptr = torch.cat([start, start[-1:] + num[-1:]])      # first node of every graph (+ the end): nodes are contiguous per graph
         trash = batch_size * self.mx
         bi = batch.clamp(max=batch_size - 1)
         self.idx = torch.where(inside, torch.arange(batch.numel(), device=batch.device) - start[bi] + bi * self.mx,
@@ -88,25 +89,12 @@ def to_dense_batch(x, batch, batch_size):
 
 def knn_graph(pos, k, batch, batch_size, dm=None):
     """For every node its k nearest other nodes of the same graph, row = centre (torch_cluster.knn_graph with
-    flow='target_to_source', CP:293,330).  Dense per-graph distance matrices on the GPU.  Returns a fixed-size
-    [2, B*max_nodes*k] list in which slots that do not exist (padding rows, graphs with fewer than k+1 nodes) hold -1:
-    no data-dependent compaction (and no host synchronisation) happens here."""
+    flow='target_to_source', CP:293,330): the library's kernel singa_knn_graph (one wavefront per centre atom, exact fp32
+    coordinate differences as torch_cluster forms them, ties to the lower index).  Returns a fixed-size [2, N * k] list in
+    which slots that do not exist (graphs with fewer than k+1 nodes, atoms of no graph) hold -1: no data-dependent
+    compaction (and no host synchronisation) happens here."""
     dm = dm or DenseMap(batch, batch_size)
-    dense, mask, idx = dm.dense(pos), dm.mask, dm.idx
-    mx = dense.shape[1]
-    d = torch.cdist(dense, dense)
-    d = d.masked_fill(~mask.unsqueeze(1), float("inf"))
-    d = d + torch.diag_embed(torch.full((mx,), float("inf"), device=pos.device)).unsqueeze(0)
-    kk = min(k, mx - 1)
-    dist, nb = d.topk(kk, dim=2, largest=False)
-    node_of = torch.full((batch_size * mx + 1,), -1, dtype=torch.long, device=pos.device)
-    node_of[idx] = torch.arange(pos.shape[0], device=pos.device)
-    node_of = node_of[:batch_size * mx].view(batch_size, mx)
-    centre = node_of.unsqueeze(2).expand(-1, -1, kk)
-    neigh = torch.gather(node_of.unsqueeze(1).expand(-1, mx, -1), 2, nb)
-    ok = torch.isfinite(dist) & (centre >= 0)
-    minus = torch.full_like(neigh, -1)
-    return torch.stack([torch.where(ok, centre, minus).reshape(-1), torch.where(ok, neigh, minus).reshape(-1)], 0)
+    return ops.knn_graph(pos, k, batch, dm.ptr, dm.mx)
 
 
 class KnnEdges:

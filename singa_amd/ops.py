@@ -21,10 +21,45 @@ from . import _capi, _lib, so3
 PROFILE_ON = False
 
 
-def profile_start():
-    global PROFILE_ON
+def profile_start(in_graph=False):
+    """in_graph: a device-timestamp kernel in front of and behind every tagged dispatch instead of events attached to it -
+    plain kernel nodes that are captured with the step and re-run by every replay (read with profile_read after a replay)."""
+    global PROFILE_ON, _STAMPS
     PROFILE_ON = True
-    _chk(_lib.lib().singa_prof_enable(1), "singa_prof_enable")
+    if in_graph:
+        _STAMPS = torch.zeros(2 * 8192 + 2, dtype=torch.int64, device="cuda")
+        _chk(_lib.lib().singa_prof_stamps(_p(_STAMPS), _STAMPS.numel()), "singa_prof_stamps")
+    else:
+        _chk(_lib.lib().singa_prof_enable(1), "singa_prof_enable")
+
+
+_STAMPS = None
+
+
+def profile_pause():
+    """Stop tagging new dispatches but keep the records and the stamp buffer (graph mode: after the capture, before the
+    replays)."""
+    global PROFILE_ON
+    PROFILE_ON = False
+    _chk(_lib.lib().singa_prof_stamps(None, 0), "singa_prof_stamps")
+    _chk(_lib.lib().singa_prof_enable(0), "singa_prof_enable")
+
+
+def profile_read():
+    """Graph mode, after a replay + synchronize: [(tag, ms, n_edges, n_nodes)] of the captured dispatches (kept)."""
+    cap = 8192
+    host = _STAMPS.cpu().numpy()
+    ms, tg, ne, nn = (ctypes.c_float * cap)(), (ctypes.c_int * cap)(), (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
+    n = _lib.lib().singa_prof_read_stamps(host.ctypes.data_as(ctypes.c_void_p), ms, tg, ne, nn, cap)
+    return [(PROF_TAGS.get(tg[i], str(tg[i])), ms[i], ne[i], nn[i]) for i in range(n)]
+
+
+def profile_end():
+    """Graph mode: forget the records and release the stamp buffer (the capture that writes into it must be gone)."""
+    global _STAMPS
+    _chk(_lib.lib().singa_prof_stamps(None, 0), "singa_prof_stamps")
+    _chk(_lib.lib().singa_prof_reset(), "singa_prof_reset")
+    _STAMPS = None
 
 
 PROF_TAGS = {1: "k10_fwd", 2: "k10_bwd", 3: "k4_fwd", 4: "k4_bwd_rad", 5: "k4_bwd_dst", 6: "k4_bwd_src",           # include/singa_hip.h
@@ -319,6 +354,20 @@ def segment_sum_rows(v, row_ptr):
     w = torch.ones(max(E, 1), 1, device=v.device, dtype=torch.float32)
     _chk(_lib.lib().singa_segment_wsum_fwd(_p(w), _p(v), _p(row_ptr), _p(out), N, 1, F, _stream()), "singa_segment_wsum_fwd")
     return out.view(N, F)
+
+
+def knn_graph(pos, k, batch, ptr, max_nodes):
+    """n1: torch_cluster.knn_graph(pos, k, batch, flow='target_to_source') (CP:293,330) -> [2, N * k] int64, row = centre,
+    -1 where a slot does not exist (singa_knn_graph).  batch ids outside [0, len(ptr) - 1) = atoms of no molecule."""
+    pos = pos.detach().to(torch.float32).contiguous()
+    _dev(pos, batch, ptr)
+    N = pos.shape[0]
+    out = torch.empty(2, N * k, dtype=torch.int64, device=pos.device)
+    b32 = batch.to(torch.int32).contiguous()
+    p64 = ptr.to(torch.int64).contiguous()
+    _chk(_lib.lib().singa_knn_graph(_p(pos), _p(b32), _p(p64), p64.numel() - 1, N, int(k), int(max_nodes), _p(out[0]), _p(out[1]),
+                                    _stream()), "singa_knn_graph")
+    return out
 
 
 def segment_wsum(w, v, row_ptr):

@@ -77,13 +77,18 @@ class Adam(torch.optim.Optimizer):
             self._pinned[ids] = self.g_ptr = torch.tensor(ids, dtype=torch.int64, device=self.p_ptr.device)
         return self.g_ptr
 
-    def unpin(self, table=None):
-        """Forget a pinned address table (the capture that used it is gone); None = all of them."""
+    def unpin(self, table):
+        """Forget ONE pinned address table (the capture that used it is gone).  None = a capture that never pinned one:
+        nothing to forget (it must not wipe the tables of the live captures - `unpin_all` is the explicit form)."""
         if table is None:
-            self._pinned.clear()
-        else:
-            for k in [k for k, v in self._pinned.items() if v is table]:
-                del self._pinned[k]
+            return
+        for k in [k for k, v in self._pinned.items() if v is table]:
+            del self._pinned[k]
+        self._grad_ids = None
+
+    def unpin_all(self):
+        """Forget every pinned address table (all captures are being dropped)."""
+        self._pinned.clear()
         self._grad_ids = None
 
     def sync_hyper(self):

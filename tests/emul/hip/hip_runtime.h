@@ -66,6 +66,11 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
     *n = 0;
     return hipSuccess;
 }
+static inline long long wall_clock64() { return 0; }
+static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
+static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+static inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
 static inline int __shfl_xor(int, int, int) {
     fprintf(stderr, "emul: cross-lane kernel cannot be emulated sequentially\n");
     abort();

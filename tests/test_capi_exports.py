@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "singa_hip.h")).read()
+def declared_symbols(header="singa_hip.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(singa_[a-z0-9_]+)\s*\(", text)))
 
@@ -37,6 +37,9 @@ def test_library_exports_every_declared_symbol(built_lib):
 def test_binding_table_matches_header():
     from singa_amd import _capi
     assert sorted(_capi.EXPORTS) == declared_symbols()
+    # the test / lab switches live in their own header, outside the drop-in ABI
+    assert sorted(_capi.LAB_EXPORTS) == declared_symbols("singa_hip_lab.h")
+    assert not set(_capi.LAB_EXPORTS) & set(_capi.EXPORTS)
 
 
 def test_argument_errors_without_gpu(built_lib):

@@ -287,7 +287,7 @@ def _worker_phases(rank, world, port, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(7)
     model = ToyTwoPart()
-    red = dp.GradAllReducer(model, bucket_mb=0.0001)
+    red = dp.GradAllReducer(model, bucket_mb=0.0001, phases=True)
     assert red.phases is not None and len(red.phases) == 2
     data = torch.randn(10, 8, generator=torch.Generator().manual_seed(1))
     tgt = torch.randn(10, 3, generator=torch.Generator().manual_seed(2))

@@ -28,7 +28,7 @@ def _train(rank, world, ids, use_graph):
     from singa_amd.optim import Adam
     torch.manual_seed(11)
     model = SINGA(load_config(lmax=2), device="cuda").eval()       # dropout off: the ranks must see the same numbers
-    reducer = dp.GradAllReducer(model) if world > 1 else None
+    reducer = dp.GradAllReducer(model, phases=True) if world > 1 else None      # the two-phase (overlapped) order
     if reducer:
         reducer.check_same_init()
         reducer.set_shard_weight(len(ids), len(ids) * world)
@@ -161,6 +161,34 @@ def test_rccl_selftest_one_rank_bench():
     assert line["config"]["grad_allreduce_bytes"] > 60e6            # the L = 2 model's 64 MB of gradients went through RCCL
 
 
+def test_two_rank_bench_line_explains_itself():
+    """`bench.py --gpus 2` on ONE GPU (SINGA_DIST_BACKEND=gloo: two ranks sharing the device - the multi-rank control flow
+    with gloo in RCCL's place): the N > 1 line names who ran where (`rccl_ranks`, `per_rank`), what the all-reduce cost the
+    step (`allreduce_exposed_ms`), carries the weak figure per GPU, and its `allreduce_overlap` block shows the two-phase
+    order to end with the same parameters as the default one on every rank."""
+    import json
+    import subprocess
+    env = dict(os.environ, SINGA_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "SINGA_RCCL_SELFTEST"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg2_b32_l2", "--steps", "4",
+                        "--warmup", "1", "--roofline-steps", "0", "--ingraph-steps", "0"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["rccl_ranks"]["world_size"] == 2 and len(line["rccl_ranks"]["device_ordinals"]) == 2
+    pr = line["per_rank"]
+    assert [p["rank"] for p in pr] == [0, 1] and sum(p["graphs"] for p in pr) == 32
+    assert all(p["step_ms_min"] <= p["step_ms_median"] <= p["step_ms_max"] for p in pr)
+    assert line["allreduce_exposed_ms"] is not None and line["allreduce_exposed_ms"] >= 0
+    ov = line["allreduce_overlap"]
+    assert ov["overlapped"]["two_phase_engine"] and not ov["single_phase"]["two_phase_engine"]
+    assert ov["params_agree"] and ov["ranks_hold_identical_parameters"], ov
+    assert line["weak"]["global_batch"] == 64 and line["weak"]["value_per_gpu"] > 0
+    assert "after the backward pass" in line["config"]["grad_allreduce"]          # the default order of the headline region
+
+
 def _train_one_rank(reducer_on, use_graph):
     sys.path.insert(0, ROOT)
     from singa_amd import dp, graph as G
@@ -170,7 +198,7 @@ def _train_one_rank(reducer_on, use_graph):
     from singa_amd.optim import Adam
     torch.manual_seed(11)
     model = SINGA(load_config(lmax=2), device="cuda").eval()
-    reducer = dp.GradAllReducer(model, always=True) if reducer_on else None      # one-rank group: every collective still runs
+    reducer = dp.GradAllReducer(model, always=True, phases=True) if reducer_on else None      # one-rank group: every collective still runs
     eng = TrainStep(model, Adam(model.parameters(), lr=1e-4), reducer, use_graph=use_graph)
     batch = G.synthetic_batch(3, ids=[100, 101, 102], **KW).to("cuda")
     losses = [float(eng.step(batch).detach()) for _ in range(4)]

@@ -686,3 +686,62 @@ def test_block_weight_autograd():
     finally:
         ops._GradSink.on = False
     assert rel(wd2.grad - 1.0, wr_.grad) < 1e-5
+
+
+def test_knn_graph_kernel_matches_oracle():
+    """n1: singa_knn_graph (reference model/CProMG.py:293,330 -> torch_cluster.knn_graph, flow='target_to_source') against the
+    oracle's restatement on ragged batches: molecules smaller than k + 1 atoms (absent slots = -1), a single-atom molecule, an
+    empty molecule, atoms of no molecule (the inert padding of graph.pad_batch), the three register layouts (<= 512 / 1024 / 2048
+    atoms per molecule), exact ties (lower index first), neighbours in order of increasing distance."""
+    from oracle import singa_oracle as O
+    from singa_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for sizes, k, mx in (([70, 5, 1, 0, 33, 49], 48, 80), ([600, 31], 30, 608), ([1100], 48, 1104)):
+        B = len(sizes)
+        n_real = sum(sizes)
+        pos = torch.rand(n_real + 7, 3, generator=g) * 30.0
+        if sizes[0] >= 70:                                   # exact ties: a 2 x 2 x 2 lattice corner inside molecule 0
+            pos[:8] = torch.tensor([[x, y, z] for x in (1.0, 2.0) for y in (1.0, 2.0) for z in (1.0, 2.0)])
+        batch = torch.cat([torch.repeat_interleave(torch.arange(B), torch.tensor(sizes)), torch.full((7,), B)])
+        ptr = torch.tensor([0] + sizes).cumsum(0)
+        out = ops.knn_graph(pos.to(DEV), k, batch.to(DEV), ptr.to(DEV), mx).cpu()
+        N = pos.shape[0]
+        assert out.shape == (2, N * k)
+        row, col = out[0].view(N, k), out[1].view(N, k)
+        assert (row[n_real:] == -1).all() and (col[n_real:] == -1).all()          # atoms of no molecule
+        for b in range(B):
+            ids = torch.arange(int(ptr[b]), int(ptr[b + 1]))
+            if ids.numel() == 0:
+                continue
+            kk = min(k, ids.numel() - 1)
+            d = torch.cdist(pos[ids].double(), pos[ids].double())
+            df = pos[ids][:, None, :] - pos[ids][None, :, :]
+            d32 = (df[..., 0] * df[..., 0] + df[..., 1] * df[..., 1]) + df[..., 2] * df[..., 2]     # the kernel's fp32 arithmetic
+            for li, i in enumerate(ids.tolist()):
+                assert (row[i, :kk] == i).all() and (row[i, kk:] == -1).all() and (col[i, kk:] == -1).all()
+                nb = col[i, :kk]
+                assert len(set(nb.tolist())) == kk and i not in nb.tolist()
+                assert int(nb.min()) >= int(ids[0]) and int(nb.max()) <= int(ids[-1])        # same molecule
+                dn = d32[li, nb - int(ids[0])]
+                assert (dn[1:] >= dn[:-1]).all()                                              # increasing distance
+                tie = dn[1:] == dn[:-1]
+                assert (nb[1:][tie] > nb[:-1][tie]).all()                                     # exact ties: lower index first
+                # the selected set is the oracle's (fp64 distances) wherever the k-th / (k+1)-th gap is above fp32 rounding
+                want = d[li].clone()
+                want[li] = float("inf")
+                srt = torch.sort(want).values
+                if kk < ids.numel() - 1 and float(srt[kk] - srt[kk - 1]) < 1e-5:
+                    continue
+                assert set(nb.tolist()) == set(ids[torch.topk(want, kk, largest=False).indices].tolist()), (b, i)
+    # and the whole oracle list on a generated batch
+    from singa_amd import graph as G
+    L, kw, _, _ = G.resolve_workload("cfg3_b128_l4")
+    graphs = [G.synthetic_graph(i, with_lap=False, **G.graph_sizes(i, **kw)) for i in (5, 6, 7)]
+    bt = G.collate(graphs)
+    for nt, k in ((G.PA, 48), (G.LA, 30)):
+        pos, batch, ptr = bt[nt]["pos"], bt[nt]["batch"], bt[nt]["ptr"]
+        own = ops.knn_graph(pos.to(DEV), k, batch.to(DEV), ptr.to(DEV), int((ptr[1:] - ptr[:-1]).max())).cpu()
+        ref = O.knn_graph(pos, k, batch)
+        N = pos.shape[0]
+        ok = own[0] >= 0
+        assert set((own[0][ok] * N + own[1][ok]).tolist()) == set((ref[0] * N + ref[1]).tolist())

@@ -9,6 +9,16 @@ from singa_amd.model import CProMG as CP
 KW = dict(n_protein=40, n_ligand=10, e_pp=160, e_ll=20, e_x=24)
 
 
+def _knn(pos, k, batch, B):
+    """The raw kNN list as the product's kernel would hand it over (GPU only: tests/test_kernels_gpu.py) - here from the
+    oracle, on the atoms that belong to a graph; padding atoms (batch id = B) have no neighbours."""
+    from oracle import singa_oracle as O
+    real = batch < B
+    n = int(real.sum())
+    assert bool(real[:n].all())                      # the padding atoms come last
+    return O.knn_graph(pos[:n], k, batch[:n])
+
+
 def _batch(ids):
     return G.synthetic_batch(len(ids), ids=ids, **KW)
 
@@ -49,7 +59,7 @@ def test_dense_map_and_knn_edges_ignore_padding_atoms():
     smear = CP.GaussianSmearing(stop=15, num_gaussians=64, device="cpu")
     pos, batch = b[G.PA]["pos"], b[G.PA]["batch"]
     dm = CP.DenseMap(batch, 2)
-    ref = CP.KnnEdges(pos, CP.knn_graph(pos, 8, batch, 2, dm), smear)
+    ref = CP.KnnEdges(pos, _knn(pos, 8, batch, 2), smear)
     ppos, pbatch = pb[G.PA]["pos"], pb[G.PA]["batch"]
     pdm = CP.DenseMap(pbatch, 2, mx=dm.mx + 5)
     assert torch.equal(pdm.mask[:, :dm.mx], dm.mask) and not bool(pdm.mask[:, dm.mx:].any())
@@ -58,7 +68,7 @@ def test_dense_map_and_knn_edges_ignore_padding_atoms():
     assert torch.equal(dense[:, :dm.mx][dm.mask], x[:r[0]])                        # padding atoms never enter the layout
     assert torch.equal(pdm.gather(dense.reshape(-1, 3))[:r[0]], x[:r[0]])
     cap = ref.n_edges + 64 + 37
-    pe = CP.KnnEdges(ppos, CP.knn_graph(ppos, 8, pbatch, 2, pdm), smear, cap=cap + 64, n_real=r[0])
+    pe = CP.KnnEdges(ppos, _knn(ppos, 8, pbatch, 2), smear, cap=cap + 64, n_real=r[0])
     N, Np = pos.shape[0], ppos.shape[0]
     assert pe.row.numel() == cap + 64 and pe.n_edges == ref.n_edges + 64           # + the self loops of the padding atoms
     real = (pe.row < N) & (pe.col < N)
@@ -69,7 +79,7 @@ def test_dense_map_and_knn_edges_ignore_padding_atoms():
     assert bool(((pe.row >= N) == (pe.col >= N)).all())                            # no edge between real and padding atoms
     assert int(pe.row_ptr[-1]) == cap + 64 and bool((pe.row[1:] >= pe.row[:-1]).all())
     try:
-        CP.KnnEdges(ppos, CP.knn_graph(ppos, 8, pbatch, 2, pdm), smear, cap=ref.n_edges, n_real=r[0])
+        CP.KnnEdges(ppos, _knn(ppos, 8, pbatch, 2), smear, cap=ref.n_edges, n_real=r[0])
         raise AssertionError("capacity overflow not reported")
     except OverflowError:
         pass

@@ -40,7 +40,7 @@ def timed(obj, name, label=None):
 for mode in os.environ.get("MODES", "plain;reducer;reducer, one phase").split(";"):
     torch.manual_seed(0)
     model = SINGA(load_config(lmax=L), device="cuda").train()
-    red = None if mode == "plain" else dp.GradAllReducer(model, always=True, phases=None if mode == "reducer" else False)
+    red = None if mode == "plain" else dp.GradAllReducer(model, always=True, phases=True if mode == "reducer" else False)
     eng = TrainStep(model, Adam(model.parameters(), lr=1e-4), red, use_graph=True, bucket=True, growth=1.04, max_cached=6)
     eng.prefetch_priority = -1 if os.environ.get("AUX_PRIORITY", "normal") == "high" else 0
     batches = [G.synthetic_batch(len(ids), ids=[i + k * n_parent for i in ids], **kw).to("cuda") for k in range(3)]

@@ -61,6 +61,10 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="capture the step into HIP graphs and replay it; batches of different sizes are padded to size "
                          "classes, one capture per class")
+    ap.add_argument("--allreduce-overlap", action="store_true",
+                    help="several ranks: two-phase backward, the transformer's gradient buckets are all-reduced while the "
+                         "embedding's backward pass computes (dp.GradAllReducer(phases=True)); default: one all-reduce after "
+                         "the backward pass")
     ap.add_argument("--resume", type=str, default=None, help="checkpoint to load (model, optimizer, scheduler, iteration)")
     ap.add_argument("--no-dropout", action="store_true",
                     help="switch the decoder's positional-encoding dropout (reference CProMG.py:198, p = 0.1: the only stochastic "
@@ -125,7 +129,7 @@ def main():
         opt.load_state_dict(ck["optimizer"])
         sched.load_state_dict(ck["scheduler"])
         start_it = ck["iteration"] + 1
-    reducer = dp.GradAllReducer(model) if world > 1 else None
+    reducer = dp.GradAllReducer(model, phases=bool(args.allreduce_overlap)) if world > 1 else None
     if reducer:
         reducer.check_same_init()
         reducer.set_shard_weight(hi - lo, batch_size)        # token-weighted combination: exact for unequal shards too
