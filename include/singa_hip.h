@@ -251,6 +251,13 @@ int singa_s2act_sep_fwd(const singa_seg_t* x, int nseg, const float* gate, int64
 int singa_s2act_sep_bwd(const singa_seg_t* x, int nseg, const float* gate, int64_t ldg, const float* P, const float* Q,
                         const float* A, const float* g_out, float* gx, float* g_gate, int E, int C, int lmax,
                         void* stream);
+/* The feed-forward block's backward pass through [SeparableS2Activation -> SO3_LinearV2(512 -> 16)] (EF:256-262) in ONE pass over
+ * the hidden tensor: the gradient at the activation's output is formed on the fly from the small gradient g_small [N, K, 16] of
+ * the linear's output and its weight W2 [L+1][16][512] (gy[n, i, c] = sum_u g_small[n, i, u] W2[l(i)][u][c]) instead of being
+ * written by an expand launch and read back.  x: the activation's saved input [N, K, 512]; gate [N, 512] (row stride ldg);
+ * P, Q: the node grid's Legendre tables (singa_s2act_sep_fwd); outputs gx [N, K, 512], g_gate [N, 512]. */
+int singa_s2act_ffn_bwd(const float* x, const float* gate, int64_t ldg, const float* P, const float* Q, const float* g_small,
+                        const float* W2, float* gx, float* g_gate, int N, int C, int lmax, void* stream);
 /* the same with the input gradient written into `nseg` segments that mirror x's (rows equal, ld >= rows * C) and a row
  * stride for g_gate (>= C): model/EF_layers.py:1148-1178 feeds this activation from column blocks of the three outputs of an
  * SO(2) convolution, and the gradients of those outputs are assembled in place (no concatenation pass). */

@@ -55,6 +55,7 @@ _SIGS = {
     "singa_s2act_bwd": ([C.POINTER(Seg), I32, P, I64, P, P, P, P, P, I32, I32, I32, I32, P], I32),
     "singa_s2act_sep_fwd": ([C.POINTER(Seg), I32, P, I64, P, P, P, P, I32, I32, I32, P], I32),
     "singa_s2act_sep_bwd": ([C.POINTER(Seg), I32, P, I64, P, P, P, P, P, P, I32, I32, I32, P], I32),
+    "singa_s2act_ffn_bwd": ([P, P, I64, P, P, P, P, P, P, I32, I32, I32, P], I32),
     "singa_s2act_sep_bwd_seg": ([C.POINTER(Seg), I32, P, I64, P, P, P, P, C.POINTER(Seg), P, I64, I32, I32, I32, P], I32),
     "singa_so3_rmsnorm_nparts": ([I32], I32),
     "singa_so3_rmsnorm_fwd": ([P, P, P, P, I32, I32, I32, F32, P], I32),

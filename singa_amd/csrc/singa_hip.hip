@@ -3046,30 +3046,77 @@ __global__ void __launch_bounds__(256) s2act_sep_fwd2_kernel(Segs x, const float
 
 // Backward (recompute), same pairing: per ring v = P x and gq = Q^T gy (rows i >= 1); per alpha u = A v,
 // t = SiLU'(u) * (A gq); acc = A^T t; gx_i += P[b, i] acc[m(i)].  g_gate = gy_0 * SiLU'(gate).
-template <int L, bool EDGE, int C>
-__global__ void __launch_bounds__(256) s2act_sep_bwd_kernel(Segs x, const float* __restrict__ gate, long long ldg,
+// FFN (node grid only): the gradient arriving at the activation's output is not read but FORMED here - it is the input gradient
+// of the SO3_LinearV2 that follows the activation in the feed-forward block (EF:262, 655-671: 512 -> 16 channels), gy[i][c] =
+// sum_u gs[n, i, u] * W2[l(i)][u][c], a 16-long contraction per coefficient row.  `g_out` is then the SMALL gradient gs [N, K, 16]
+// and W2 the linear's weight [L+1][16][C] (c contiguous).  A workgroup holds 256 channels of ONE node: the node's K x 16 rows of
+// gs are staged in LDS once and read back as broadcasts (every lane the same address: conflict-free), each degree's 16 weights of
+// the thread's channel sit in registers while its 2l+1 rows are formed.  This removes the [N, K, 512] gradient tensor's write
+// (the k11s expand launch) and its re-read here: 2 x 2.5 GB per layer pass at config 3.
+template <int L, bool EDGE, int C, bool FFN = false>
+__global__ void __launch_bounds__(256, (FFN && L == 4) ? 3 : 1) s2act_sep_bwd_kernel(Segs x, const float* __restrict__ gate, long long ldg,
                                                             const float* __restrict__ P, const float* __restrict__ Q,
                                                             const float* __restrict__ A, const float* __restrict__ g_out,
                                                             SegsMut gx, float* __restrict__ g_gate, long long ldgg,
-                                                            long long EC) {
+                                                            long long EC, const float* __restrict__ W2) {
     using S = S2Sep<L, EDGE>;
     constexpr int KIN = S::KIN, NM = S::NM, RA = S::RA, MM = S::MM;
     (void)A;
+    static_assert(!FFN || (!EDGE && C % 256 == 0), "the fused form is the node grid's, one node per workgroup");
     long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= EC) return;
+    if (!FFN && tid >= EC) return;               // (FFN: EC is a multiple of the workgroup size - no partial workgroup, checked by the host)
     long long e = tid / C;
     int c = (int)(tid - e * C);
     constexpr int r0 = EDGE ? L + 1 : KIN, r01 = EDGE ? 3 * L + 1 : KIN;
     const float* b0 = x.p[0] + e * x.ld[0] + c;
     const float* b1 = EDGE ? x.p[1] + e * x.ld[1] + c : b0;
     const float* b2 = EDGE ? x.p[2] + e * x.ld[2] + c : b0;
-    const float* gi = g_out + e * KIN * C + c;
     float xv[KIN], gy[KIN], ga[KIN];
 #pragma unroll
     for (int i = 0; i < KIN; ++i) {
         xv[i] = i < r0 ? b0[i * C] : (i < r01 ? b1[(i - r0) * C] : b2[(i - r01) * C]);
-        gy[i] = gi[i * C];
         ga[i] = 0.f;
+    }
+    if constexpr (FFN) {
+        constexpr int U = 16;
+        __shared__ __attribute__((aligned(16))) float gs[KIN * U];
+        const float4* gp = reinterpret_cast<const float4*>(g_out + e * (KIN * U));
+        for (int t = threadIdx.x; t < KIN * U / 4; t += 256) reinterpret_cast<float4*>(gs)[t] = gp[t];
+        __syncthreads();
+        const float* wc = W2 + c;
+        float wn[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) wn[u] = wc[u * C];
+#pragma unroll
+        for (int l = 0; l <= L; ++l) {
+            float w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) w[u] = wn[u];
+            if (l < L) {                       // the next degree's weights travel behind this degree's FMAs
+#pragma unroll
+                for (int u = 0; u < U; ++u) wn[u] = wc[((l + 1) * U + u) * C];
+            }
+#pragma unroll
+            for (int i = l * l; i < (l + 1) * (l + 1); ++i) {
+                float acc = 0.f;
+#pragma unroll
+                for (int q = 0; q < U / 4; ++q) {
+                    const float4 g4 = *reinterpret_cast<const float4*>(gs + i * U + 4 * q);
+                    acc = fmaf(g4.x, w[4 * q], acc);
+                    acc = fmaf(g4.y, w[4 * q + 1], acc);
+                    acc = fmaf(g4.z, w[4 * q + 2], acc);
+                    acc = fmaf(g4.w, w[4 * q + 3], acc);
+                }
+                // one row at a time: left alone, the SLP vectoriser pairs rows of DIFFERENT degrees into v_pk_fma_f32 and keeps
+                // several degrees' weights (and the rows' LDS words) live at once - 215 registers instead of ~150 at L = 4
+                SINGA_KEEP_VGPR(acc);
+                gy[i] = acc;
+            }
+        }
+    } else {
+        const float* gi = g_out + e * KIN * C + c;
+#pragma unroll
+        for (int i = 0; i < KIN; ++i) gy[i] = gi[i * C];
     }
     for (int b = 0; b < S::RB / 2; ++b) {
         const float* Pb = P + b * KIN;
@@ -4711,9 +4758,16 @@ __global__ void calib_copy_kernel(const float* __restrict__ src, float* __restri
 }
 
 // The same with 16 bytes per lane (the guide's float4 copy): the practical HBM ceiling next to the 8 TB/s spec peak.
-__global__ void calib_copy16_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+__global__ void __launch_bounds__(256) calib_copy16_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
+    const long long stride = (long long)gridDim.x * blockDim.x;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {                 // four independent 16-byte loads in flight per lane
+        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a;
+        dst[i + stride] = b;
+        dst[i + 2 * stride] = c;
+        dst[i + 3 * stride] = d;
+    }
     for (; i < n4; i += stride) dst[i] = src[i];
 }
 
@@ -4825,7 +4879,7 @@ int singa_knn_graph(const float* pos, const int32_t* batch, const long long* ptr
 int singa_calib_copy16(const float* src, float* dst, long long n, void* stream) {
     if (!src || !dst) return fail(SINGA_E_NULL, "calib_copy16: null pointer");
     if (n % 4 || ((uintptr_t)src | (uintptr_t)dst) % 16) return fail(SINGA_E_SHAPE, "calib_copy16: n % 4 == 0 and 16-byte aligned pointers");
-    hipLaunchKernelGGL(calib_copy16_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, n / 4);
+    hipLaunchKernelGGL(calib_copy16_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, n / 4);
     return check_launch("calib_copy16");
 }
 
@@ -5217,8 +5271,32 @@ int singa_s2act_sep_bwd_seg(const singa_seg_t* x, int nseg, const float* gate, i
     const int tag = edge ? SINGA_PROF_S2_EDGE_BWD : SINGA_PROF_S2_NODE_BWD;
     SINGA_DISPATCH_S2SEP(lmax, edge, SINGA_LAUNCH(tag, E, 0, (s2act_sep_bwd_kernel<L_, EDGE_, C_>), dim3(blocks), dim3(256),
                                                   (hipStream_t)stream, s, gate, (long long)ldg, P, Q, A, g_out, so, g_gate,
-                                                  (long long)ld_gg, EC));
+                                                  (long long)ld_gg, EC, (const float*)nullptr));
     return check_launch("s2act_sep_bwd");
+}
+
+int singa_s2act_ffn_bwd(const float* x, const float* gate, int64_t ldg, const float* P, const float* Q, const float* g_small,
+                        const float* W2, float* gx, float* g_gate, int N, int C, int lmax, void* stream) {
+    if (!x || !gate || !P || !Q || !g_small || !W2 || !gx || !g_gate) return fail(SINGA_E_NULL, "s2act_ffn_bwd: null pointer");
+    if (C != 512) return fail(SINGA_E_SHAPE, "s2act_ffn_bwd: built for the feed-forward block's 512 hidden channels");
+    if (ldg < C) return fail(SINGA_E_SHAPE, "s2act_ffn_bwd: row stride of the gate below C");
+    if (((uintptr_t)g_small & 15)) return fail(SINGA_E_SHAPE, "s2act_ffn_bwd: g_small must be 16-byte aligned");
+    if (N <= 0) return SINGA_OK;
+    const int K = (lmax + 1) * (lmax + 1);
+    Segs s;
+    SegsMut so;
+    memset(&s, 0, sizeof(s));
+    memset(&so, 0, sizeof(so));
+    s.p[0] = x; s.ld[0] = (long long)K * C; s.rows[0] = K;
+    so.p[0] = gx; so.ld[0] = (long long)K * C; so.rows[0] = K;
+    const long long EC = (long long)N * C;                 // a multiple of 256: whole workgroups only (they share LDS + a barrier)
+    const int blocks = (int)(EC / 256);
+    const bool edge = false;
+    SINGA_DISPATCH_S2SEP(lmax, edge, SINGA_LAUNCH(SINGA_PROF_S2_NODE_BWD, N, 0, (s2act_sep_bwd_kernel<L_, false, 512, true>), dim3(blocks),
+                                                  dim3(256), (hipStream_t)stream, s, gate, (long long)ldg, P, Q, (const float*)nullptr,
+                                                  g_small, so, g_gate, (long long)C, EC, W2));
+    (void)edge;
+    return check_launch("s2act_ffn_bwd");
 }
 
 int singa_s2act_sep_bwd(const singa_seg_t* x, int nseg, const float* gate, int64_t ldg, const float* P, const float* Q,

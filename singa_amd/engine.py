@@ -359,7 +359,8 @@ class TrainStep:
     def aux_stream(self):
         """The prefetch stream (found by the concurrency probe of `concurrent_stream`: 256 MB of scratch, a few device
         synchronisations, with a reducer a few tiny all-reduces - every rank must call it at the same point).  `step`
-        creates it before its first step, so that it never falls into a timed steady-state region."""
+        creates it at the end of every capture (eager mode: before its first step), so that it never falls into a timed
+        steady-state region."""
         if self._aux is None:
             r = self.reducer
             self._aux = concurrent_stream(self.prefetch_priority, group=r.group if (r is not None and r.active) else False)
@@ -502,6 +503,13 @@ class TrainStep:
             self._update()
         if self.post_capture_hook is not None:
             self.post_capture_hook()
+        # the prefetch stream is (re-)chosen AFTER every capture: a capture creates streams of its own, and a stream probed
+        # before it ended up sharing a hardware queue with the replayed step (round 4, first bench: the 17-graph shard at
+        # 39.9 ms instead of 31.2 - exactly the preparation running behind the step instead of beside it).  Captures happen in
+        # warm-up and are collective under data parallelism, so the probe never lands in a timed steady-state region and every
+        # rank runs its collectives at the same point.
+        self._aux = None
+        self.aux_stream()
         self.captures += 1
         self._opt_gen = getattr(self.opt, "generation", 0)     # (the warm-up may have built the optimizer)
 
@@ -557,9 +565,9 @@ class TrainStep:
         EF_layers.check_edge_frames()
 
     def step(self, batch):
-        if self._aux is None and batch[PA]["x"].is_cuda:
-            self.aux_stream()               # first step: the probe runs here, not inside somebody's timed region
         if not self.use_graph:
+            if self._aux is None and batch[PA]["x"].is_cuda:
+                self.aux_stream()           # first step: the probe runs here, not inside somebody's timed region
             return self.eager_step(batch)
         gen = getattr(self.opt, "generation", 0)
         if gen != self._opt_gen:

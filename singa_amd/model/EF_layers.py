@@ -429,8 +429,13 @@ class FeedForwardNetwork(nn.Module):
         x = input_embedding.embedding
         gate = self.gating_linear(x[:, 0])
         h = self.so3_linear_1.apply_tensor(x)
-        h = ops.s2act_node(h, gate, self.max_lmax)
-        out = self.so3_linear_2.apply_tensor(h, residual)             # (+ x_res of EF:1405-1406 in the same launch)
+        if ops.USE_SKINNY_SO3 and self.hidden_channels == 512 and self.output_channels == 16:
+            # activation + second linear (+ x_res of EF:1405-1406) as one autograd node: its backward forms the activation's
+            # output gradient inside the activation's backward kernel (ops._FFNTail)
+            out = ops.ffn_tail(h, gate, self.so3_linear_2.weight, self.so3_linear_2.bias, self.max_lmax, residual)
+        else:
+            h = ops.s2act_node(h, gate, self.max_lmax)
+            out = self.so3_linear_2.apply_tensor(h, residual)         # (+ x_res of EF:1405-1406 in the same launch)
         return SO3_Embedding(0, input_embedding.lmax_list.copy(), self.output_channels, out.dtype, self.device, out)
 
 

@@ -360,11 +360,11 @@ def knn_graph(pos, k, batch, ptr, max_nodes):
     """n1: torch_cluster.knn_graph(pos, k, batch, flow='target_to_source') (CP:293,330) -> [2, N * k] int64, row = centre,
     -1 where a slot does not exist (singa_knn_graph).  batch ids outside [0, len(ptr) - 1) = atoms of no molecule."""
     pos = pos.detach().to(torch.float32).contiguous()
-    _dev(pos, batch, ptr)
+    b32 = batch.to(torch.int32).contiguous()
+    _dev(pos, b32)
+    p64 = ptr.to(device=pos.device, dtype=torch.int64).contiguous()
     N = pos.shape[0]
     out = torch.empty(2, N * k, dtype=torch.int64, device=pos.device)
-    b32 = batch.to(torch.int32).contiguous()
-    p64 = ptr.to(torch.int64).contiguous()
     _chk(_lib.lib().singa_knn_graph(_p(pos), _p(b32), _p(p64), p64.numel() - 1, N, int(k), int(max_nodes), _p(out[0]), _p(out[1]),
                                     _stream()), "singa_knn_graph")
     return out
@@ -1470,6 +1470,78 @@ class _SO3Linear(torch.autograd.Function):
 def so3_linear(x, weight, bias, L, addend=None):
     """SO3_LinearV2 (EF:624-674); `addend` [N, K, out]: a residual added in the same launch (EF:1383-1384, 1405-1406)."""
     return _SO3Linear.apply(x, weight, bias, L, addend)
+
+
+class _FFNTail(torch.autograd.Function):
+    """The back half of the feed-forward block, a = SeparableS2Activation(h, gate) -> SO3_LinearV2(512 -> 16)(a) (+ residual)
+    (EF:256-262, 1405-1406), as ONE autograd node, so that the backward pass touches the [N, K, 512] tensors once less: the
+    gradient of `a` (the linear's input gradient, a 16-long contraction per row) is formed inside the activation's backward kernel
+    (singa_s2act_ffn_bwd) instead of being written by an expand launch and read back.  Forward: the two existing launches."""
+
+    @staticmethod
+    def forward(ctx, h, gate, weight, bias, L, addend=None):
+        ctx.params = (weight, bias)
+        h, gate, weight, bias = h.contiguous(), gate.contiguous(), weight.contiguous(), bias.contiguous()
+        _dev(h, gate, weight, bias)
+        N, K, cin = h.shape
+        cout = weight.shape[1]
+        assert cin == 512 and cout == 16 and weight.shape[2] == cin
+        lib = _lib.lib()
+        P, Q, A = _grid_factors(L, L, False, h.device)
+        a = torch.empty_like(h)
+        seg, n = _capi.segs([(h.data_ptr(), K * cin, K)])
+        _chk(lib.singa_s2act_sep_fwd(seg, n, _p(gate), gate.stride(0), _p(P), _p(Q), _p(A), _p(a), N, cin, L, _stream()),
+             "singa_s2act_sep_fwd(node)")
+        out = torch.empty(N, K, cout, device=h.device, dtype=torch.float32)
+        ctx.has_addend = addend is not None
+        if addend is not None:
+            addend = addend.contiguous()
+            _dev(addend)
+            assert addend.shape == out.shape
+        items = []
+        for l in range(L + 1):
+            nl = 2 * l + 1
+            items.append(dict(a=a.data_ptr() + 4 * l * l * cin, lda=cin, a_group=nl, a_group_ld=K * cin,
+                              b=weight.data_ptr() + 4 * l * cout * cin, ldb=cin,
+                              c=out.data_ptr() + 4 * l * l * cout, ldc=cout, c_group=nl, c_group_ld=K * cout,
+                              bias=bias.data_ptr() if l == 0 else None,
+                              addend=(addend.data_ptr() + 4 * l * l * cout) if addend is not None else None,
+                              I=N * nl, J=cout, R=cin))
+        if N > 0:
+            _gemm(items, True, True)
+        ctx.save_for_backward(h, gate, a, weight)
+        ctx.L = L
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        h, gate, a, weight = ctx.saved_tensors
+        L = ctx.L
+        g = g.contiguous()
+        N, K, cin = h.shape
+        cout = weight.shape[1]
+        lib = _lib.lib()
+        P, Q, _ = _grid_factors(L, L, False, h.device)
+        gh, gg = torch.empty_like(h), torch.empty_like(gate)
+        if N > 0:
+            _chk(lib.singa_s2act_ffn_bwd(_p(h), _p(gate), gate.stride(0), _p(P), _p(Q), _p(g), _p(weight), _p(gh), _p(gg), N, cin, L,
+                                         _stream()), "singa_s2act_ffn_bwd")
+        # the linear's weight gradient: rows [l][u][c] summed over the nodes (k11s reduce: small = g, big = a)
+        wsz = (L + 1) * 16 * cin
+        gw = None
+        if N > 0:
+            part = torch.empty(lib.singa_so3_skinny_nparts(N, L, cin), wsz, device=h.device, dtype=torch.float32)
+            _chk(lib.singa_so3_skinny_reduce(_p(g), _p(a), _p(part), N, cin, L, 0, 0, _stream()), "singa_so3_skinny_reduce")
+            gw = param_colsum(part, [(0, wsz, ctx.params[0])])[0]
+        else:
+            gw = torch.zeros(wsz, device=h.device, dtype=torch.float32)
+        gb = param_colsum(g[:, 0, :], [(0, cout, ctx.params[1])])[0]
+        return gh, gg, (gw.view(L + 1, cout, cin) if gw is not None else None), gb, None, (g if ctx.has_addend else None)
+
+
+def ffn_tail(h, gate, weight, bias, L, addend=None):
+    """SO3_LinearV2(512 -> 16)(SeparableS2Activation(h, gate)) (+ addend) - see _FFNTail."""
+    return _FFNTail.apply(h, gate, weight, bias, L, addend)
 
 
 class _GroupedLinear(torch.autograd.Function):
