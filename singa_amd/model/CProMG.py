@@ -7,7 +7,7 @@ Same class names, constructor arguments and parameter names as the reference.  D
   * scatter_softmax / scatter_sum (CP:66,74) are the segmented HIP kernels (ops.segment_softmax / segment_wsum);
   * grouped 1x1 Conv1d and position-wise Conv1d layers are evaluated as GEMMs on their own weights;
   * the causal mask is built on the device (the reference builds it with numpy on the host, CP:507-514).
-Dense projections and attention matmuls are library GEMMs (MFMA via hipBLASLt).
+Dense projections run on the library's own f32 MFMA GEMM, the dense attentions on its flash-style MFMA kernel (k19).
 """
 import math
 
@@ -196,11 +196,6 @@ class MultiHeadAttention(nn.Module):
         self.act = ShiftedSoftplus()
         self.out_transform = Linear(hidden_channels, hidden_channels, device=device)
         self.layer_norm = LayerNorm(hidden_channels, device=device)
-
-    def _grouped(self, conv, h):
-        N, heads = h.shape[0], self.num_heads
-        # the Conv1d weight [heads*og, ig, 1] as it is (a `[:, :, 0]` select would cost a zero-fill and a copy backward)
-        return ops.grouped_linear(h, conv.weight, heads)
 
     def _edge_mlp(self, net, x):
         # first Linear as a plain GEMM, its bias inside the activation kernel (one pass instead of three)

@@ -1068,12 +1068,6 @@ def param_colsum(src, targets):
     return out
 
 
-def _mm_acc(out, a, b):
-    """out += a @ b (beta = 1 in the GEMM)."""
-    with _blas(a.shape[0], b.shape[1], a.shape[1], b.stride(0) == 1 and b.stride(1) != 1):
-        out.addmm_(a, b)
-
-
 class _BiasAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, b):
@@ -1093,76 +1087,16 @@ def bias_add(x, b):
 
 import os as _os
 
-_SPLITK_MIN_ROWS = int(_os.environ.get("SINGA_SPLITK_MIN", "8192"))
-
-
-def _splitk_tn(a, b, param=None):
-    """a^T @ b for tall-skinny a [M,p], b [M,q] (M >> p,q): batched split-K so that the library GEMM has enough
-    workgroups (a single [p,M]x[M,q] GEMM launches p*q/tile workgroups only).  The number of splits grows as the
-    output shrinks (about 512 workgroups in total, at most 64 splits, at least 256 rows each); rows are divided evenly,
-    so the remainder product has fewer rows than there are splits.  `param`: the [p, q] parameter this is the gradient
-    of - when the gradient sink takes it, the product is added into param.grad and None is returned."""
-    M, p = a.shape
-    q = b.shape[1]
-    direct = param is not None and M > 0 and _GradSink.takes(param)
-    acc = param.grad.view(p, q) if direct else None
-    tiles = -(-p // 32) * -(-q // 32)
-    S = min(64, max(M // 8192, -(-512 // tiles)), M // 256) if M > _SPLITK_MIN_ROWS else 1
-    if S < 2:
-        if direct:
-            _mm_acc(acc, a.t(), b)
-            return None
-        return _mm(a.t(), b)
-    chunk = M // S
-    Mc = S * chunk
-    part = torch.bmm(a[:Mc].view(S, chunk, p).transpose(1, 2), b[:Mc].view(S, chunk, q))
-    if direct:
-        _GradSink.jobs.append((part.view(S, p * q), [(0, param.grad)]))
-        if Mc < M:
-            _mm_acc(acc, a[Mc:].t(), b[Mc:])
-        return None
-    out = colsum(part)
-    if Mc < M:
-        out = out + _mm(a[Mc:].t(), b[Mc:])
-    return out
-
-
-class _blas:
-    """Per-call choice of the GEMM library (measured on MI355X, fp32, tools/lab/gemm_probe.py): hipBLASLt has a ~19 us
-    floor and picks single-workgroup tiles for some small shapes (256x960x256: 214 us vs 8 us in rocBLAS), rocBLAS
-    collapses on tall reductions (64x28800x64: 1.5 ms).  Small-K / moderate-M products go to rocBLAS, the rest to
-    hipBLASLt.  The switch is host-side state only; under HIP-graph replay the chosen kernels are baked in."""
-
-    def __init__(self, m, n, k, b_transposed=False):
-        # second clause (tools/lab/tn_probe.py): weight-gradient products a^T b with a few thousand rows and a small
-        # output, e.g. 256x6400x256: 43 us in hipBLASLt (64 workgroups), 22 us in rocBLAS; 64x5938x64: 48 vs 18 us
-        # third clause (tools/lab/addmm_probe.py): the per-edge products of the CProMG attention, 374578x64x64: 37 us in
-        # rocBLAS, 75 us in hipBLASLt (x64x32: 23 vs 40) - but x32x32: 104 vs 32 and x16x192: 42 vs 19, hence k == 64 only,
-        # and only for x @ w^T: the non-transposed product g @ w of the same size takes 164 us in rocBLAS (92 us in Lt)
-        self.use_rocblas = _ROCBLAS_SMALL and ((k <= 2048 and m <= 32768 and n <= 4096) or (k <= 8192 and m * n <= 80000)
-                                               or (b_transposed and m > 32768 and k == 64 and n <= 64))
-
-    def __enter__(self):
-        if self.use_rocblas:
-            torch.backends.cuda.preferred_blas_library("cublas")
-
-    def __exit__(self, *a):
-        if self.use_rocblas:
-            torch.backends.cuda.preferred_blas_library("cublaslt")
-        return False
-
-
-_ROCBLAS_SMALL = _os.environ.get("SINGA_ROCBLAS_SMALL", "1") == "1"
-
 
 class _rocblas:
+    """Inside: torch's GEMMs go to rocBLAS (the `cublas` backend) instead of hipBLASLt.  Only the generic dense-attention
+    branch (head sizes other than the shipped 32 / 64) still multiplies through the library, see _BmmSmall."""
+
     def __enter__(self):
-        if _ROCBLAS_SMALL:
-            torch.backends.cuda.preferred_blas_library("cublas")
+        torch.backends.cuda.preferred_blas_library("cublas")
 
     def __exit__(self, *a):
-        if _ROCBLAS_SMALL:
-            torch.backends.cuda.preferred_blas_library("cublaslt")
+        torch.backends.cuda.preferred_blas_library("cublaslt")
         return False
 
 
@@ -1189,50 +1123,6 @@ class _BmmSmall(torch.autograd.Function):
 
 def bmm_small(a, b):
     return _BmmSmall.apply(a, b)
-
-
-def _mm(a, b):
-    with _blas(a.shape[0], b.shape[1], a.shape[1], b.stride(0) == 1 and b.stride(1) != 1):
-        return a @ b
-
-
-class _Linear(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, w, b):
-        x2 = x.reshape(-1, x.shape[-1])
-        ctx.params = (w, b)
-        if w.dim() == 3:                      # a 1x1 Conv1d weight [out, in, 1] used as it is
-            w = w.view(w.shape[0], w.shape[1])
-        ctx.save_for_backward(x2, w)
-        ctx.xshape, ctx.has_bias = x.shape, b is not None
-        lib = _blas(x2.shape[0], w.shape[0], x2.shape[1], True)
-        with lib:
-            if b is not None and lib.use_rocblas and x2.is_cuda and x2.shape[0] * w.shape[0] <= (1 << 23):
-                # addmm always takes hipBLASLt's bias epilogue, whatever library is preferred; where rocBLAS is the
-                # faster GEMM (6400x256x1024: 37 vs 65 us) the bias is a separate in-place pass over a small output
-                y = (x2 @ w.t()).add_(b)
-            else:
-                y = torch.addmm(b, x2, w.t()) if b is not None else x2 @ w.t()
-        return y.view(*x.shape[:-1], w.shape[0])
-
-    @staticmethod
-    def backward(ctx, g):
-        x2, w = ctx.saved_tensors
-        g2 = g.reshape(-1, g.shape[-1])
-        gx = None
-        if ctx.needs_input_grad[0]:
-            if g2.is_cuda and g2.shape[0] > 32768 and w.shape[0] == 64 and w.shape[1] <= 64:
-                # per-edge 64-channel products: rocBLAS' x @ W^T kernel (46 us) beats both libraries' x @ W (92 / 164 us),
-                # so dX = g @ w is issued as g @ (w^T)^T with the 64x64 transpose materialised
-                gx = _mm(g2, w.t().contiguous().t()).view(ctx.xshape)
-            else:
-                gx = _mm(g2, w).view(ctx.xshape)
-        wp, bp = ctx.params
-        gw = _splitk_tn(g2, x2, wp) if ctx.needs_input_grad[1] else None
-        if gw is not None:
-            gw = gw.view(wp.shape)
-        gb = param_colsum(g2, [(0, g2.shape[1], bp)])[0] if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return gx, gw, gb
 
 
 # ---------------------------------------------------------------------------------------- k7 / k11: own f32 MFMA GEMM
@@ -1544,43 +1434,6 @@ def ffn_tail(h, gate, weight, bias, L, addend=None):
     return _FFNTail.apply(h, gate, weight, bias, L, addend)
 
 
-class _GroupedLinear(torch.autograd.Function):
-    """Grouped 1x1 Conv1d on node rows (CP:27-29, 55-57): h [N, heads*ig] x w [heads, og, ig] -> [N, heads, og], one
-    batched GEMM over the heads reading and writing the node-major tensors through transposed views (no head-major
-    copies forward or backward)."""
-
-    @staticmethod
-    def forward(ctx, h, w, heads):
-        h = h.contiguous()
-        ctx.param = w
-        w = w.view(heads, w.shape[0] // heads, w.shape[1])       # the Conv1d weight [heads*og, ig, 1] (or [heads, og, ig])
-        heads, og, ig = w.shape
-        N = h.shape[0]
-        out = torch.empty(N, heads, og, device=h.device, dtype=h.dtype)
-        with _rocblas():                  # [4][6400,64]x[64,32]: 8 us in rocBLAS, 18 us in hipBLASLt (tools/lab/bmm_probe.py)
-            torch.bmm(h.view(N, heads, ig).transpose(0, 1), w.transpose(1, 2), out=out.transpose(0, 1))
-        ctx.save_for_backward(h, w)
-        return out
-
-    @staticmethod
-    def backward(ctx, g):
-        h, w = ctx.saved_tensors
-        heads, og, ig = w.shape
-        N = h.shape[0]
-        g = g.contiguous()
-        gT = g.transpose(0, 1)                                                    # [heads, N, og] view
-        gh = torch.empty(N, heads, ig, device=h.device, dtype=h.dtype)
-        wp = ctx.param
-        with _rocblas():
-            torch.bmm(gT, w, out=gh.transpose(0, 1))
-            if _GradSink.takes(wp):
-                wp.grad.view(heads, og, ig).baddbmm_(gT.transpose(1, 2), h.view(N, heads, ig).transpose(0, 1))
-                gw = None
-            else:
-                gw = torch.bmm(gT.transpose(1, 2), h.view(N, heads, ig).transpose(0, 1)).view(wp.shape)
-        return gh.view(N, heads * ig), gw, None
-
-
 class _GroupedLinear3(torch.autograd.Function):
     """The three grouped 1x1 Conv1d layers of the graph attention (k_lin, q_lin, v_lin: CP:27-29, 55-57) on the SAME node
     rows h [N, heads * ig] as ONE launch of the own MFMA GEMM (k7) with one problem per (layer, head) - h's column block
@@ -1654,17 +1507,10 @@ def grouped_linear3(h, wk, wq, wv, heads):
     ig = wk.shape[1]
     ok = (h.is_cuda and ig % 4 == 0 and all((w.shape[0] // heads) % 4 == 0 and w.shape[1] == ig for w in (wk, wq, wv))
           and 3 * heads <= 12)
-    if ok:
-        return _GroupedLinear3.apply(h, wk, wq, wv, heads)
-    return tuple(grouped_linear(h, w, heads) for w in (wk, wq, wv))
-
-
-def grouped_linear(h, w, heads=None):
-    """w: [heads, og, ig], or the grouped 1x1 Conv1d weight [heads*og, ig, 1] with `heads` given."""
-    if heads is None:
-        heads = w.shape[0]
-        w = w.reshape(w.shape[0] * w.shape[1], w.shape[2])
-    return _GroupedLinear.apply(h, w, heads)
+    if not ok:
+        raise ValueError("grouped_linear3: channel counts per head must be multiples of 4 and heads <= 4 (the own GEMM's "
+                         "float4 accesses, 12 problems per launch)")
+    return _GroupedLinear3.apply(h, wk, wq, wv, heads)
 
 
 def _tn_splits(rows, out, cin):
@@ -1796,13 +1642,37 @@ def _tn_grad(g2, x2, param, bias=None):
     return gw.view(param.shape) if gw is not None else None
 
 
+def _pad4(x, w):
+    """Zero-pad the reduction axis of (x [.., K], w [N, K]) to a multiple of 4 floats - the own GEMM reads float4s (the
+    3-column property embedding prop_nn, CP:379, is the one such Linear of the model).  Plain differentiable torch ops."""
+    K = x.shape[-1]
+    if w.dim() == 3:
+        w = w.view(w.shape[0], w.shape[1])
+    pad = -K % 4
+    if pad:
+        x = torch.nn.functional.pad(x, (0, pad))
+        w = torch.nn.functional.pad(w, (0, pad))
+    return x, w
+
+
 def linear(x, w, b=None):
-    """y = x W^T + b (w: [out, in] or a 1x1 Conv1d weight [out, in, 1]) on the own MFMA GEMM (k7); shapes the kernel's float4
-    accesses cannot take (a reduction or an output that is not a multiple of 4: the 3-column property embedding) go
-    through the BLAS library."""
+    """y = x W^T + b (w: [out, in] or a 1x1 Conv1d weight [out, in, 1]) on the own MFMA GEMM (k7).  A reduction that is not a
+    multiple of 4 floats is zero-padded, an output width that is not is computed 4-aligned and cut; there is no
+    BLAS-library path."""
+    if not x.is_cuda:
+        raise RuntimeError("singa_amd ops run on the GPU only (no CPU fallback); got a CPU tensor")
+    N = w.shape[0]
+    if x.numel() == 0:                              # nothing to multiply: zeros that still hang in the autograd graph
+        return x.new_zeros(*x.shape[:-1], N) + 0.0 * w.sum() + (0.0 * b.sum() if b is not None else 0.0)
     if _own_linear_ok(x, w, b):
         return _LinearOwn.apply(x, w, b, None)
-    return _Linear.apply(x, w, b)
+    x, w = _pad4(x, w)
+    padn = -N % 4
+    if padn:
+        w = torch.nn.functional.pad(w, (0, 0, 0, padn))
+        b = torch.nn.functional.pad(b, (0, padn)) if b is not None else None
+    y = _LinearOwn.apply(x.contiguous(), w.contiguous(), b, None)
+    return y[..., :N] if padn else y
 
 
 class _LinearMulti(torch.autograd.Function):
@@ -1901,7 +1771,7 @@ def linear_add(x, w, b, addend):
     """x W^T + b + addend (addend shaped like the result) in one launch."""
     if _own_linear_ok(x, w, b):
         return _LinearOwn.apply(x, w, b, addend)
-    return _Linear.apply(x, w, b) + addend
+    return linear(x, w, b) + addend
 
 
 class _PosFFN(torch.autograd.Function):
@@ -1952,10 +1822,6 @@ class _PosFFN(torch.autograd.Function):
 def pos_ffn(x, w1, b1, w2, b2):
     """relu(x W1^T + b1) W2^T + b2 (the position-wise feed-forward of CP:161-191 before its residual LayerNorm)."""
     return _PosFFN.apply(x, w1, b1, w2, b2)
-
-
-def skinny_linear(x, w, b):
-    return _Linear.apply(x, w, b)
 
 
 class _SmallVocabEmbedding(torch.autograd.Function):

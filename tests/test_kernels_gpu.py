@@ -395,20 +395,27 @@ def F_lin(x, w, b):
     return torch.nn.functional.linear(x, w, b)
 
 
-def test_skinny_linear_split_k():
+def test_linear_pads_odd_shapes():
+    """ops.linear on shapes the own GEMM's float4 accesses cannot take directly - a 3-long reduction (the property embedding
+    prop_nn, CP:379), an output width of 6, an empty input - against torch: zero-padded / cut, no BLAS-library path."""
     ops = _ops()
     rs = np.random.RandomState(10)
-    x = torch.tensor(rs.randn(40000, 64), dtype=torch.float32, device=DEV, requires_grad=True)
-    w = torch.tensor(rs.randn(32, 64), dtype=torch.float32, device=DEV, requires_grad=True)
-    b = torch.tensor(rs.randn(32), dtype=torch.float32, device=DEV, requires_grad=True)
-    g = torch.tensor(rs.randn(40000, 32), dtype=torch.float32, device=DEV)
-    ref = F_lin(x, w, b)
-    ref.backward(g)
-    gx, gw, gb = x.grad.clone(), w.grad.clone(), b.grad.clone()
-    x.grad = w.grad = b.grad = None
-    out = ops.skinny_linear(x, w, b)
-    out.backward(g)
-    assert rel(out, ref) < 1e-6 and rel(x.grad, gx) < 1e-6 and rel(w.grad, gw) < 1e-5 and rel(b.grad, gb) < 1e-5
+    for M, K, N in ((40000, 64, 32), (128, 3, 256), (77, 10, 6), (0, 3, 8)):
+        x = torch.tensor(rs.randn(M, K), dtype=torch.float32, device=DEV, requires_grad=True)
+        w = torch.tensor(rs.randn(N, K), dtype=torch.float32, device=DEV, requires_grad=True)
+        b = torch.tensor(rs.randn(N), dtype=torch.float32, device=DEV, requires_grad=True)
+        g = torch.tensor(rs.randn(M, N), dtype=torch.float32, device=DEV)
+        ref = F_lin(x, w, b)
+        ref.backward(g)
+        gx, gw, gb = x.grad.clone(), w.grad.clone(), b.grad.clone()
+        x.grad = w.grad = b.grad = None
+        out = ops.linear(x, w, b)
+        out.backward(g)
+        assert out.shape == ref.shape
+        if M == 0:
+            assert float(w.grad.abs().max()) == 0.0 and float(b.grad.abs().max()) == 0.0
+            continue
+        assert rel(out, ref) < 1e-6 and rel(x.grad, gx) < 1e-6 and rel(w.grad, gw) < 1e-5 and rel(b.grad, gb) < 1e-5
 
 
 def test_edge_head_logits_and_activation():
@@ -780,3 +787,40 @@ def test_knn_graph_kernel_matches_oracle():
         N = pos.shape[0]
         ok = own[0] >= 0
         assert set((own[0][ok] * N + own[1][ok]).tolist()) == set((ref[0] * N + ref[1]).tolist())
+
+
+@pytest.mark.parametrize("hidden,key,heads", [(256, 128, 4), (128, 64, 4), (256, 256, 8)])
+def test_dense_attention_module_all_head_geometries(hidden, key, heads):
+    """MultiHeadDeAttention (reference model/CProMG.py:134-158) against the oracle's dense_mha: the shipped head geometry
+    (32 / 64 channels per head: the MFMA attention kernel k19 on fused projections) AND other geometries, which take the
+    generic branch of CProMG._dense_attention (separate projections, masked softmax kernel, batched library products) -
+    self attention with a causal + padding mask, cross attention with a padding mask, all parameter gradients."""
+    from singa_amd.model.CProMG import MultiHeadDeAttention
+    torch.manual_seed(hidden + key + heads)
+    B, T, S = 3, 37, 53
+    m = MultiHeadDeAttention(hidden, key, heads, device=DEV)
+    sd = {"a." + k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x = torch.randn(B, T, hidden)
+    enc = torch.randn(B, S, hidden)
+    causal = torch.triu(torch.ones(T, T, dtype=torch.bool), 1).unsqueeze(0).expand(B, T, T) | (torch.rand(B, 1, T) < 0.15)
+    causal[:, :, 0] = False
+    pad = (torch.rand(B, 1, S) < 0.3).expand(B, T, S)
+    for Qc, Kc, mask in ((x, x, causal), (x, enc, pad)):
+        for v in sd.values():
+            v.grad = None
+        m.zero_grad(set_to_none=True)
+        q_o = Qc.clone().requires_grad_(True)
+        k_o = q_o if Kc is Qc else Kc.clone().requires_grad_(True)
+        ref = O.dense_mha(sd, "a", q_o, k_o, k_o, mask, heads=heads)
+        g = torch.randn_like(ref)
+        ref.backward(g)
+        q_d = Qc.to(DEV).requires_grad_(True)
+        k_d = q_d if Kc is Qc else Kc.to(DEV).requires_grad_(True)
+        out = m(q_d, k_d, k_d, mask.to(DEV))
+        out.backward(g.to(DEV))
+        assert rel(out, ref) < 2e-5
+        assert rel(q_d.grad, q_o.grad) < 5e-5
+        if k_d is not q_d:
+            assert rel(k_d.grad, k_o.grad) < 5e-5
+        for name, p in m.named_parameters():
+            assert rel(p.grad, sd["a." + name].grad) < 1e-4, name
