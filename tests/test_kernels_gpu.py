@@ -823,4 +823,8 @@ def test_dense_attention_module_all_head_geometries(hidden, key, heads):
         if k_d is not q_d:
             assert rel(k_d.grad, k_o.grad) < 5e-5
         for name, p in m.named_parameters():
-            assert rel(p.grad, sd["a." + name].grad) < 1e-4, name
+            want = sd["a." + name].grad
+            if name == "W_K.bias":          # softmax is shift-invariant along the keys: this gradient is zero up to rounding
+                assert float(p.grad.abs().max()) < 1e-5 and float(want.abs().max()) < 1e-5
+                continue
+            assert rel(p.grad, want) < 1e-4, name
