@@ -480,11 +480,17 @@ class TransBlockV2(nn.Module):
         x[target].embedding = self.norm_1(x[target].embedding)
 
     def forward(self, x: Union[SO3_Embedding, Dict], atomic_numbers: Union[Tensor, Dict], edge_distance: Tensor,
-                edge_index: Tensor, batch: int, hetero: bool, source_target: Optional[Tuple[str, str]] = None):
+                edge_index: Tensor, batch: int, hetero: bool, source_target: Optional[Tuple[str, str]] = None,
+                renormed_residual: Optional[Tensor] = None):
+        """renormed_residual (hetero only): the caller has applied `renorm_only` already and hands over the target's
+        embedding from before it (the block's residual) - the dict is then only read."""
         if isinstance(x, dict):
             assert hetero and source_target is not None
-            x_res = x[source_target[1]].embedding
-            self.renorm_only(x, source_target)
+            if renormed_residual is None:
+                x_res = x[source_target[1]].embedding
+                self.renorm_only(x, source_target)
+            else:
+                x_res = renormed_residual
             out = self.ga(x, atomic_numbers, edge_distance, edge_index, hetero, source_target, residual=x_res)
         else:
             x_res = x.embedding

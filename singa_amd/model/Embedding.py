@@ -58,6 +58,7 @@ class EquivariantEmbedding(nn.Module):
         self.skip_dead_hetero_layers = True
         # Parts 1 and 2 (protein-protein and ligand-ligand, same blocks, disjoint node sets) as ONE pass over their union
         self.fuse_homo_passes = True
+        self.overlap_hetero_passes = True      # Part 3's live layer on a second stream beside Part 4 (see _forward)
 
         self.SO3_rotation = nn.ModuleList([SO3_Rotation(self.lmax_list[0], device=device)])
         self.sphere_embedding = nn.Embedding(self.max_num_elements, self.sphere_channels_all, device=device)
@@ -125,12 +126,30 @@ class EquivariantEmbedding(nn.Module):
         x.embedding = self.norm(x.embedding)
         return x
 
-    def _hetero_pass(self, g, x_dict, atomic_numbers, edge_type, source, target, ev_dist, batch):
+    def _hetero_pass(self, g, x_dict, atomic_numbers, edge_type, source, target, ev_dist, batch, deferred=False):
+        """deferred: everything that CHANGES the shared dict (the edge-degree sum and the in-place norm_1 of every layer,
+        Q4) happens now; what only reads it - the last layer's attention + feed-forward block and the final norm, i.e. the
+        pass's result - is returned as a function to be called later (on another stream: _forward)."""
         ei = g[edge_type]["edge_index"]
         edge_distance = self._edge_scalars(ev_dist, atomic_numbers[source], atomic_numbers[target], ei)
         edge_degree = self.edge_degree_embedding(atomic_numbers, edge_distance, ei, hetero=True,
                                                  source_target=(source, target))
         x_dict[target].embedding = x_dict[target].embedding + edge_degree.embedding
+        if deferred and self.skip_dead_hetero_layers:
+            for i in range(self.num_layers - 1):
+                self.blocks[i].renorm_only(x_dict, (source, target))
+            last = self.blocks[self.num_layers - 1]
+            x_res = x_dict[target].embedding
+            last.renorm_only(x_dict, (source, target))
+            mk = lambda t: SO3_Embedding(0, self.lmax_list, self.sphere_channels, torch.float32, self.device, t)
+            view = {source: mk(x_dict[source].embedding), target: mk(x_dict[target].embedding)}   # what the last layer reads
+
+            def compute():
+                x = last(x=view, atomic_numbers=atomic_numbers, edge_distance=edge_distance, edge_index=ei, batch=batch,
+                         hetero=True, source_target=(source, target), renormed_residual=x_res)
+                x.embedding = self.norm(x.embedding)
+                return x
+            return compute
         x = None
         for i in range(self.num_layers):
             if self.skip_dead_hetero_layers and i < self.num_layers - 1:
@@ -203,11 +222,32 @@ class EquivariantEmbedding(nn.Module):
         self.SO3_rotation[0].set_wigner(self._frames(g, "lp", lp_ev))
         if batch is None:
             batch = len(atomic_numbers[PA])
-        x_dict["lp_edge"] = self._hetero_pass(g, x_dict, atomic_numbers, E_LP, LA, PA, lp_ev.norm(dim=-1), batch)
-        # Part 4: protein -> ligand, REUSING the Part-3 frames edge by edge (EMB:437-475, Q5)
         pl_ei = g[E_PL]["edge_index"]
         pl_ev = pos_p[pl_ei[0]] - pos_l[pl_ei[1]]
-        x_dict["pl_edge"] = self._hetero_pass(g, x_dict, atomic_numbers, E_PL, PA, LA, pl_ev.norm(dim=-1), batch)
+        if self.overlap_hetero_passes and self.skip_dead_hetero_layers and pos_p.is_cuda:
+            # Part 4 only depends on what Part 3 does to the shared dict (the edge-degree sum and the norm_1 chain, Q4), not
+            # on Part 3's result: Part 3's live layer (attention over the interaction edges + the feed-forward block over
+            # all protein atoms) runs on a second stream while Part 4 (the same on the few ligand atoms: latency-bound
+            # launches) runs here.  Same arithmetic in the same order inside each pass; autograd mirrors the split in the
+            # backward pass and a HIP-graph capture records two parallel branches (as for the two CProMG encoders).
+            cur = torch.cuda.current_stream()
+            if getattr(self, "_aux_stream", None) is None:
+                self._aux_stream = torch.cuda.Stream()
+            aux = self._aux_stream
+            part3 = self._hetero_pass(g, x_dict, atomic_numbers, E_LP, LA, PA, lp_ev.norm(dim=-1), batch, deferred=True)
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            with torch.cuda.stream(aux):
+                aux.wait_event(fork)
+                x_dict["lp_edge"] = part3()
+            # Part 4: protein -> ligand, REUSING the Part-3 frames edge by edge (EMB:437-475, Q5)
+            x_dict["pl_edge"] = self._hetero_pass(g, x_dict, atomic_numbers, E_PL, PA, LA, pl_ev.norm(dim=-1), batch)
+            cur.wait_stream(aux)
+            x_dict["lp_edge"].embedding.record_stream(cur)
+        else:
+            x_dict["lp_edge"] = self._hetero_pass(g, x_dict, atomic_numbers, E_LP, LA, PA, lp_ev.norm(dim=-1), batch)
+            # Part 4: protein -> ligand, REUSING the Part-3 frames edge by edge (EMB:437-475, Q5)
+            x_dict["pl_edge"] = self._hetero_pass(g, x_dict, atomic_numbers, E_PL, PA, LA, pl_ev.norm(dim=-1), batch)
         x_dict[PA].embedding = x_dict[PA].embedding + x_dict["lp_edge"].embedding
         x_dict[LA].embedding = x_dict[LA].embedding + x_dict["pl_edge"].embedding
         return x_dict

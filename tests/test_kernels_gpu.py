@@ -633,7 +633,8 @@ def test_lap_eig_batched_against_numpy():
     dgl's own output carries random signs, so the subspace is what can be compared): orthonormal columns, invariant
     subspace, Ritz values = eigenvalues 1..8, sign convention.  Cases: a path (distinct, clustered small eigenvalues), a
     ring with chords, many small components (a 30-fold zero eigenvalue), graphs with fewer than 9 nodes (zero-padded
-    columns), a single node, an edgeless graph, and 800-atom graphs (the two-pass register layout for n > 512)."""
+    columns), a single node, an edgeless graph, 800-atom graphs (the two-pass register layout for n > 512) and a 1,000-atom
+    graph (above the kernel's limit: the dense torch.linalg.eigh route)."""
     from singa_amd import graph as G
     rs = np.random.RandomState(0)
     graphs = []
@@ -653,10 +654,13 @@ def test_lap_eig_batched_against_numpy():
     # components interleaved in index order (positions != atom indices inside the kernel)
     n = 60
     graphs.append((n, _sym_edges([(i, i + 3) for i in range(n - 3)])))                                   # three interleaved paths
-    for big in (False, True):
+    # big = 800: the kernel's two-pass register layout; big = 1000: above the kernel's 896-atom limit, i.e. the dense fp64
+    # route of graph.laplacian_pe_batched (one batched torch.linalg.eigh on the device, padding rows sorted last) - a host-side
+    # graph utility for molecules larger than anything BASELINE.json's configurations hold (config 5: 800 + 40 atoms)
+    for big in (0, 800, 1000):
         gs = list(graphs)
         if big:
-            n = 800
+            n = big
             pairs = [(i, i + 1) for i in range(n - 1)] + [(int(a), int(b)) for a, b in rs.randint(0, n, (400, 2)) if a != b]
             gs = [(n, _sym_edges(pairs)), gs[0], gs[3]]
         off, eis, batch = 0, [], []
