@@ -109,8 +109,8 @@ def kernel_bytes(tag, E, N, L, C=16, CH=112, heads=7):
         return E * ((KR + 1) * 128 * 4 + KR * 128 * 4 + (KR + 1) * 128 * 4)
     if tag == "s2_node_fwd":
         return E * ((K + 1) * 512 * 4 + K * 512 * 4)
-    if tag == "s2_node_bwd":
-        return E * ((K + 1) * 512 * 4 + K * 512 * 4 + (K + 1) * 512 * 4)
+    if tag == "s2_node_bwd":  # the fused form (singa_s2act_ffn_bwd): reads the input, the gate and the SMALL gradient [K, 16]; writes d input, d gate
+        return E * ((K + 1) * 512 * 4 + K * 16 * 4 + (K + 1) * 512 * 4)
     raise KeyError(tag)
 
 
@@ -302,24 +302,39 @@ def rocprof_in_graph_us(prof, kernel_substr, grid):
 
 
 def copy_ceiling_gbs(dev, n=64 * 1024 * 1024, reps=10, wide=True):
-    """Measured device-copy bandwidth (read + write bytes / time) of the library's own copy kernels on 256 MB operands:
-    singa_calib_copy16 (16 bytes per lane - the practical HBM ceiling next to the 8 TB/s spec peak) or singa_calib_copy (one
-    dword per lane, the segment kernels' access shape)."""
+    """Measured device-copy bandwidth (read + write bytes / time) of the library's own copy kernels on 256 MB operands.
+    wide: singa_calib_copy16 (16 bytes per lane) over a small sweep of launch shapes (workgroups per CU x loads in flight
+    per lane) - the best is the practical HBM ceiling of this box next to the 8 TB/s spec peak; returns (GB/s, shape).
+    Otherwise singa_calib_copy (one dword per lane, the segment kernels' access shape)."""
     import ctypes
     from singa_amd import _lib
     a = torch.randn(n, device=dev)
     b = torch.empty_like(a)
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    fn = _lib.lib().singa_calib_copy16 if wide else _lib.lib().singa_calib_copy
-    for _ in range(2):
-        fn(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n, st)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n, st)
-    e1.record()
-    torch.cuda.synchronize()
-    return round(2.0 * 4 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+    lib = _lib.lib()
+    pa, pb = ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr())
+
+    def rate(fn):
+        for _ in range(2):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return round(2.0 * 4 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+    if not wide:
+        return rate(lambda: lib.singa_calib_copy(pa, pb, n, st))
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    best = (0.0, None)
+    for per_cu in (4, 8, 16, 32):
+        for unroll in (1, 2, 4):
+            r = rate(lambda: lib.singa_calib_copy16(pa, pb, n, cus * per_cu, unroll, st))
+            if r > best[0]:
+                best = (r, f"{per_cu} workgroups per CU x {unroll} loads in flight per lane")
+    return best
 
 
 def timed_region(engine, batches, steps, multi, dev, prefetch=True):
@@ -908,14 +923,16 @@ def main():
                     "avg_launch_us_eager": per_e.get("k10_fwd", {}).get("avg_launch_us"),
                     "avg_launch_us_rocprof": in_prof,
                     "rocprof_source": f"rocprofv3 --kernel-trace of this command (replayed steps): {src}" if in_prof else None,
-                    "hbm_copy_ceiling": copy_ceiling_gbs(dev, wide=True),
-                    "hbm_copy_ceiling_note": "GB/s, read + write bytes of the library's 16-byte-per-lane copy kernel on 256 MB operands, "
-                                             "measured in this process (hbm_copy_dword: one dword per lane, the segment kernels' shape)",
+                    "hbm_copy_ceiling": None,
+                    "hbm_copy_ceiling_note": "GB/s, read + write bytes of the library's 16-byte-per-lane copy kernel on 256 MB operands, best "
+                                             "of a sweep of launch shapes, measured in this process (hbm_copy_dword: one dword per lane, the "
+                                             "segment kernels' access shape)",
                     "hbm_copy_dword": copy_ceiling_gbs(dev, wide=False),
                     "edges": big, "dst_nodes": n_union,
                     "other_kernels": {t: v for t, v in src_rows.items() if t != "k10_fwd"},
                     "other_kernels_eager": {t: {"avg_launch_us": v["avg_launch_us"], "frac": v["frac"]} for t, v in per_e.items()}
                     if how == "in_graph" else None}
+            roof["hbm_copy_ceiling"], roof["hbm_copy_ceiling_shape"] = copy_ceiling_gbs(dev, wide=True)
             roof["frac_of_copy_ceiling"] = round(k["achieved"] / roof["hbm_copy_ceiling"], 4) if roof["hbm_copy_ceiling"] else None
             if prof and prof[1].get("mfma"):
                 roof["mfma"] = dict(prof[1]["mfma"], source=os.path.relpath(prof[0], ROOT), peak_tflops=MFMA_F32_PEAK_TFLOPS)

@@ -424,8 +424,10 @@ int singa_prof_stamps(unsigned long long* buf, int cap);
 int singa_prof_read_stamps(const unsigned long long* host_stamps, float* ms, int* tags, int* edges, int* nodes, int cap);
 int singa_prof_reset(void);
 int singa_calib_copy(const float* src, float* dst, long long n, void* stream);
-/* the same copy with 16 bytes per lane (n % 4 == 0, 16-byte aligned): the practical HBM ceiling bench.py reports */
-int singa_calib_copy16(const float* src, float* dst, long long n, void* stream);
+/* a copy with 16 bytes per lane (n % 4 == 0, 16-byte aligned), `blocks` workgroups of 256 threads moving contiguous chunks of
+ * 256 * unroll float4s (unroll in {1, 2, 4, 8} loads in flight per lane): bench.py sweeps a few shapes and reports the best as the
+ * practical HBM ceiling of the box */
+int singa_calib_copy16(const float* src, float* dst, long long n, int blocks, int unroll, void* stream);
 
 #ifdef __cplusplus
 }

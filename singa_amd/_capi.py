@@ -108,7 +108,7 @@ _SIGS = {
     "singa_prof_read_stamps": ([P, P, P, P, P, I32], I32),
     "singa_prof_reset": ([], I32),
     "singa_calib_copy": ([P, P, C.c_longlong, P], I32),
-    "singa_calib_copy16": ([P, P, C.c_longlong, P], I32),
+    "singa_calib_copy16": ([P, P, C.c_longlong, I32, I32, P], I32),
 }
 
 EXPORTS = tuple(_SIGS)

@@ -61,6 +61,13 @@ int g_stamp_cap = 0;
 __global__ void stamp_kernel(unsigned long long* dst) { *dst = (unsigned long long)wall_clock64(); }
 int g_prof_edges_hint = 0;  // E of the next profiled launch (the kernel itself only needs row_ptr)
 
+// Streaming accesses of the scatter kernel (k10): message rows are read once and node rows written once per launch - marked
+// non-temporal so that they do not displace the Wigner records and row pointers (re-read by the next launches) from the caches.
+#ifndef SINGA_NT_LOAD
+#define SINGA_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define SINGA_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+
 // SINGA_KEEP_VGPR(x): an empty asm that pins x to its own vector register at that point (tests/emul defines it away)
 #ifndef SINGA_KEEP_VGPR
 #define SINGA_KEEP_VGPR(x) __asm__ volatile("" : "+v"(x))
@@ -464,7 +471,7 @@ __global__ void __launch_bounds__(128) rotate_back_scatter_kernel(Segs msg, cons
                 const int m = mi - I::mm(l);
                 if (M0 && m != 0) continue;
                 const int q = I::mpos(l, m);        // compile-time: segment and offset are immediates
-                const float x = q < r0 ? b0[q * CH] : (q < r01 ? b1[(q - r0) * CH] : b2[(q - r01) * CH]);
+                const float x = SINGA_NT_LOAD(q < r0 ? b0 + q * CH : (q < r01 ? b1 + (q - r0) * CH : b2 + (q - r01) * CH));
                 v[M0 ? l : I::kr_off(l) + mi] = x * a;
             }
         }
@@ -523,7 +530,7 @@ __global__ void __launch_bounds__(128) rotate_back_scatter_kernel(Segs msg, cons
             for (int l = 0; l <= L; ++l) {
 #pragma unroll
                 for (int j = 0; j < 2 * l + 1; ++j)
-                    o[(long long)(l * l + j) * CH] = acc[l * l + j] * (rescale_of(l, M) * out_scale);
+                    SINGA_NT_STORE(acc[l * l + j] * (rescale_of(l, M) * out_scale), o + (long long)(l * l + j) * CH);
             }
         }
     }
@@ -4758,17 +4765,24 @@ __global__ void calib_copy_kernel(const float* __restrict__ src, float* __restri
 }
 
 // The same with 16 bytes per lane (the guide's float4 copy): the practical HBM ceiling next to the 8 TB/s spec peak.
+template <int UNROLL>
 __global__ void __launch_bounds__(256) calib_copy16_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long long n4) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n4; i += 4 * stride) {                 // four independent 16-byte loads in flight per lane
-        const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a;
-        dst[i + stride] = b;
-        dst[i + 2 * stride] = c;
-        dst[i + 3 * stride] = d;
+    // a workgroup moves contiguous chunks of 256 * UNROLL float4s: UNROLL independent 16-byte loads in flight per lane, every
+    // wave instruction a contiguous 1 KB
+    const long long chunk = 256LL * UNROLL;
+    for (long long base = (long long)blockIdx.x * chunk; base < n4; base += (long long)gridDim.x * chunk) {
+        float4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const long long i = base + threadIdx.x + 256LL * u;
+            if (i < n4) v[u] = src[i];
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const long long i = base + threadIdx.x + 256LL * u;
+            if (i < n4) dst[i] = v[u];
+        }
     }
-    for (; i < n4; i += stride) dst[i] = src[i];
 }
 
 }  // namespace
@@ -4876,10 +4890,18 @@ int singa_knn_graph(const float* pos, const int32_t* batch, const long long* ptr
     return check_launch("knn_graph");
 }
 
-int singa_calib_copy16(const float* src, float* dst, long long n, void* stream) {
+int singa_calib_copy16(const float* src, float* dst, long long n, int blocks, int unroll, void* stream) {
     if (!src || !dst) return fail(SINGA_E_NULL, "calib_copy16: null pointer");
     if (n % 4 || ((uintptr_t)src | (uintptr_t)dst) % 16) return fail(SINGA_E_SHAPE, "calib_copy16: n % 4 == 0 and 16-byte aligned pointers");
-    hipLaunchKernelGGL(calib_copy16_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (float4*)dst, n / 4);
+    if (blocks < 1 || blocks > (1 << 20) || (unroll != 1 && unroll != 2 && unroll != 4 && unroll != 8))
+        return fail(SINGA_E_SHAPE, "calib_copy16: blocks >= 1, unroll in {1, 2, 4, 8}");
+    const float4* s4 = (const float4*)src;
+    float4* d4 = (float4*)dst;
+    hipStream_t st = (hipStream_t)stream;
+    if (unroll == 1) hipLaunchKernelGGL(calib_copy16_kernel<1>, dim3(blocks), dim3(256), 0, st, s4, d4, n / 4);
+    else if (unroll == 2) hipLaunchKernelGGL(calib_copy16_kernel<2>, dim3(blocks), dim3(256), 0, st, s4, d4, n / 4);
+    else if (unroll == 4) hipLaunchKernelGGL(calib_copy16_kernel<4>, dim3(blocks), dim3(256), 0, st, s4, d4, n / 4);
+    else hipLaunchKernelGGL(calib_copy16_kernel<8>, dim3(blocks), dim3(256), 0, st, s4, d4, n / 4);
     return check_launch("calib_copy16");
 }
 

@@ -58,7 +58,9 @@ class EquivariantEmbedding(nn.Module):
         self.skip_dead_hetero_layers = True
         # Parts 1 and 2 (protein-protein and ligand-ligand, same blocks, disjoint node sets) as ONE pass over their union
         self.fuse_homo_passes = True
-        self.overlap_hetero_passes = True      # Part 3's live layer on a second stream beside Part 4 (see _forward)
+        import os
+        # Part 3's live layer on a second stream beside Part 4 (see _forward); SINGA_OVERLAP_HETERO=0: one stream (lab)
+        self.overlap_hetero_passes = os.environ.get("SINGA_OVERLAP_HETERO", "1") == "1"
 
         self.SO3_rotation = nn.ModuleList([SO3_Rotation(self.lmax_list[0], device=device)])
         self.sphere_embedding = nn.Embedding(self.max_num_elements, self.sphere_channels_all, device=device)
