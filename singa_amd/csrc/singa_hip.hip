@@ -61,13 +61,8 @@ int g_stamp_cap = 0;
 __global__ void stamp_kernel(unsigned long long* dst) { *dst = (unsigned long long)wall_clock64(); }
 int g_prof_edges_hint = 0;  // E of the next profiled launch (the kernel itself only needs row_ptr)
 
-// Streaming accesses of the scatter kernel (k10): message rows are read once and node rows written once per launch - marked
-// non-temporal so that they do not displace the Wigner records and row pointers (re-read by the next launches) from the caches.
-#ifndef SINGA_NT_LOAD
-#define SINGA_NT_LOAD(p) __builtin_nontemporal_load(p)
-#define SINGA_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
-#endif
-
+// (Tried in round 4 and dropped: non-temporal loads of the message rows / stores of the node rows in the scatter kernel k10 -
+// 320 instead of 270 us per config-3 launch.)
 // SINGA_KEEP_VGPR(x): an empty asm that pins x to its own vector register at that point (tests/emul defines it away)
 #ifndef SINGA_KEEP_VGPR
 #define SINGA_KEEP_VGPR(x) __asm__ volatile("" : "+v"(x))
@@ -471,7 +466,7 @@ __global__ void __launch_bounds__(128) rotate_back_scatter_kernel(Segs msg, cons
                 const int m = mi - I::mm(l);
                 if (M0 && m != 0) continue;
                 const int q = I::mpos(l, m);        // compile-time: segment and offset are immediates
-                const float x = SINGA_NT_LOAD(q < r0 ? b0 + q * CH : (q < r01 ? b1 + (q - r0) * CH : b2 + (q - r01) * CH));
+                const float x = q < r0 ? b0[q * CH] : (q < r01 ? b1[(q - r0) * CH] : b2[(q - r01) * CH]);
                 v[M0 ? l : I::kr_off(l) + mi] = x * a;
             }
         }
@@ -530,7 +525,7 @@ __global__ void __launch_bounds__(128) rotate_back_scatter_kernel(Segs msg, cons
             for (int l = 0; l <= L; ++l) {
 #pragma unroll
                 for (int j = 0; j < 2 * l + 1; ++j)
-                    SINGA_NT_STORE(acc[l * l + j] * (rescale_of(l, M) * out_scale), o + (long long)(l * l + j) * CH);
+                    o[(long long)(l * l + j) * CH] = acc[l * l + j] * (rescale_of(l, M) * out_scale);
             }
         }
     }
@@ -3116,7 +3111,6 @@ __global__ void __launch_bounds__(256, (FFN && L == 4) ? 3 : 1) s2act_sep_bwd_ke
                 }
                 // one row at a time: left alone, the SLP vectoriser pairs rows of DIFFERENT degrees into v_pk_fma_f32 and keeps
                 // several degrees' weights (and the rows' LDS words) live at once - 215 registers instead of ~150 at L = 4
-                SINGA_KEEP_VGPR(acc);
                 gy[i] = acc;
             }
         }

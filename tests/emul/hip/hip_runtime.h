@@ -66,8 +66,6 @@ static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, K,
     *n = 0;
     return hipSuccess;
 }
-#define SINGA_NT_LOAD(p) (*(p))
-#define SINGA_NT_STORE(v, p) (*(p) = (v))
 static inline long long wall_clock64() { return 0; }
 static inline float __fsub_rn(float a, float b) { volatile float r = a - b; return r; }
 static inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
