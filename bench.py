@@ -78,6 +78,7 @@ def parse():
     ap.add_argument("--cpu-graphs", type=int, default=8, help="graphs in the bounded CPU-oracle sample")
     ap.add_argument("--cpu-graphs-1t", type=int, default=2, help="graphs of the one-thread CPU-oracle figure (0 = skip)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--ingraph-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-threads", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-state", type=str, default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -655,34 +656,6 @@ def run_workload(R, workload, steps, warmup, main=True):
         log(f"strong proxy: {len(p_ids)} graphs, median step {res['proxy']['ms_per_step_median']} ms")
         del p_batches
 
-    # ---- roofline, measured INSIDE the replayed step: a second capture of the same step with a device-timestamp kernel in
-    # front of and behind every k4 / k10 / S2 / GEMM dispatch (the library's tagging in graph mode; external event-record nodes
-    # are refused under capture by this ROCm build), replayed a few times
-    per_graph = None
-    if use_graph and args.ingraph_steps > 0:
-        try:
-            engine.release()
-            engine.pre_capture_hook = lambda: ops.profile_start(in_graph=True)
-            engine.post_capture_hook = ops.profile_pause
-            engine.step(batches[0])                       # capture (tagged) + first replay
-            engine.pre_capture_hook = engine.post_capture_hook = None
-            acc = []
-            for i in range(args.ingraph_steps):
-                engine.step(batches[0])
-                torch.cuda.synchronize()
-                acc += ops.profile_read()
-            per_graph, big_g, n_union_g = roofline_rows(acc, L)
-            res["ingraph"] = (per_graph, big_g, n_union_g)
-            log("in-graph launches (us): " + "; ".join(f"{k} {v['avg_launch_us']}" for k, v in per_graph.items()))
-        except Exception as e:                             # noqa: BLE001 - the eager timing below still stands
-            log(f"in-graph dispatch timing failed: {type(e).__name__}: {e}")
-            res["ingraph_error"] = f"{type(e).__name__}: {e}"
-        finally:
-            engine.pre_capture_hook = engine.post_capture_hook = None
-            torch.cuda.synchronize()
-            engine.release()                               # the stamped capture goes before its stamp buffer does
-            ops.profile_end()
-
     # ---- instrumented eager pass: the same step run eagerly with start/stop events attached to every tagged dispatch
     if main and args.roofline_steps > 0:
         if use_graph:
@@ -746,7 +719,78 @@ def run_workload(R, workload, steps, warmup, main=True):
     gc.collect()
     torch.cuda.synchronize()
     torch.cuda.empty_cache()
+
+    # ---- roofline, measured INSIDE the replayed step: a second capture of the same step with a device-timestamp kernel in
+    # front of and behind every k4 / k10 / S2 / GEMM dispatch (the library's tagging in graph mode; external event-record nodes
+    # are refused under capture by this ROCm build), replayed a few times.  In a CHILD process (one GPU, after this workload's
+    # memory has been handed back): an instrumented capture is not the product path, and whatever goes wrong in it must not
+    # take the measured line down with it.
+    if use_graph and args.ingraph_steps > 0 and world == 1 and not multi and rank == 0:
+        recs, err = ingraph_child(args, workload)
+        if recs is not None:
+            per_graph, big_g, n_union_g = roofline_rows(recs, L)
+            res["ingraph"] = (per_graph, big_g, n_union_g)
+            log("in-graph launches (us): " + "; ".join(f"{k} {v['avg_launch_us']}" for k, v in per_graph.items()))
+        else:
+            res["ingraph_error"] = err
+            log(f"in-graph dispatch timing failed: {err}")
     return res
+
+
+def ingraph_worker(args):
+    """Child process of `ingraph_child`: the step of one workload captured with the library's tagging in graph mode, replayed
+    `--ingraph-steps` times; prints {"records": [[tag, ms, edges, nodes], ...]} (one line) on stdout."""
+    out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    import __graft_entry__
+    __graft_entry__.build()
+    from singa_amd import graph as G, ops
+    from singa_amd.config import load_config
+    from singa_amd.engine import TrainStep
+    from singa_amd.model.GAN import SINGA
+    from singa_amd.optim import Adam
+    L, kw, base_ids, _ = G.resolve_workload(args.workload)
+    cfg = load_config(lmax=L)
+    torch.manual_seed(cfg.train.seed)
+    model = SINGA(cfg, device=dev)
+    model.train()
+    opt = Adam(model.parameters(), lr=cfg.train.optimizer.lr, betas=(cfg.train.optimizer.beta1, cfg.train.optimizer.beta2))
+    engine = TrainStep(model, opt, None, use_graph=True, max_grad_norm=float(cfg.train.max_grad_norm), bucket=True,
+                       growth=args.growth, max_cached=2)
+    batch = G.synthetic_batch(len(base_ids), ids=base_ids, with_lap=False, **kw).to(dev)
+    batch.extras["lap_pe_in_step"] = True
+    engine.pre_capture_hook = lambda: ops.profile_start(in_graph=True)
+    engine.post_capture_hook = ops.profile_pause
+    engine.step(batch)                                 # capture (tagged) + first replay
+    engine.pre_capture_hook = engine.post_capture_hook = None
+    acc = []
+    for _ in range(max(1, args.ingraph_steps)):
+        engine.step(batch)
+        torch.cuda.synchronize()
+        acc += ops.profile_read()
+    print(json.dumps({"records": [[t, float(ms), int(e), int(n)] for t, ms, e, n in acc]}), file=out, flush=True)
+    engine.release()
+    ops.profile_end()
+    return 0
+
+
+def ingraph_child(args, workload, limit_s=240):
+    """-> (records, None) or (None, reason)."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--ingraph-worker", "--workload", workload, "--ingraph-steps",
+           str(args.ingraph_steps), "--growth", str(args.growth)]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SINGA_RCCL_SELFTEST"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, timeout=limit_s)
+        lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return None, f"child exited with code {r.returncode}"
+        return [tuple(x) for x in json.loads(lines[-1])["records"]], None
+    except Exception as e:                                 # noqa: BLE001
+        return None, f"{type(e).__name__}: {e}"
 
 
 def overlap_check(R, model, opt, batches, ids, n_graphs, scaling, cfg, bucket, log, k_steps=6):
@@ -805,6 +849,8 @@ def main():
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args.workload, args.cpu_graphs, args.cpu_threads or host_cores(), args.cpu_state,
                                    args.cpu_graphs_1t)
+    if args.ingraph_worker:
+        return ingraph_worker(args)
     if args.sweep:
         return sweep(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -912,7 +958,7 @@ def main():
             roof = {"bound": "hbm", "kernel": "rotate_back_scatter_kernel (k10 fwd, 'scatter-TP', on the bonded edges: "
                                               "protein-protein U ligand-ligand pass)",
                     "achieved": k["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": k["frac"],
-                    "frac_uses": ("avg_launch_us = the kernel's dispatches INSIDE the replayed step of this run: a second capture of "
+                    "frac_uses": ("avg_launch_us = the kernel's dispatches INSIDE a replayed step, measured by a child process of this run: a capture of "
                                   "the same step with a device-timestamp kernel (100 MHz wall clock) in front of and behind each "
                                   "tagged launch, minus a calibration pair with nothing in between (so it still includes ~one "
                                   f"dependent-launch gap); {args.ingraph_steps} replays" if how == "in_graph" else

@@ -3109,8 +3109,10 @@ __global__ void __launch_bounds__(256, (FFN && L == 4) ? 3 : 1) s2act_sep_bwd_ke
                     acc = fmaf(g4.z, w[4 * q + 2], acc);
                     acc = fmaf(g4.w, w[4 * q + 3], acc);
                 }
-                // one row at a time: left alone, the SLP vectoriser pairs rows of DIFFERENT degrees into v_pk_fma_f32 and keeps
-                // several degrees' weights (and the rows' LDS words) live at once - 215 registers instead of ~150 at L = 4
+                // L = 6: one row at a time.  Left alone, the SLP vectoriser pairs rows into v_pk_fma_f32 and keeps more weights
+                // and LDS words live at once: fine inside the 168-register budget of L = 4 (three wavefronts per SIMD, see
+                // __launch_bounds__), scratch spills at L = 6
+                if constexpr (L > 4) SINGA_KEEP_VGPR(acc);
                 gy[i] = acc;
             }
         }

@@ -503,9 +503,7 @@ class Transformer(nn.Module):
         waits for through events.  Autograd replays the same split in the backward pass, and a HIP-graph capture records
         the two streams as parallel branches.  Same arithmetic, same order within each encoder."""
         cur = torch.cuda.current_stream()
-        if getattr(self, "_aux_stream", None) is None:
-            self._aux_stream = torch.cuda.Stream()
-        aux = self._aux_stream
+        aux = ops.branch_stream(node_attr.device)
         if prep.get("p") is None:
             prep = dict(prep, p=self.encoder.prepare(pos, batch, B, knn))
         if prep.get("l") is None:

@@ -233,9 +233,7 @@ class EquivariantEmbedding(nn.Module):
             # launches) runs here.  Same arithmetic in the same order inside each pass; autograd mirrors the split in the
             # backward pass and a HIP-graph capture records two parallel branches (as for the two CProMG encoders).
             cur = torch.cuda.current_stream()
-            if getattr(self, "_aux_stream", None) is None:
-                self._aux_stream = torch.cuda.Stream()
-            aux = self._aux_stream
+            aux = ops.branch_stream(pos_p.device)       # the same second stream the transformer uses: never three branches
             part3 = self._hetero_pass(g, x_dict, atomic_numbers, E_LP, LA, PA, lp_ev.norm(dim=-1), batch, deferred=True)
             fork = torch.cuda.Event()
             fork.record(cur)

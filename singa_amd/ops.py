@@ -83,6 +83,22 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_branch_streams = {}
+
+
+def branch_stream(device=None):
+    """THE second stream of the model's forward / backward passes on `device` (one per device, created on first use): the
+    ligand encoder beside the protein encoder (CProMG.Transformer), the ligand -> protein pass's live layer beside the protein
+    -> ligand pass (EquivariantEmbedding).  One shared stream on purpose: a captured step then never has more than two
+    concurrent branches - with a stream per module the embedding's backward branch could run beside the ligand encoder's
+    (three branches), and an instrumented capture of such a step crashed inside hipGraphLaunch on this ROCm build."""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    dev = torch.cuda.current_device() if dev is None else dev
+    if dev not in _branch_streams:
+        _branch_streams[dev] = torch.cuda.Stream(device=dev)
+    return _branch_streams[dev]
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
