@@ -949,7 +949,15 @@ def main():
             big, n_union = (big_g, nu_g) if how == "in_graph" else (big_e, nu_e)
             k = src_rows["k10_fwd"]
             prof = committed_profile(args.workload)
-            tr = pmc_traffic(prof, f"rotate_back_scatter_kernel<{L}, 2, false", n_union * 128)
+            # PMC traffic: the counter passes run the step eagerly on the UNPADDED batch, so their k10 launch is the eager rows'
+            # (edges, nodes), not the padded one of the replayed step: looked up by either grid, reported with its own bytes
+            tr, tr_launch = None, None
+            for e_, n_ in ((big, n_union), (big_e, nu_e)):
+                if n_ and tr is None:
+                    tr = pmc_traffic(prof, f"rotate_back_scatter_kernel<{L}, 2, false", n_ * 128)
+                    if tr is not None:
+                        alg = kernel_bytes("k10_fwd", e_, n_, L)
+                        tr_launch = {"edges": e_, "dst_nodes": n_, "algorithmic_bytes": alg, "traffic_over_algorithmic": round(tr / alg, 4)}
             in_prof = rocprof_in_graph_us(prof, f"rotate_back_scatter_kernel<{L}, 2, false", n_union * 128)
             sha = lib_source_sha()
             same = prof is not None and prof[1].get("lib_sha") == sha
@@ -963,7 +971,7 @@ def main():
                                   "tagged launch, minus a calibration pair with nothing in between (so it still includes ~one "
                                   f"dependent-launch gap); {args.ingraph_steps} replays" if how == "in_graph" else
                                   "avg_launch_us (events attached to each EAGER dispatch, measured in this process)"),
-                    "traffic": tr,
+                    "traffic": tr, "traffic_launch": tr_launch,
                     "traffic_source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command: {src}" if tr else None,
                     "bytes_per_launch": k["bytes_per_launch"], "avg_launch_us": k["avg_launch_us"], "launches": k["launches"],
                     "avg_launch_us_eager": per_e.get("k10_fwd", {}).get("avg_launch_us"),
