@@ -3063,6 +3063,11 @@ __global__ void __launch_bounds__(256, (FFN && L == 4) ? 3 : 1) s2act_sep_bwd_ke
                                                             long long EC, const float* __restrict__ W2) {
     using S = S2Sep<L, EDGE>;
     constexpr int KIN = S::KIN, NM = S::NM, RA = S::RA, MM = S::MM;
+#ifdef SINGA_S2_BWD_SCALAR_RINGS
+    constexpr bool PACK_RINGS = false;
+#else
+    constexpr bool PACK_RINGS = true;
+#endif
     (void)A;
     static_assert(!FFN || (!EDGE && C % 256 == 0), "the fused form is the node grid's, one node per workgroup");
     long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -3138,7 +3143,27 @@ __global__ void __launch_bounds__(256, (FFN && L == 4) ? 3 : 1) s2act_sep_bwd_ke
             else ge[S::mc(i)] = fmaf(Qb[i], gy[i], ge[S::mc(i)]);
         }
         float acc1[NM], acc2[NM];
-        {
+        if constexpr (PACK_RINGS) {
+            // the two rings of the mirror pair go through the SAME Fourier steps with the same (compile-time) coefficients: packed
+            // into the two halves of v_pk_fma_f32 operands the three transforms of a pair cost the instructions of one ring
+            // (the same operations per ring in the same order: bit-identical to the scalar form below)
+            v2f v[NM], q[NM], u[RA], t[RA], acc[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                v[m] = v2f{ve[m] + vo[m], ve[m] - vo[m]};
+                q[m] = v2f{ge[m] + go[m], ge[m] - go[m]};
+            }
+            ring_to_grid2<RA, MM>(v, u);
+            ring_to_grid2<RA, MM>(q, t);
+#pragma unroll
+            for (int a = 0; a < RA; ++a) {
+                t[a][0] *= silu_grad_fast(u[a][0]);
+                t[a][1] *= silu_grad_fast(u[a][1]);
+            }
+            ring_from_grid2<RA, MM>(t, acc);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) { acc1[m] = acc[m][0]; acc2[m] = acc[m][1]; }
+        } else {
             float v[NM], q[NM], u[RA], t[RA];
 #pragma unroll
             for (int m = 0; m < NM; ++m) { v[m] = ve[m] + vo[m]; q[m] = ge[m] + go[m]; }
