@@ -3063,10 +3063,13 @@ __global__ void __launch_bounds__(256, (FFN && L == 4) ? 3 : 1) s2act_sep_bwd_ke
                                                             long long EC, const float* __restrict__ W2) {
     using S = S2Sep<L, EDGE>;
     constexpr int KIN = S::KIN, NM = S::NM, RA = S::RA, MM = S::MM;
-#ifdef SINGA_S2_BWD_SCALAR_RINGS
-    constexpr bool PACK_RINGS = false;
-#else
+    // (round 4, measured and left off: the two rings of a mirror pair packed into v_pk_fma_f32 halves - 2.45 instead of 2.41 ms on
+    // the feed-forward grid, 565 instead of 520 us on the attention grid: the ~110 exp + rcp pairs per thread, quarter rate,
+    // and the moves that build the pairs cost what the halved FMA count saves)
+#ifdef SINGA_S2_BWD_PACK_RINGS
     constexpr bool PACK_RINGS = true;
+#else
+    constexpr bool PACK_RINGS = false;
 #endif
     (void)A;
     static_assert(!FFN || (!EDGE && C % 256 == 0), "the fused form is the node grid's, one node per workgroup");
