@@ -12,6 +12,9 @@ int singa_gemm_force_cfg(int cfg);
 int singa_gemm_occupancy(int a_r_contig, int b_r_contig, int cfg);
 /* 1 selects the VALU (lane-broadcast) form of singa_so3_skinny_expand / _reduce, 0 (default) the matrix-core form */
 int singa_so3_skinny_variant(int valu);
+/* singa_lap_pe: graphs whose largest connected component has at least n atoms take the sparse route (Chebyshev-filtered subspace
+ * iteration); default 384, a value above 896 switches it off, a small one forces it (tests) */
+int singa_lap_pe_fsi_min(int n);
 #ifdef __cplusplus
 }
 #endif

@@ -118,6 +118,7 @@ _LAB_SIGS = {
     "singa_so3_skinny_variant": ([I32], I32),
     "singa_gemm_occupancy": ([I32, I32, I32], I32),
     "singa_gemm_force_cfg": ([I32], I32),
+    "singa_lap_pe_fsi_min": ([I32], I32),
 }
 LAB_EXPORTS = tuple(_LAB_SIGS)
 

@@ -4201,11 +4201,281 @@ __global__ void __launch_bounds__(256) rowdot32_bwd_kernel(const float* __restri
 //      good as the reference's (dgl draws random signs on top) -
 //   5. back-transformation through the reflectors, sign convention (entry of largest magnitude positive), fp32 output.
 #ifndef SINGA_EMUL      // (workgroup-cooperative: not part of the sequential CPU emulation build of tests/emul)
+// ---- the sparse route of lap_pe_kernel (see "1b." there): Chebyshev-filtered subspace iteration, block of 16 vectors
+constexpr int LAP_FSI_PB = 16, LAP_FSI_ELLW = 32, LAP_FSI_DEG = 24, LAP_FSI_MAXIT = 40;
+constexpr int LAP_FSI_PER_LD = 3 * LAP_FSI_PB + LAP_FSI_ELLW + LAP_FSI_ELLW / 2;     // doubles of global scratch per atom
+constexpr int LAP_WORK_PER_LD = 3 + 4 * 9 + LAP_FSI_PER_LD;
+template <int NW, int KV>
+__device__ __forceinline__ bool lap_fsi(const double* __restrict__ A, int ld, int n, int sl, const int* perm, const int* cbeg,
+                                        const int* cend, int* ell_n, int* flag, double* Xl, double* sc, double* wk, int m, int tid,
+                                        int lane, int wave) {
+    constexpr int PB = LAP_FSI_PB, W = LAP_FSI_ELLW;
+    double* Yg = wk;                                    // [n][PB] the filter's previous block (global, L2 resident)
+    double* Wg = Yg + (long long)ld * PB;               // [n][PB] L X
+    double* Ng = Wg + (long long)ld * PB;               // [n][PB] the filter's next block, before it moves into LDS
+    double* ell_v = Ng + (long long)ld * PB;            // [n][W] the Laplacian's rows: values ...
+    int* ell_i = reinterpret_cast<int*>(ell_v + (long long)ld * W);     // ... and column POSITIONS
+    double* H = sc;                                     // [16][16] projected matrix / Gram matrix
+    double* Q = sc + 256;                               // [16][16] rotations / Cholesky factor
+    double* part = sc + 512;                            // [512] reduction scratch
+    double* theta = sc + 1024;                          // [16] Ritz values (ascending after `ritz`)
+    double* resn = theta + 16;                          // [16] residual norms
+    double* misc = resn + 16;                           // [8]
+    const int total = n * PB;
+    (void)sl;
+    // ---- rows of the Laplacian in ELL form, from the component blocks phase 1 has built (entries outside them are undefined)
+    if (tid == 0) flag[1] = 0;
+    __syncthreads();
+    for (int s0 = wave; s0 < n; s0 += NW) {
+        const int lo = cbeg[s0], hi = cend[s0];
+        const double* row = A + (long long)perm[s0] * ld;
+        int cnt = 0;
+        for (int t0 = lo; t0 <= hi; t0 += 64) {
+            const int t = t0 + lane;
+            const double v = t <= hi ? row[perm[t]] : 0.0;
+            const bool nz = v != 0.0;
+            const unsigned long long mask = __ballot(nz);
+            const int at = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            if (nz && at < W) {
+                ell_i[(long long)s0 * W + at] = t;
+                ell_v[(long long)s0 * W + at] = v;
+            }
+            cnt += __popcll(mask);
+        }
+        if (lane == 0) {
+            ell_n[s0] = cnt < W ? cnt : W;
+            if (cnt > W) flag[1] = 1;
+        }
+    }
+    __syncthreads();
+    if (flag[1]) return false;
+    // ---- start block: deterministic pseudo-random entries tied to the ATOM
+    for (int idx = tid; idx < total; idx += 1024) {
+        const int r = idx >> 4, j = idx & 15;
+        unsigned h = (unsigned)(perm[r] * 2654435761u) ^ (unsigned)((j + 11) * 40503u * 2246822519u);
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+        Xl[idx] = (double)(h & 0xFFFFFF) / 8388608.0 - 1.0;
+    }
+    __syncthreads();
+    auto lx = [&](int idx) -> double {                  // (L X)[r][j] from the block in LDS
+        const int r = idx >> 4, j = idx & 15;
+        const int cnt = ell_n[r];
+        const double* ev = ell_v + (long long)r * W;
+        const int* ei = ell_i + (long long)r * W;
+        double acc = 0.0;
+        for (int e = 0; e < cnt; ++e) acc += ev[e] * Xl[ei[e] * PB + j];
+        return acc;
+    };
+    // G = X^T B (B = X in LDS: Gram matrix; B = Wg: projected matrix), symmetrised, -> H
+    auto gram = [&](const double* B) {
+        if (tid < 512) {
+            const int p = tid & 255, ch = tid >> 8, a = p >> 4, b = p & 15;
+            double acc = 0.0;
+            for (int r = ch; r < n; r += 2) acc += Xl[r * PB + a] * B[r * PB + b];
+            part[ch * 256 + p] = acc;
+        }
+        __syncthreads();
+        if (tid < 256) Q[tid] = part[tid] + part[256 + tid];
+        __syncthreads();
+        if (tid < 256) H[tid] = 0.5 * (Q[tid] + Q[(tid & 15) * 16 + (tid >> 4)]);
+        __syncthreads();
+    };
+    // X <- X R^-1 with G = X^T X = R^T R (twice: CholQR2); false if a pivot vanishes
+    auto orthonormalise = [&]() -> bool {
+        for (int pass = 0; pass < 2; ++pass) {
+            gram(Xl);
+            if (tid == 0) {
+                misc[0] = 0.0;
+                double tr = 0.0;
+                for (int j = 0; j < PB; ++j) tr += H[j * 16 + j];
+                for (int j = 0; j < PB; ++j) {
+                    double d = H[j * 16 + j];
+                    for (int k = 0; k < j; ++k) d -= Q[k * 16 + j] * Q[k * 16 + j];
+                    if (!(d > 1e-26 * tr)) { misc[0] = 1.0; d = 1.0; }
+                    const double rj = sqrt(d);
+                    Q[j * 16 + j] = rj;
+                    for (int i = j + 1; i < PB; ++i) {
+                        double v = H[j * 16 + i];
+                        for (int k = 0; k < j; ++k) v -= Q[k * 16 + j] * Q[k * 16 + i];
+                        Q[j * 16 + i] = v / rj;
+                    }
+                }
+            }
+            __syncthreads();
+            if (misc[0] != 0.0) return false;
+            if (tid < n) {                  // the thread's own row, solved in place (y R = x): no register arrays
+                double* xr = Xl + tid * PB;
+#pragma unroll 1
+                for (int j = 0; j < PB; ++j) {
+                    double v = xr[j];
+#pragma unroll 1
+                    for (int i = 0; i < j; ++i) v -= xr[i] * Q[i * 16 + j];
+                    xr[j] = v / Q[j * 16 + j];
+                }
+            }
+            __syncthreads();
+        }
+        return true;
+    };
+    // Rayleigh-Ritz: Wg = L X, H = X^T L X, Jacobi, X <- X Q, Wg <- Wg Q (Ritz values ascending), residual norms
+    auto ritz = [&]() {
+        for (int idx = tid; idx < total; idx += 1024) Wg[idx] = lx(idx);
+        __syncthreads();
+        gram(Wg);
+        if (tid < 256) Q[tid] = (tid >> 4) == (tid & 15) ? 1.0 : 0.0;
+        __syncthreads();
+        // cyclic Jacobi with the round-robin ordering: 8 disjoint pairs per step, 8 lanes per pair (two rows each)
+        for (int sweep = 0; sweep < 10; ++sweep) {
+            if (tid == 0) {
+                double off = 0.0, dg = 0.0;
+                for (int i = 0; i < PB; ++i)
+                    for (int j = 0; j < PB; ++j) (i == j ? dg : off) += H[i * 16 + j] * H[i * 16 + j];
+                misc[1] = off <= 1e-30 * (dg + 1e-300) ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            const bool done = misc[1] != 0.0;
+            __syncthreads();
+            if (done) break;
+            for (int st = 0; st < 15; ++st) {
+                const int pr = tid >> 3, sub = tid & 7;
+                const int p = pr == 0 ? 15 : (st + pr) % 15, q = pr == 0 ? st : (st + 15 - pr) % 15;
+                double c = 1.0, sn = 0.0;
+                if (tid < 64) {
+                    const double hpp = H[p * 16 + p], hqq = H[q * 16 + q], hpq = H[p * 16 + q];
+                    if (fabs(hpq) > 1e-300) {
+                        const double tau = (hqq - hpp) / (2.0 * hpq);
+                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = 1.0 / sqrt(1.0 + t * t);
+                        sn = t * c;
+                    }
+                }
+                __syncthreads();
+                if (tid < 64) {
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int i = sub + 8 * h2;
+                        const double aip = H[i * 16 + p], aiq = H[i * 16 + q];
+                        H[i * 16 + p] = c * aip - sn * aiq;
+                        H[i * 16 + q] = sn * aip + c * aiq;
+                        const double qip = Q[i * 16 + p], qiq = Q[i * 16 + q];
+                        Q[i * 16 + p] = c * qip - sn * qiq;
+                        Q[i * 16 + q] = sn * qip + c * qiq;
+                    }
+                }
+                __syncthreads();
+                if (tid < 64) {
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int i = sub + 8 * h2;
+                        const double api = H[p * 16 + i], aqi = H[q * 16 + i];
+                        H[p * 16 + i] = c * api - sn * aqi;
+                        H[q * 16 + i] = sn * api + c * aqi;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // ascending order of the Ritz values; part[0..255] = Q with its columns in that order
+        if (tid == 0) {
+            int ord[PB];
+            for (int j = 0; j < PB; ++j) ord[j] = j;
+            for (int a = 1; a < PB; ++a) {
+                const int oa = ord[a];
+                int b = a;
+                while (b > 0 && H[ord[b - 1] * 16 + ord[b - 1]] > H[oa * 16 + oa]) { ord[b] = ord[b - 1]; --b; }
+                ord[b] = oa;
+            }
+            for (int j = 0; j < PB; ++j) {
+                theta[j] = H[ord[j] * 16 + ord[j]];
+                for (int i = 0; i < PB; ++i) part[i * 16 + j] = Q[i * 16 + ord[j]];
+            }
+        }
+        __syncthreads();
+        if (tid < n) {                      // one row of X, then the same row of L X (one at a time: 16 doubles of registers each)
+            for (int which = 0; which < 2; ++which) {
+                double* rowp = which == 0 ? Xl + tid * PB : Wg + tid * PB;
+                double x[PB];
+#pragma unroll
+                for (int i = 0; i < PB; ++i) x[i] = rowp[i];
+#pragma unroll 1
+                for (int j = 0; j < PB; ++j) {
+                    double xs = 0.0;
+#pragma unroll
+                    for (int i = 0; i < PB; ++i) xs += x[i] * part[i * 16 + j];
+                    rowp[j] = xs;
+                }
+            }
+        }
+        __syncthreads();
+        {   // residual norms |L x_j - theta_j x_j|
+            const int j = tid & 15, ch = tid >> 4;
+            const double th = theta[j];
+            double acc = 0.0;
+            for (int r = ch; r < n; r += 64) {
+                const double d = Wg[r * PB + j] - th * Xl[r * PB + j];
+                acc += d * d;
+            }
+            acc += __shfl_xor(acc, 16, 64);
+            acc += __shfl_xor(acc, 32, 64);
+            __syncthreads();                 // (part is read above by every row thread)
+            if (lane < 16) part[wave * 16 + lane] = acc;
+            __syncthreads();
+            if (tid < PB) {
+                double t = 0.0;
+                for (int w2 = 0; w2 < NW; ++w2) t += part[w2 * 16 + tid];
+                resn[tid] = sqrt(t);
+            }
+            __syncthreads();
+        }
+    };
+    if (!orthonormalise()) return false;
+    bool ok = false;
+    for (int it = 0; it < LAP_FSI_MAXIT; ++it) {
+        ritz();
+        double worst = 0.0;
+        for (int j = 0; j < m; ++j) worst = fmax(worst, resn[j]);
+        if (worst <= 2e-10) { ok = true; break; }
+        // Chebyshev filter of degree LAP_FSI_DEG: damp [a, 2], scaled at a0 (Zhou & Saad's recurrence)
+        const double a0 = theta[0], b = 2.0 + 1e-9;
+        const double a = fmax(theta[PB - 1], a0 + 1e-4);
+        if (!(a < b - 1e-3)) break;
+        const double e = 0.5 * (b - a), c = 0.5 * (b + a);
+        double sigma = e / (a0 - c);
+        const double sigma1 = sigma;
+        // (every step: next block -> global, barrier, then previous <- current, current <- next: a thread moves the elements it
+        // computed, so the only cross-thread hazard is the gather from the current block in LDS)
+        for (int idx = tid; idx < total; idx += 1024) Ng[idx] = (lx(idx) - c * Xl[idx]) * (sigma1 / e);
+        __syncthreads();
+        for (int idx = tid; idx < total; idx += 1024) { Yg[idx] = Xl[idx]; Xl[idx] = Ng[idx]; }
+        __syncthreads();
+        for (int i = 2; i <= LAP_FSI_DEG; ++i) {
+            const double sigma2 = 1.0 / (2.0 / sigma1 - sigma);
+            const double f1 = 2.0 * sigma2 / e, f2 = sigma * sigma2;
+            for (int idx = tid; idx < total; idx += 1024) Ng[idx] = (lx(idx) - c * Xl[idx]) * f1 - f2 * Yg[idx];
+            __syncthreads();
+            for (int idx = tid; idx < total; idx += 1024) { Yg[idx] = Xl[idx]; Xl[idx] = Ng[idx]; }
+            __syncthreads();
+            sigma = sigma2;
+        }
+        if (!orthonormalise()) return false;
+    }
+    if (!ok) return false;
+    // ---- the m lowest pairs -> Z[k][position] (the same LDS region: staged through global memory)
+    for (int idx = tid; idx < total; idx += 1024) Yg[idx] = Xl[idx];
+    __syncthreads();
+    for (int r = tid; r < m * sl; r += 1024) {
+        const int k = r / sl, i = r - k * sl;
+        Xl[r] = i < n ? Yg[i * PB + k] : 0.0;
+    }
+    __syncthreads();
+    return true;
+}
+
 template <int NQ>
 __global__ void __launch_bounds__(1024) lap_pe_kernel(double* __restrict__ Aall, const int* __restrict__ esrc, const int* __restrict__ edst,
                                                       const int* __restrict__ eptr, const int* __restrict__ nnodes,
                                                       const int* __restrict__ first, double* __restrict__ work, float* __restrict__ out,
-                                                      int ld, int kout) {
+                                                      int ld, int kout, int fsi_min) {
     constexpr int NW = 16, KV = 9;                                 // wavefronts per workgroup; vectors computed (k + 1 <= 9)
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -4225,7 +4495,8 @@ __global__ void __launch_bounds__(1024) lap_pe_kernel(double* __restrict__ Aall,
     int* cbeg = cend + sl;                                         // [sl] first position of that component
     int* posof = cbeg + sl;                                        // [sl] atom -> position
     int* flag = posof + sl;                                        // [2]
-    double* dd = work + (long long)g * (3 + 4 * KV) * ld;          // diagonal
+    double* dd = work + (long long)g * LAP_WORK_PER_LD * ld;       // diagonal
+    double* work_fsi = dd + (long long)(3 + 4 * KV) * ld;          // [LAP_FSI_PER_LD * ld] scratch of the sparse route
     double* ee = dd + ld;                                          // off-diagonal
     double* bb = ee + ld;                                          // reflector factors
     double* lu = bb + ld;                                          // [KV][4][ld] scratch of the tridiagonal solves
@@ -4323,6 +4594,35 @@ __global__ void __launch_bounds__(1024) lap_pe_kernel(double* __restrict__ Aall,
     }
     __syncthreads();
 
+    const int m = n < KV ? n : KV;          // eigenpairs computed (the smallest + up to kout more)
+    double* Z = pw;                         // [KV][sl] the vectors, by POSITION (both routes leave them here)
+
+    // ---- 1b. graphs with a LARGE component: Chebyshev-filtered subspace iteration on the SPARSE Laplacian instead of the dense
+    // O(n^3) tridiagonalisation below (a bonded molecular graph has ~10 neighbours per atom: one product with the Laplacian is
+    // ~10 n multiply-adds instead of n^2).  Whole graph at once (all components); a block of PB = 16 vectors, so eigenvalues of
+    // multiplicity up to 16 - the zero eigenvalue of a many-component graph, symmetric fragments - come out as a basis of their
+    // subspace, as from the dense route.  Per outer iteration: Rayleigh-Ritz on the block (16 x 16 Jacobi), residuals of the
+    // lowest m pairs, then a degree-FSI_DEG Chebyshev polynomial of L that damps [theta_15, 2] and amplifies what lies below,
+    // then CholQR2.  Anything that does not go by the book - a row with more than ELLW neighbours, a Cholesky pivot that
+    // vanishes, no convergence in FSI_MAXIT iterations - returns false and the dense route runs: never a wrong answer, at worst
+    // a slow one.
+    bool fsi_ok = false;
+    {
+        int big = tid < n ? cend[tid] - cbeg[tid] + 1 : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) big = max(big, __shfl_xor(big, o, 64));
+        __syncthreads();
+        if (tid == 0) flag[0] = 0;
+        __syncthreads();
+        if (lane == 0) atomicMax(&flag[0], big);
+        __syncthreads();
+        big = flag[0];
+        __syncthreads();
+        // (the iteration's small matrices live in the first 4 sl doubles of LDS: 1,064 are needed)
+        if (big >= fsi_min && n > 2 * 16 && 4 * sl >= 1064) fsi_ok = lap_fsi<NW, KV>(A, ld, n, sl, perm, cbeg, cend, label, flag, pw, sm, work_fsi, m, tid, lane, wave);
+        __syncthreads();
+    }
+    if (!fsi_ok) {
     // ---- 2. tridiagonalisation, component by component (positions cs .. ce; nend = ce + 1)
     // reflector from row `row` (positions row + 1 .. nend - 1) -> vec[] (other entries of the component zero)
     auto reflector = [&](int row, int nend, double* vec) {
@@ -4449,7 +4749,6 @@ __global__ void __launch_bounds__(1024) lap_pe_kernel(double* __restrict__ Aall,
         cs = nend;
     }
     // ---- 3. eigenvalues 0 .. m - 1 of the tridiagonal matrix (d, e): multi-section on the Sturm count
-    const int m = n < KV ? n : KV;
     double* td = va;                       // diagonal and squared off-diagonal in LDS
     double* te2 = wa;
     double* lam = wb;                      // [KV]
@@ -4528,7 +4827,7 @@ __global__ void __launch_bounds__(1024) lap_pe_kernel(double* __restrict__ Aall,
         __syncthreads();
     }
     const double eps = 2.220446049250313e-16, tiny = eps * (tnorm > 0.0 ? tnorm : 1.0);
-    double* Z = pw;                         // [KV][sl] (the eigenvalue intervals / counts kept there are dead now)
+    // (Z = pw: the eigenvalue intervals / counts kept there are dead now)
     if (tid < m) vb[tid] = lam[tid];         // shifts; separated inside clusters below (LAPACK dstein does the same)
     __syncthreads();
     if (tid == 0) {
@@ -4627,6 +4926,7 @@ __global__ void __launch_bounds__(1024) lap_pe_kernel(double* __restrict__ Aall,
             for (int r = j + 1 + lane; r <= hi; r += 64) x[r] -= s * v[perm[r]];
         }
     }
+    }   // (dense route)
     __syncthreads();
     // sign convention + output: columns 1 .. kout of the spectrum (the smallest eigenvalue's vector is dropped)
     float* o = out + (long long)first[g] * kout;
@@ -5478,7 +5778,20 @@ int singa_rowdot_bwd(const float* g, const float* x, const float* b, float* gx, 
     return check_launch("rowdot_bwd");
 }
 
-int singa_lap_pe_work(int B, int ld) { return (B < 0 || ld < 0) ? 0 : B * (3 + 4 * 9) * ld; }
+static int g_lap_fsi_min = 384;      // components of at least this many atoms take the sparse route (lab switch: singa_lap_pe_fsi_min)
+int singa_lap_pe_fsi_min(int n) {
+    if (n < 0) return fail(SINGA_E_SHAPE, "lap_pe_fsi_min: >= 0 (a value above 896 switches the sparse route off)");
+    g_lap_fsi_min = n;
+    return SINGA_OK;
+}
+
+int singa_lap_pe_work(int B, int ld) {
+#ifdef SINGA_EMUL
+    return (B < 0 || ld < 0) ? 0 : B * (3 + 4 * 9) * ld;
+#else
+    return (B < 0 || ld < 0) ? 0 : B * LAP_WORK_PER_LD * ld;
+#endif
+}
 
 int singa_lap_pe(double* A, const int32_t* esrc, const int32_t* edst, const int32_t* eptr, const int32_t* nnodes, const int32_t* first,
                  double* work, float* out, int B, int ld, int kout, void* stream) {
@@ -5496,11 +5809,11 @@ int singa_lap_pe(double* A, const int32_t* esrc, const int32_t* edst, const int3
     if (ld <= 512) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_pe_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail((int)e, "lap_pe: LDS size refused");
-        hipLaunchKernelGGL(lap_pe_kernel<8>, dim3(B), dim3(1024), lds, st, A, esrc, edst, eptr, nnodes, first, work, out, ld, kout);
+        hipLaunchKernelGGL(lap_pe_kernel<8>, dim3(B), dim3(1024), lds, st, A, esrc, edst, eptr, nnodes, first, work, out, ld, kout, g_lap_fsi_min);
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(lap_pe_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return fail((int)e, "lap_pe: LDS size refused");
-        hipLaunchKernelGGL(lap_pe_kernel<16>, dim3(B), dim3(1024), lds, st, A, esrc, edst, eptr, nnodes, first, work, out, ld, kout);
+        hipLaunchKernelGGL(lap_pe_kernel<16>, dim3(B), dim3(1024), lds, st, A, esrc, edst, eptr, nnodes, first, work, out, ld, kout, g_lap_fsi_min);
     }
     return check_launch("lap_pe");
 #endif

@@ -657,7 +657,13 @@ def test_lap_eig_batched_against_numpy():
     # big = 800: the kernel's two-pass register layout; big = 1000: above the kernel's 896-atom limit, i.e. the dense fp64
     # route of graph.laplacian_pe_batched (one batched torch.linalg.eigh on the device, padding rows sorted last) - a host-side
     # graph utility for molecules larger than anything BASELINE.json's configurations hold (config 5: 800 + 40 atoms)
-    for big in (0, 800, 1000):
+    from singa_amd import _lib
+    for big in (0, 800, 1000, -800, -1):
+        # big < 0: the same cases with the SPARSE route (Chebyshev-filtered subspace iteration, taken by default for components of
+        # >= 384 atoms) forced on every graph of more than 32 atoms: the clustered spectrum of the 300-atom path, the 30-fold zero
+        # eigenvalue (more than the block holds: the route gives up and the dense one answers), interleaved components
+        _lib.lib().singa_lap_pe_fsi_min(1 if big < 0 else 384)
+        big = 0 if big == -1 else abs(big)
         gs = list(graphs)
         if big:
             n = big
@@ -688,6 +694,7 @@ def test_lap_eig_batched_against_numpy():
             assert np.abs(lap @ v - v @ ritz).max() < 2e-6, n
             assert np.abs(np.linalg.eigvalsh(ritz) - w[1:kk + 1]).max() < 2e-6, n
             assert (v.max(0) >= (-v).max(0) - 1e-6).all()
+    _lib.lib().singa_lap_pe_fsi_min(384)
 
 
 @pytest.mark.parametrize("M", [1, 37, 26000])
