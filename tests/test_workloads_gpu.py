@@ -94,13 +94,16 @@ def test_cfg5_l6_b8_loss_matches_oracle():
     assert abs(float(loss) - float(loss_o)) < 1e-4 * abs(float(loss_o)), (float(loss), float(loss_o))
 
 
-def test_laplacian_pe_batched_on_gpu_against_oracle_spectrum():
+@pytest.mark.parametrize("workload", ["cfg3_b128_l4", "cfg5_l6"])
+def test_laplacian_pe_batched_on_gpu_against_oracle_spectrum(workload):
     """graph.laplacian_pe_batched (batched symmetric eigensolve on the GPU, what SINGA.prepare uses when a batch carries
     no encoding) per graph: orthonormal columns, an invariant subspace of the oracle's Laplacian, Ritz values =
-    eigenvalues 1..8, fixed sign convention.  Ragged batch (config-3 generator) so that the padding path is exercised."""
+    eigenvalues 1..8, fixed sign convention.  Ragged batch (config-3 generator: dozens of small components per pocket, the
+    dense route of singa_lap_pe) and config-5 graphs (one 800-atom component: the sparse route, Chebyshev-filtered subspace
+    iteration)."""
     from singa_amd import graph as G
-    kw = {k: v for k, v in G.WORKLOADS["cfg3_b128_l4"].items() if k not in ("n_graphs", "lmax")}
-    graphs = [G.synthetic_graph(i, **G.graph_sizes(i, **kw)) for i in (11, 12, 13)]
+    kw = {k: v for k, v in G.WORKLOADS[workload].items() if k not in ("n_graphs", "lmax")}
+    graphs = [G.synthetic_graph(i, with_lap=False, **G.graph_sizes(i, **kw)) for i in (11, 12, 13)]
     b = G.collate(graphs).to(DEV)
     for nt, et in ((G.PA, G.E_PP), (G.LA, G.E_LL)):
         pe = G.laplacian_pe_batched(b[et]["edge_index"], b[nt]["batch"], 3).cpu().double().numpy()
