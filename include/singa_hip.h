@@ -274,6 +274,10 @@ int singa_so3_rmsnorm_fwd(const float* x, const float* weight, const float* bias
 int singa_so3_rmsnorm_nparts(int N);
 int singa_so3_rmsnorm_bwd(const float* x, const float* weight, const float* gy, float* gx, float* gw_part,
                           float* gb_part, int N, int C, int lmax, float eps, void* stream);
+/* the same with gx = (norm's input gradient) + g_add: the gradient of the residual branch that leaves the norm's input
+ * (x + f(norm(x)), EF:1383-1384, 1405-1406) is added here instead of by a separate pass over both tensors */
+int singa_so3_rmsnorm_bwd_add(const float* x, const float* weight, const float* gy, const float* g_add, float* gx, float* gw_part,
+                              float* gb_part, int N, int C, int lmax, float eps, void* stream);
 
 /* Column sums out[n] = sum_i x[i*ld + j] (bias and broadcast gradients; replaces torch's multi-block `sum(0)`, which
  * is not replay-safe on this ROCm build).  work: singa_colsum_work(M, n) floats. */

@@ -60,6 +60,7 @@ _SIGS = {
     "singa_so3_rmsnorm_nparts": ([I32], I32),
     "singa_so3_rmsnorm_fwd": ([P, P, P, P, I32, I32, I32, F32, P], I32),
     "singa_so3_rmsnorm_bwd": ([P, P, P, P, P, P, I32, I32, I32, F32, P], I32),
+    "singa_so3_rmsnorm_bwd_add": ([P, P, P, P, P, P, P, I32, I32, I32, F32, P], I32),
     "singa_edge_logits_fwd": ([P] * 7 + [I32, I32, I32, F32, P], I32),
     "singa_edge_logits_bwd": ([P] * 13 + [I32, I32, I32, F32, P], I32),
     "singa_gather_wsum_fwd": ([P] * 6 + [I32, I32, I32, P], I32),

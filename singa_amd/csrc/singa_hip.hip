@@ -3578,9 +3578,12 @@ __global__ void __launch_bounds__(64) rmsnorm_fwd_kernel(const float* __restrict
 
 // gx~ = r w g - r^3 S b_k x~ / C  with S = sum(g w x~);  row 0 then loses its channel mean (centering).
 // Per-wave partial parameter grads: gw_part[part, k, c] += g x~ r,  gb_part[part, c] += g[0, c].
-template <int L>
+// ADD: gx += g_add - the gradient of the block's residual branch, which leaves the same tensor (x + f(norm(x)), EF:1383-1384,
+// 1405-1406), arrives here instead of in a separate add launch over both [N, K, C] tensors.
+template <int L, bool ADD>
 __global__ void __launch_bounds__(64) rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ weight,
-                                                         const float* __restrict__ gy, float* __restrict__ gx,
+                                                         const float* __restrict__ gy, const float* __restrict__ g_add,
+                                                         float* __restrict__ gx,
                                                          float* __restrict__ gw_part, float* __restrict__ gb_part, int N,
                                                          float eps) {
     constexpr int C = 16, K = (L + 1) * (L + 1), KC = K * C, NT = (KC + 63) / 64;
@@ -3592,7 +3595,7 @@ __global__ void __launch_bounds__(64) rmsnorm_bwd_kernel(const float* __restrict
     // the rows of the wavefront's NEXT node travel while this node's three wave reductions run (a node is a chain load ->
     // reduce -> reduce -> store: un-pipelined, 2,048 wavefronts moved 2.3 TB/s); every load is issued - from a clamped
     // index - and the padding lanes are zeroed by a select, not by a branch around the load
-    float vn[NT], gn[NT];
+    float vn[NT], gn[NT], an[ADD ? NT : 1];
     auto fetch = [&](int n) __attribute__((always_inline)) {
         const float* xi = x + (long long)n * KC;
         const float* gi = gy + (long long)n * KC;
@@ -3601,16 +3604,18 @@ __global__ void __launch_bounds__(64) rmsnorm_bwd_kernel(const float* __restrict
             const int idx = lane + 64 * t, ic = idx < KC ? idx : KC - 1;
             vn[t] = xi[ic];
             gn[t] = gi[ic];
+            if constexpr (ADD) an[t] = g_add[(long long)n * KC + ic];
         }
     };
     if ((int)blockIdx.x < N) fetch(blockIdx.x);
     for (int n = blockIdx.x; n < N; n += gridDim.x) {
-        float v[NT], g[NT];
+        float v[NT], g[NT], ad[ADD ? NT : 1];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int idx = lane + 64 * t;
             v[t] = idx < KC ? vn[t] : 0.f;
             g[t] = idx < KC ? gn[t] : 0.f;
+            if constexpr (ADD) ad[t] = an[t];
         }
         {
             const int nn = n + (int)gridDim.x;
@@ -3655,7 +3660,7 @@ __global__ void __launch_bounds__(64) rmsnorm_bwd_kernel(const float* __restrict
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             int idx = lane + 64 * t;
-            if (idx < KC) go[idx] = g[t];
+            if (idx < KC) go[idx] = ADD ? g[t] + ad[t] : g[t];
         }
     }
     // the affine weight is per DEGREE (EF:2114: affine_weight [L + 1, C], expanded over the 2l + 1 rows): the rows of a degree
@@ -6308,9 +6313,19 @@ int singa_so3_rmsnorm_bwd(const float* x, const float* weight, const float* gy, 
     if (!x || !weight || !gy || !gx || !gw_part || !gb_part) return fail(SINGA_E_NULL, "so3_rmsnorm_bwd: null pointer");
     if (C != 16) return fail(SINGA_E_SHAPE, "so3_rmsnorm: built for C = 16 sphere channels");
     if (N <= 0) return SINGA_OK;
-    SINGA_DISPATCH_L(lmax, 2, hipLaunchKernelGGL((rmsnorm_bwd_kernel<L_>), dim3(singa_so3_rmsnorm_nparts(N)), dim3(64),
-                                                 0, (hipStream_t)stream, x, weight, gy, gx, gw_part, gb_part, N, eps));
+    SINGA_DISPATCH_L(lmax, 2, hipLaunchKernelGGL((rmsnorm_bwd_kernel<L_, false>), dim3(singa_so3_rmsnorm_nparts(N)), dim3(64),
+                                                 0, (hipStream_t)stream, x, weight, gy, (const float*)nullptr, gx, gw_part, gb_part, N, eps));
     return check_launch("so3_rmsnorm_bwd");
+}
+
+int singa_so3_rmsnorm_bwd_add(const float* x, const float* weight, const float* gy, const float* g_add, float* gx, float* gw_part,
+                              float* gb_part, int N, int C, int lmax, float eps, void* stream) {
+    if (!x || !weight || !gy || !g_add || !gx || !gw_part || !gb_part) return fail(SINGA_E_NULL, "so3_rmsnorm_bwd_add: null pointer");
+    if (C != 16) return fail(SINGA_E_SHAPE, "so3_rmsnorm: built for C = 16 sphere channels");
+    if (N <= 0) return SINGA_OK;
+    SINGA_DISPATCH_L(lmax, 2, hipLaunchKernelGGL((rmsnorm_bwd_kernel<L_, true>), dim3(singa_so3_rmsnorm_nparts(N)), dim3(64),
+                                                 0, (hipStream_t)stream, x, weight, gy, g_add, gx, gw_part, gb_part, N, eps));
+    return check_launch("so3_rmsnorm_bwd_add");
 }
 
 }  // extern "C"

@@ -218,6 +218,11 @@ class EquivariantRMSNormArraySphericalHarmonicsV2(nn.Module):
     def forward(self, node_input: Tensor) -> Tensor:
         return ops.so3_rmsnorm(node_input, self.affine_weight, self.affine_bias, self.lmax, self.eps)
 
+    def forward_skip(self, node_input: Tensor):
+        """-> (norm(x), x) with both uses of x in one autograd node (the residual branch of a TransBlockV2): the backward
+        kernel adds the residual's gradient itself."""
+        return ops.so3_rmsnorm_skip(node_input, self.affine_weight, self.affine_bias, self.lmax, self.eps)
+
 
 def get_normalization_layer(norm_type, lmax, num_channels, eps: float = 1e-5, affine: bool = True,
                             normalization: str = "component", device: str = "cuda"):
@@ -479,6 +484,14 @@ class TransBlockV2(nn.Module):
         x[source].embedding = self.norm_1(x[source].embedding)
         x[target].embedding = self.norm_1(x[target].embedding)
 
+    def renorm_with_residual(self, x: Dict, source_target: Tuple[str, str]) -> Tensor:
+        """renorm_only for a layer whose output IS used: returns the target's embedding from before the norm (the block's
+        residual, EF:1356) tied to the norm in one autograd node."""
+        source, target = source_target
+        x[source].embedding = self.norm_1(x[source].embedding)
+        x[target].embedding, x_res = self.norm_1.forward_skip(x[target].embedding)
+        return x_res
+
     def forward(self, x: Union[SO3_Embedding, Dict], atomic_numbers: Union[Tensor, Dict], edge_distance: Tensor,
                 edge_index: Tensor, batch: int, hetero: bool, source_target: Optional[Tuple[str, str]] = None,
                 renormed_residual: Optional[Tensor] = None):
@@ -487,18 +500,16 @@ class TransBlockV2(nn.Module):
         if isinstance(x, dict):
             assert hetero and source_target is not None
             if renormed_residual is None:
-                x_res = x[source_target[1]].embedding
-                self.renorm_only(x, source_target)
+                x_res = self.renorm_with_residual(x, source_target)
             else:
                 x_res = renormed_residual
             out = self.ga(x, atomic_numbers, edge_distance, edge_index, hetero, source_target, residual=x_res)
         else:
-            x_res = x.embedding
-            x.embedding = self.norm_1(x.embedding)
+            x.embedding, x_res = self.norm_1.forward_skip(x.embedding)
             out = self.ga(x, atomic_numbers, edge_distance, edge_index, hetero, residual=x_res)
-        # (both residual sums of the block ride in the epilogue of the SO3 linear in front of them)
-        x_res = out.embedding
-        out.embedding = self.norm_2(out.embedding)
+        # (both residual sums of the block ride in the epilogue of the SO3 linear in front of them, and their gradients in
+        # the backward kernel of the norm they bypass: forward_skip)
+        out.embedding, x_res = self.norm_2.forward_skip(out.embedding)
         return self.ffn(out, residual=x_res)
 
 

@@ -141,8 +141,7 @@ class EquivariantEmbedding(nn.Module):
             for i in range(self.num_layers - 1):
                 self.blocks[i].renorm_only(x_dict, (source, target))
             last = self.blocks[self.num_layers - 1]
-            x_res = x_dict[target].embedding
-            last.renorm_only(x_dict, (source, target))
+            x_res = last.renorm_with_residual(x_dict, (source, target))
             mk = lambda t: SO3_Embedding(0, self.lmax_list, self.sphere_channels, torch.float32, self.device, t)
             view = {source: mk(x_dict[source].embedding), target: mk(x_dict[target].embedding)}   # what the last layer reads
 

@@ -616,6 +616,55 @@ def so3_rmsnorm(x, weight, bias, L, eps=1e-5):
     return _SO3RMSNorm.apply(x, weight, bias, L, eps)
 
 
+class _SO3RMSNormSkip(torch.autograd.Function):
+    """(norm(x), x): the norm together with the residual branch that leaves its input (x + f(norm(x)) of a TransBlockV2,
+    EF:1383-1384, 1405-1406).  One autograd node for both uses of x, so that the backward kernel adds the residual's gradient
+    to the norm's input gradient itself (singa_so3_rmsnorm_bwd_add) instead of autograd adding two [N, K, C] tensors afterwards."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, L, eps):
+        ctx.params = (weight, bias)
+        xc, weight, bias = x.contiguous(), weight.contiguous(), bias.contiguous()
+        _dev(xc, weight, bias)
+        N, K, C = xc.shape
+        y = torch.empty_like(xc)
+        _chk(_lib.lib().singa_so3_rmsnorm_fwd(_p(xc), _p(weight), _p(bias), _p(y), N, C, L, eps, _stream()),
+             "singa_so3_rmsnorm_fwd")
+        ctx.save_for_backward(xc, weight)
+        ctx.L, ctx.eps = L, eps
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, gy, gskip):
+        x, weight = ctx.saved_tensors
+        L, eps = ctx.L, ctx.eps
+        N, K, C = x.shape
+        lib = _lib.lib()
+        if gy is None:                                  # (the norm's output unused: only the skip carries a gradient)
+            return gskip, None, None, None, None
+        gy = gy.contiguous()
+        nparts = lib.singa_so3_rmsnorm_nparts(N)
+        gx = torch.empty_like(x)
+        gwp = torch.empty(nparts, (L + 1) * C, device=x.device, dtype=torch.float32)
+        gbp = torch.empty(nparts, C, device=x.device, dtype=torch.float32)
+        if gskip is not None:
+            gskip = gskip.contiguous()
+            _chk(lib.singa_so3_rmsnorm_bwd_add(_p(x), _p(weight), _p(gy), _p(gskip), _p(gx), _p(gwp), _p(gbp), N, C, L, eps,
+                                               _stream()), "singa_so3_rmsnorm_bwd_add")
+        else:
+            _chk(lib.singa_so3_rmsnorm_bwd(_p(x), _p(weight), _p(gy), _p(gx), _p(gwp), _p(gbp), N, C, L, eps, _stream()),
+                 "singa_so3_rmsnorm_bwd")
+        gw = param_colsum(gwp, [(0, (L + 1) * C, ctx.params[0])])[0]
+        if gw is not None:
+            gw = gw.view(L + 1, C)
+        return gx, gw, param_colsum(gbp, [(0, C, ctx.params[1])])[0], None, None
+
+
+def so3_rmsnorm_skip(x, weight, bias, L, eps=1e-5):
+    """-> (norm(x), x) as ONE autograd node: see _SO3RMSNormSkip."""
+    return _SO3RMSNormSkip.apply(x, weight, bias, L, eps)
+
+
 # ----------------------------------------------------------------------------------------------- fused graph attention
 class _EdgeLogits(torch.autograd.Function):
     @staticmethod

@@ -338,6 +338,18 @@ def test_so3_rmsnorm(L):
     assert rel(y, ref) < 1e-5
     y.backward(g.to(DEV))
     assert rel(xg.grad, x.grad) < 2e-5
+    # the norm with the residual branch that leaves its input as ONE autograd node (x + f(norm(x)) of a TransBlockV2): the
+    # backward kernel adds the skip's gradient itself
+    g2 = torch.tensor(rs.randn(N, K, C), dtype=torch.float32)
+    xs, ws, bs = (t.detach().to(DEV).requires_grad_(True) for t in (x, w, b))
+    y2, skip = ops.so3_rmsnorm_skip(xs, ws, bs, L)
+    assert torch.equal(y2, y) and torch.equal(skip, xs)
+    torch.autograd.backward([y2, skip], [g.to(DEV), g2.to(DEV)])
+    assert rel(xs.grad, x.grad + g2) < 2e-5 and rel(ws.grad, wg.grad) < 1e-6 and rel(bs.grad, bg.grad) < 1e-6
+    xs.grad = None
+    y3, skip3 = ops.so3_rmsnorm_skip(xs, ws, bs, L)
+    skip3.backward(g2.to(DEV))                       # only the skip used
+    assert torch.equal(xs.grad, g2.to(DEV))
     assert rel(wg.grad, w.grad) < 2e-5 and rel(bg.grad, b.grad) < 2e-5
     # identity property: affine = identity -> balanced RMS of the output is 1
     y1 = ops.so3_rmsnorm(xg.detach(), torch.ones_like(wg), torch.zeros_like(bg), L).cpu()
