@@ -3509,180 +3509,130 @@ static int so3_skinny_reduce_runs(int lmax) {
 static inline bool so3_skinny_channels_ok(int C) { return C == 512 || C == 112; }
 
 // ------------------------------------------------------------------------------------------------ k12: equivariant RMS norm
-__device__ __forceinline__ float wave_sum(float v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// FOUR nodes per wavefront, C = 16: lane group q = lane >> 4 owns node 4 w + q, lane & 15 = channel; a lane holds its channel's K
+// coefficient rows in registers (K independent loads in flight), the degree of a row is a compile-time constant of the
+// unrolled loop, the sums over a node are K serial FMAs per lane + a 16-lane butterfly, and the per-wave partial parameter
+// gradients are per-lane registers folded over the four groups at the end.  (Rounds 1-3: one node per wavefront, element idx =
+// lane + 64 t with idx / C and a degree search per element at run time, 7 loads in flight, two 64-lane reductions per node and an
+// LDS round trip for the per-degree sums: 68 / 91 us per launch on the 79 MB node tensors of config 3 = 2.3 / 2.6 TB/s.)
+// forward:  x~ = x with its l = 0 row centred over the channels; r = (mean_c sum_k b_k x~^2 + eps)^-1/2, b_k = 1 / ((2l+1)(L+1));
+//           y = x~ r w[l][c] (+ bias[c] on the l = 0 row)                                                   (EF:2155-2192, Q3)
+// backward: gx~ = r w g - r^3 S b_k x~ / C with S = sum(g w x~); the l = 0 row then loses its channel mean (centering); ADD: + g_add,
+//           the gradient of the residual branch that bypasses the norm.  Per-wave partials gw_part[wave][l][c] = sum g x~ r,
+//           gb_part[wave][c] = sum g[0][c].
+__device__ __forceinline__ float group16_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
     return v;
 }
-
-__device__ __forceinline__ int degree_of(int k) {
+__host__ __device__ constexpr int deg_of_c(int k) {
     int l = 0;
     while ((l + 1) * (l + 1) <= k) ++l;
     return l;
 }
+__host__ __device__ constexpr float bal_of_c(int k, int L) { return 1.0f / (float)((2 * deg_of_c(k) + 1) * (L + 1)); }
 
-// One wavefront per node (grid-stride), C = 16.  Elements idx = lane + 64 t  ->  (k = idx / C, c = idx % C).
 template <int L>
-__global__ void __launch_bounds__(64) rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ weight,
-                                                         const float* __restrict__ bias, float* __restrict__ y, int N,
-                                                         float eps) {
-    constexpr int C = 16, K = (L + 1) * (L + 1), KC = K * C, NT = (KC + 63) / 64;
-    const int lane = threadIdx.x;
-    float vn[NT];                                          // the next node's row, loaded while this one is reduced (see the backward kernel)
-    auto fetch = [&](int n) __attribute__((always_inline)) {
-        const float* xi = x + (long long)n * KC;
+__global__ void __launch_bounds__(64) rmsnorm_fwd4_kernel(const float* __restrict__ x, const float* __restrict__ weight,
+                                                          const float* __restrict__ bias, float* __restrict__ y, int N, float eps) {
+    constexpr int C = 16, K = (L + 1) * (L + 1), KC = K * C;
+    const int lane = threadIdx.x, q = lane >> 4, c = lane & 15;
+    float w[L + 1];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int idx = lane + 64 * t;
-            vn[t] = xi[idx < KC ? idx : KC - 1];
-        }
-    };
-    if ((int)blockIdx.x < N) fetch(blockIdx.x);
-    for (int n = blockIdx.x; n < N; n += gridDim.x) {
-        float v[NT];
-        float s0 = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int idx = lane + 64 * t;
-            v[t] = idx < KC ? vn[t] : 0.f;
-        }
-        {
-            const int nn = n + (int)gridDim.x;
-            fetch(nn < N ? nn : n);
-        }
-        if (lane < C) s0 = v[0];
-        float mean0 = wave_sum(s0) * (1.0f / C);
-        if (lane < C) v[0] -= mean0;
+    for (int l = 0; l <= L; ++l) w[l] = weight[l * C + c];
+    const float bc = bias[c];
+    for (int n0 = 4 * (int)blockIdx.x; n0 < N; n0 += 4 * (int)gridDim.x) {
+        const int n = n0 + q;
+        const bool ok = n < N;
+        const float* xi = x + (long long)(ok ? n : N - 1) * KC + c;
+        float v[K];
+#pragma clang loop unroll(full)
+        for (int k = 0; k < K; ++k) v[k] = xi[k * C];
+        v[0] -= group16_sum(v[0]) * (1.0f / C);
         float ss = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            int idx = lane + 64 * t;
-            if (idx < KC) {
-                int l = degree_of(idx / C);
-                ss = fmaf(v[t] * v[t], 1.0f / (float)((2 * l + 1) * (L + 1)), ss);
-            }
-        }
-        float r = rsqrtf(wave_sum(ss) * (1.0f / C) + eps);
-        float* yo = y + (long long)n * KC;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            int idx = lane + 64 * t;
-            if (idx < KC) {
-                int k = idx / C, c = idx - k * C;
-                float o = v[t] * r * weight[degree_of(k) * C + c];
-                if (k == 0) o += bias[c];
-                yo[idx] = o;
+#pragma clang loop unroll(full)
+        for (int k = 0; k < K; ++k) ss = fmaf(v[k] * v[k], bal_of_c(k, L), ss);
+        const float r = rsqrtf(group16_sum(ss) * (1.0f / C) + eps);
+        if (ok) {
+            float* yo = y + (long long)n * KC + c;
+#pragma clang loop unroll(full)
+            for (int k = 0; k < K; ++k) {
+                const float rw = r * w[deg_of_c(k)];
+                yo[k * C] = k == 0 ? fmaf(v[k], rw, bc) : v[k] * rw;
             }
         }
     }
 }
 
-// gx~ = r w g - r^3 S b_k x~ / C  with S = sum(g w x~);  row 0 then loses its channel mean (centering).
-// Per-wave partial parameter grads: gw_part[part, k, c] += g x~ r,  gb_part[part, c] += g[0, c].
-// ADD: gx += g_add - the gradient of the block's residual branch, which leaves the same tensor (x + f(norm(x)), EF:1383-1384,
-// 1405-1406), arrives here instead of in a separate add launch over both [N, K, C] tensors.
 template <int L, bool ADD>
-__global__ void __launch_bounds__(64) rmsnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ weight,
-                                                         const float* __restrict__ gy, const float* __restrict__ g_add,
-                                                         float* __restrict__ gx,
-                                                         float* __restrict__ gw_part, float* __restrict__ gb_part, int N,
-                                                         float eps) {
-    constexpr int C = 16, K = (L + 1) * (L + 1), KC = K * C, NT = (KC + 63) / 64;
-    const int lane = threadIdx.x;
-    float gwp[NT];
+__global__ void __launch_bounds__(64) rmsnorm_bwd4_kernel(const float* __restrict__ x, const float* __restrict__ weight,
+                                                          const float* __restrict__ gy, const float* __restrict__ g_add,
+                                                          float* __restrict__ gx, float* __restrict__ gw_part,
+                                                          float* __restrict__ gb_part, int N, float eps) {
+    constexpr int C = 16, K = (L + 1) * (L + 1), KC = K * C;
+    const int lane = threadIdx.x, q = lane >> 4, c = lane & 15;
+    float w[L + 1], gwp[L + 1];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) gwp[t] = 0.f;
+    for (int l = 0; l <= L; ++l) { w[l] = weight[l * C + c]; gwp[l] = 0.f; }
     float gbp = 0.f;
-    // the rows of the wavefront's NEXT node travel while this node's three wave reductions run (a node is a chain load ->
-    // reduce -> reduce -> store: un-pipelined, 2,048 wavefronts moved 2.3 TB/s); every load is issued - from a clamped
-    // index - and the padding lanes are zeroed by a select, not by a branch around the load
-    float vn[NT], gn[NT], an[ADD ? NT : 1];
-    auto fetch = [&](int n) __attribute__((always_inline)) {
-        const float* xi = x + (long long)n * KC;
-        const float* gi = gy + (long long)n * KC;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int idx = lane + 64 * t, ic = idx < KC ? idx : KC - 1;
-            vn[t] = xi[ic];
-            gn[t] = gi[ic];
-            if constexpr (ADD) an[t] = g_add[(long long)n * KC + ic];
+    for (int n0 = 4 * (int)blockIdx.x; n0 < N; n0 += 4 * (int)gridDim.x) {
+        const int n = n0 + q;
+        const bool ok = n < N;
+        const long long base = (long long)(ok ? n : N - 1) * KC + c;
+        float v[K], g[K], ga[ADD ? K : 1];
+#pragma clang loop unroll(full)
+        for (int k = 0; k < K; ++k) {
+            v[k] = x[base + k * C];
+            g[k] = gy[base + k * C];
+            if constexpr (ADD) ga[k] = g_add[base + k * C];
         }
-    };
-    if ((int)blockIdx.x < N) fetch(blockIdx.x);
-    for (int n = blockIdx.x; n < N; n += gridDim.x) {
-        float v[NT], g[NT], ad[ADD ? NT : 1];
+        const float live = ok ? 1.f : 0.f;
+        v[0] -= group16_sum(v[0]) * (1.0f / C);
+        float ss = 0.f, gl[L + 1];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int idx = lane + 64 * t;
-            v[t] = idx < KC ? vn[t] : 0.f;
-            g[t] = idx < KC ? gn[t] : 0.f;
-            if constexpr (ADD) ad[t] = an[t];
+        for (int l = 0; l <= L; ++l) gl[l] = 0.f;
+#pragma clang loop unroll(full)
+        for (int k = 0; k < K; ++k) {
+            ss = fmaf(v[k] * v[k], bal_of_c(k, L), ss);
+            gl[deg_of_c(k)] = fmaf(g[k], v[k], gl[deg_of_c(k)]);      // sum of g x~ over the degree's rows
         }
-        {
-            const int nn = n + (int)gridDim.x;
-            fetch(nn < N ? nn : n);
-        }
-        float mean0 = wave_sum(lane < C ? v[0] : 0.f) * (1.0f / C);
-        if (lane < C) v[0] -= mean0;
-        float ss = 0.f, S = 0.f;
+        float S = 0.f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            int idx = lane + 64 * t;
-            if (idx < KC) {
-                int k = idx / C, c = idx - k * C;
-                int l = degree_of(k);
-                ss = fmaf(v[t] * v[t], 1.0f / (float)((2 * l + 1) * (L + 1)), ss);
-                S = fmaf(g[t] * weight[l * C + c], v[t], S);
+        for (int l = 0; l <= L; ++l) S = fmaf(gl[l], w[l], S);
+        gbp = fmaf(g[0], live, gbp);
+        const float r = rsqrtf(group16_sum(ss) * (1.0f / C) + eps);
+        S = group16_sum(S);
+        const float r3s = r * r * r * S * (1.0f / C);
+#pragma unroll
+        for (int l = 0; l <= L; ++l) gwp[l] = fmaf(gl[l] * live, r, gwp[l]);
+        float* go = gx + base;
+        float d0 = fmaf(r * w[0], g[0], -r3s * bal_of_c(0, L) * v[0]);
+        d0 -= group16_sum(d0) * (1.0f / C);
+        if (ok) {
+            go[0] = ADD ? d0 + ga[0] : d0;
+#pragma clang loop unroll(full)
+            for (int k = 1; k < K; ++k) {
+                const float d = fmaf(r * w[deg_of_c(k)], g[k], -r3s * bal_of_c(k, L) * v[k]);
+                go[k * C] = ADD ? d + ga[k] : d;
             }
         }
-        float r = rsqrtf(wave_sum(ss) * (1.0f / C) + eps);
-        S = wave_sum(S);
-        float r3s = r * r * r * S * (1.0f / C);
-        float d0 = 0.f;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            int idx = lane + 64 * t;
-            if (idx < KC) {
-                int k = idx / C, c = idx - k * C;
-                int l = degree_of(k);
-                float bk = 1.0f / (float)((2 * l + 1) * (L + 1));
-                gwp[t] = fmaf(g[t] * v[t], r, gwp[t]);
-                float d = r * weight[l * C + c] * g[t] - r3s * bk * v[t];
-                if (t == 0 && lane < C) {
-                    d0 = d;
-                    gbp += g[t];
-                }
-                g[t] = d;
-            }
-        }
-        float dm = wave_sum(lane < C ? d0 : 0.f) * (1.0f / C);
-        if (lane < C) g[0] -= dm;
-        float* go = gx + (long long)n * KC;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            int idx = lane + 64 * t;
-            if (idx < KC) go[idx] = ADD ? g[t] + ad[t] : g[t];
-        }
     }
-    // the affine weight is per DEGREE (EF:2114: affine_weight [L + 1, C], expanded over the 2l + 1 rows): the rows of a degree
-    // are added up here (one wavefront per workgroup: a wave barrier orders the LDS round trip), so that the partials are
-    // [nparts][(L + 1) * C] and go straight into the step's shared column-sum launch
-    __shared__ float sh[KC];
+    // fold the four lane groups' partials; one row of partials per wavefront
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        int idx = lane + 64 * t;
-        if (idx < KC) sh[idx] = gwp[t];
+    for (int l = 0; l <= L; ++l) {
+        gwp[l] += __shfl_xor(gwp[l], 16, 64);
+        gwp[l] += __shfl_xor(gwp[l], 32, 64);
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_s_waitcnt(0xC07F);                              // lgkmcnt(0): the LDS writes above have landed
-    __builtin_amdgcn_wave_barrier();
-    float* wp = gw_part + (long long)blockIdx.x * (L + 1) * C;
-    for (int idx = lane; idx < (L + 1) * C; idx += 64) {
-        const int l = idx / C, c = idx - l * C;
-        float acc = 0.f;
-        for (int k = l * l; k < (l + 1) * (l + 1); ++k) acc += sh[k * C + c];
-        wp[idx] = acc;
+    gbp += __shfl_xor(gbp, 16, 64);
+    gbp += __shfl_xor(gbp, 32, 64);
+    if (lane < C) {
+        float* wp = gw_part + (long long)blockIdx.x * (L + 1) * C;
+#pragma unroll
+        for (int l = 0; l <= L; ++l) wp[l * C + c] = gwp[l];
+        gb_part[(long long)blockIdx.x * C + c] = gbp;
     }
-    if (lane < C) gb_part[(long long)blockIdx.x * C + lane] = gbp;
 }
 
 
@@ -6296,14 +6246,14 @@ int singa_colsum_multi(int n_jobs, const float* const* x, const long long* ld, c
 
 // (one wavefront per partial row: 2,048 wavefronts = 2 per SIMD left the backward kernel - three dependent wave reductions per
 // node behind its loads - at 2.3 TB/s; the partial rows are only (L + 2) * 16 floats)
-int singa_so3_rmsnorm_nparts(int N) { return grid_for(N, 8192); }
+int singa_so3_rmsnorm_nparts(int N) { return grid_for((N + 3) / 4, 8192); }      // wavefronts of four nodes each
 
 int singa_so3_rmsnorm_fwd(const float* x, const float* weight, const float* bias, float* y, int N, int C, int lmax,
                           float eps, void* stream) {
     if (!x || !weight || !bias || !y) return fail(SINGA_E_NULL, "so3_rmsnorm_fwd: null pointer");
     if (C != 16) return fail(SINGA_E_SHAPE, "so3_rmsnorm: built for C = 16 sphere channels");
     if (N <= 0) return SINGA_OK;
-    SINGA_DISPATCH_L(lmax, 2, hipLaunchKernelGGL((rmsnorm_fwd_kernel<L_>), dim3(grid_for(N)), dim3(64), 0,
+    SINGA_DISPATCH_L(lmax, 2, hipLaunchKernelGGL((rmsnorm_fwd4_kernel<L_>), dim3(singa_so3_rmsnorm_nparts(N)), dim3(64), 0,
                                                  (hipStream_t)stream, x, weight, bias, y, N, eps));
     return check_launch("so3_rmsnorm_fwd");
 }
@@ -6313,7 +6263,7 @@ int singa_so3_rmsnorm_bwd(const float* x, const float* weight, const float* gy, 
     if (!x || !weight || !gy || !gx || !gw_part || !gb_part) return fail(SINGA_E_NULL, "so3_rmsnorm_bwd: null pointer");
     if (C != 16) return fail(SINGA_E_SHAPE, "so3_rmsnorm: built for C = 16 sphere channels");
     if (N <= 0) return SINGA_OK;
-    SINGA_DISPATCH_L(lmax, 2, hipLaunchKernelGGL((rmsnorm_bwd_kernel<L_, false>), dim3(singa_so3_rmsnorm_nparts(N)), dim3(64),
+    SINGA_DISPATCH_L(lmax, 2, hipLaunchKernelGGL((rmsnorm_bwd4_kernel<L_, false>), dim3(singa_so3_rmsnorm_nparts(N)), dim3(64),
                                                  0, (hipStream_t)stream, x, weight, gy, (const float*)nullptr, gx, gw_part, gb_part, N, eps));
     return check_launch("so3_rmsnorm_bwd");
 }
@@ -6323,7 +6273,7 @@ int singa_so3_rmsnorm_bwd_add(const float* x, const float* weight, const float* 
     if (!x || !weight || !gy || !g_add || !gx || !gw_part || !gb_part) return fail(SINGA_E_NULL, "so3_rmsnorm_bwd_add: null pointer");
     if (C != 16) return fail(SINGA_E_SHAPE, "so3_rmsnorm: built for C = 16 sphere channels");
     if (N <= 0) return SINGA_OK;
-    SINGA_DISPATCH_L(lmax, 2, hipLaunchKernelGGL((rmsnorm_bwd_kernel<L_, true>), dim3(singa_so3_rmsnorm_nparts(N)), dim3(64),
+    SINGA_DISPATCH_L(lmax, 2, hipLaunchKernelGGL((rmsnorm_bwd4_kernel<L_, true>), dim3(singa_so3_rmsnorm_nparts(N)), dim3(64),
                                                  0, (hipStream_t)stream, x, weight, gy, g_add, gx, gw_part, gb_part, N, eps));
     return check_launch("so3_rmsnorm_bwd_add");
 }
