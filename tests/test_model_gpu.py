@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import singa_oracle as O
-from tests.helpers import NAMES, golden, grad_sample_errors, product_batch, rel_err, state_from_spec
+from tests.helpers import NAMES, golden, grad_sample_errors, pinned_relu_ties, product_batch, rel_err, state_from_spec
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -90,11 +90,14 @@ def test_singa_step_matches_reference(L):
     assert not unexpected and all(("offset" in m) or m.endswith("pos_emb.pe") or "batch_norm" in m for m in missing), missing
     model.eval()
     g = product_batch(NAMES, z)
-    logits = model(g)
-    assert rel_err(logits.detach().cpu(), z["logits"]) < 1e-4
-    loss = torch.nn.functional.cross_entropy(logits, g["ligand_data"]["smiIndices_tgt"].reshape(-1))
-    assert abs(float(loss) - float(z["loss"])) < 1e-4 * float(z["loss"])
-    loss.backward()
+    with pinned_relu_ties(L) as pins:          # fp32 ties of the ReLU gates follow the reference's run (see the helper)
+        logits = model(g)
+        assert rel_err(logits.detach().cpu(), z["logits"]) < 1e-4
+        loss = torch.nn.functional.cross_entropy(logits, g["ligand_data"]["smiIndices_tgt"].reshape(-1))
+        assert abs(float(loss) - float(z["loss"])) < 1e-4 * float(z["loss"])
+        loss.backward()
+    assert pins.call == 18 and pins.flipped <= 16, (pins.call, pins.flipped)      # of 10.5 M gates; measured: 0 .. 3
+    print(f"L={L}: {pins.flipped} near-zero ReLU gates pinned to the reference's choice")
     tot = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
     assert abs(tot - float(z["grad_total"])) < 1e-4 * float(z["grad_total"])      # measured: 1e-6 .. 1e-5 (tools/lab/grad_err_probe.py)
     params = dict(model.named_parameters())
@@ -108,7 +111,9 @@ def test_singa_step_matches_reference(L):
             bad.append((str(n), None if gr is None else float(gr.norm()), float(ref)))
     assert not bad, bad[:8]
     # element-wise samples of every parameter's gradient against the reference's
-    bad = grad_sample_errors({n: p.grad for n, p in params.items()}, z, 3e-3)
+    errs = sorted(grad_sample_errors({n: p.grad for n, p in params.items()}, z, 0.0), key=lambda e: -e[1])
+    print(f"L={L}: worst element-wise gradient sample errors: " + ", ".join(f"{n} {e:.1e}" for n, e in errs[:3]))
+    bad = [e for e in errs if e[1] > 3e-3]
     assert not bad, bad[:8]
 
 
