@@ -102,6 +102,22 @@ def test_singa_step(L):
     assert not bad, bad[:10]
 
 
+@pytest.mark.parametrize("L", [2, 4, 6])
+def test_relu_tie_fixture_is_consistent(L):
+    """The recorded near-zero ReLU gates of the golden step (oracle/make_relu_ties.py): 18 PoswiseFeedForward calls with
+    the golden batch's token rows, indices in range, a few hundred entries, about half of them open."""
+    t = golden(f"singa_L{L}_B3_relu_ties.npz")
+    g = O.collate([O.load_graph_npz(f"tests/golden/graph_{n}.npz") for n in NAMES])
+    rows = [int(r) for r in t["rows"]]
+    n_p, n_l, B, T = g["x_p"].shape[0], g["x_l"].shape[0], *g["tok_tgt"].shape
+    # decoder rows: the property token in front of the tgt_len tokens of each graph (CP:371-420)
+    assert len(rows) == 18 and rows[:6] == [n_p] * 6 and rows[6:12] == [n_l] * 6 and rows[12:] == [B * (T + 1)] * 6
+    assert len(t["layer"]) == len(t["row"]) == len(t["unit"]) == len(t["on"])
+    assert 100 < len(t["layer"]) < 5000 and 0.3 < t["on"].mean() < 0.7
+    assert int(t["layer"].min()) >= 0 and int(t["layer"].max()) <= 17 and int(t["unit"].max()) < 1024
+    assert all(int(r) < rows[int(l)] for l, r in zip(t["layer"], t["row"]))
+
+
 @pytest.mark.parametrize("case", BEAM_CASES)
 def test_beam_search(case):
     """Restated beam search vs the reference's own (BeamSearch.py:38-175) on reference-embedded proteins: decoded
