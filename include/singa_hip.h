@@ -341,6 +341,31 @@ typedef struct {
 } singa_gemm_t;
 int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_contig, int splits, void* stream);
 
+/* k7c - the order-m > 0 blocks of an SO(2) convolution (reference model/EF_layers.py:677-729: `x = self.fc(x)` on the +m and -m
+ * rows, then out_r = x_r[:, 0] - x_i[:, 1], out_i = x_r[:, 1] + x_i[:, 0]) as COMPLEX products with three real multiplications
+ * instead of four (3M): for every problem
+ *     C_re(i, j) = sum_r a(i, r) c(r, j) - b(i, r) sigma d(r, j),    C_im(i, j) = sum_r a(i, r) sigma d(r, j) + b(i, r) c(r, j)
+ * where (a, b) are the real and imaginary part of the A operand, (c, d) of the B operand; the imaginary part of each operand
+ * and of the result lies a_im / b_im / c_im ELEMENTS behind the real part (same pitches).  Operand forms as singa_gemm_f32:
+ * (1, 1) forward (A = [x_+ | x_-] rows, a_im = K; B = fc.weight [2N, K], b_im = N * K; C = [out_r | out_i], c_im = N; sigma = +1),
+ * (1, 0) d input (A = [g_r | g_i], B = fc.weight as [r = n][j = k], sigma = -1, C = [dx_+ | dx_-]),
+ * (0, 0) d weight (A = [g_r | g_i] as [r = e][i = n], B = [x_+ | x_-] as [r = e][j = k], sigma = -1, C = d fc.weight [2N, K],
+ * c_im = N * K; splits > 1: dense partial slabs c_split_stride apart).  I, J, R count COMPLEX rows / columns / reduction
+ * indices.  Exact f32 products and accumulation; the three-product form rounds differently from the four-product one (a few
+ * 1e-7 of the operands' magnitudes). */
+#define SINGA_CGEMM_MAX 4
+typedef struct {
+    const float* a;
+    const float* b;
+    float* c;
+    int64_t lda, ldb, ldc;
+    int64_t a_im, b_im, c_im;
+    int64_t c_split_stride;
+    int I, J, R;
+    float sigma;
+} singa_cgemm_t;
+int singa_cgemm3m_f32(const singa_cgemm_t* probs, int n, int a_r_contig, int b_r_contig, int splits, void* stream);
+
 /* k11s - SO3_LinearV2 (model/EF_layers.py:655-671) between 16 and C = 512 channels (the feed-forward block, EF:232-262) or
  * C = 112 (the attention's output projection, EF:1201-1204; there only the backward maps 16 -> 112 channels), where
  * the contraction is only 16 long: VALU kernels, thread = one of the 512 channels, whole 2 KB rows of the big tensor per access.
@@ -418,6 +443,9 @@ int singa_prof_collect(float* ms, int* edges, int* nodes, int cap); /* after syn
 #define SINGA_PROF_S2_EDGE_BWD 11
 #define SINGA_PROF_S2_NODE_FWD 12   /* ... on the feed-forward grid (node rows, 512 channels) */
 #define SINGA_PROF_S2_NODE_BWD 13
+#define SINGA_PROF_CGEMM_NT 14    /* singa_cgemm3m_f32 (1,1): nodes field = number of 128 x 64 complex tiles */
+#define SINGA_PROF_CGEMM_NN 15
+#define SINGA_PROF_CGEMM_TN 16
 int singa_prof_collect_tagged(float* ms, int* tags, int* edges, int* nodes, int cap);
 /* Graph mode: per-dispatch timing INSIDE a replayed HIP graph.  (External event-record nodes are refused under stream capture by
  * this ROCm build, so:) while a stamp buffer is set, a one-thread kernel in front of and behind every tagged launch writes the

@@ -23,6 +23,21 @@ class Gemm(C.Structure):
                 ("addend", P), ("relu", C.c_int32), ("asum", P), ("asum_stride", I64)]
 
 
+class CGemm(C.Structure):
+    """singa_cgemm_t of include/singa_hip.h"""
+    _fields_ = [("a", P), ("b", P), ("c", P), ("lda", I64), ("ldb", I64), ("ldc", I64), ("a_im", I64), ("b_im", I64),
+                ("c_im", I64), ("c_split_stride", I64), ("I", C.c_int32), ("J", C.c_int32), ("R", C.c_int32),
+                ("sigma", C.c_float)]
+
+
+def cgemm_probs(items):
+    arr = (CGemm * len(items))()
+    for g, it in zip(arr, items):
+        for k, v in it.items():
+            setattr(g, k, v)
+    return arr, len(items)
+
+
 def gemm_probs(items):
     """items: list of dicts with the fields of singa_gemm_t (pointers as ints, missing fields 0) -> (ctypes array, n)"""
     arr = (Gemm * len(items))()
@@ -100,6 +115,7 @@ _SIGS = {
     "singa_adam_step": ([P, P, P, P, P, P, P, I32, I32, P, P, F32, F32, F32, P], I32),
     "singa_grad_norm": ([P, P, P, P, I32, I32, P, P, P], I32),
     "singa_gemm_f32": ([C.POINTER(Gemm), I32, I32, I32, I32, P], I32),
+    "singa_cgemm3m_f32": ([C.POINTER(CGemm), I32, I32, I32, I32, P], I32),
     "singa_knn_graph": ([P, P, P, I32, I32, I32, I32, P, P, P], I32),
     "singa_prof_enable": ([I32], I32),
     "singa_prof_hint_edges": ([I32], I32),

@@ -4064,6 +4064,273 @@ __global__ void __launch_bounds__(256, 2) gemm_f32_kernel(GemmBatch gb) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------ k7c: complex f32 MFMA GEMM (3M)
+// The order-m > 0 blocks of an SO(2) convolution (EF:677-729) are COMPLEX products: with x = x_+m + i x_-m and W = Wr + i Wi
+//     out_re = x_re Wr^T - x_im Wi^T,   out_im = x_re Wi^T + x_im Wr^T.
+// As one real GEMM on the block weight [[Wr, -Wi], [Wi, Wr]] (what k7 did) that is four real products; here three:
+//     P1 = (a + b) c,  P2 = a (d - c),  P3 = b (c + d):   re = P1 - P3,  im = P1 + P2        (a + i b)(c + i d)
+// - a quarter of the MFMA work of 80 % of the convolution's flops.  The forward pass, d input and d weight are the same product
+// with different operand forms (sigma = the sign on the B side's imaginary part):
+//     forward   (a, b) = x_re, x_im [E, K]      (c, d) = Wr, Wi [N, K]           sigma = +1      A RC, B RC
+//     d input   (a, b) = g_re, g_im [E, N]      (c, d) = Wr, Wi ([r = n][j = k])  sigma = -1      A RC, B OC
+//     d weight  (a, b) = g_re, g_im ([r = e][i = n])   (c, d) = x_re, x_im ([r = e][j = k])  sigma = -1   A OC, B OC, split over e
+// The imaginary part of every operand lies a fixed number of elements behind the real part (a_im, b_im, c_im).  Both parts of
+// both operands are staged in LDS as they are; the sums a + b, sigma d - c, c + sigma d are formed on the fragments in
+// registers (8 + 8 VALU operations per 24 MFMAs).  Workgroup = 256 threads = 2 x 2 wavefronts, tile 128 rows x 64 complex
+// columns, K step 16 (complex), three accumulator sets of 2 MFMA tiles (96 registers), LDS images / two-step register prefetch /
+// XCD-contiguous tile ranges / staged float4 epilogue as in k7.
+struct CGemmProb {
+    const float* A;
+    const float* B;
+    float* C;
+    long long lda, ldb, ldc, a_im, b_im, c_im, c_split;
+    int I, J, R, tiles_j, tile_begin;
+    float sigma;
+};
+struct CGemmBatch {
+    CGemmProb p[SINGA_CGEMM_MAX];
+    int n, tiles_total, splits, tj_total;
+    long long r_chunk;
+};
+
+template <bool A_RC, bool B_RC>
+__global__ void __launch_bounds__(256, 2) cgemm3m_f32_kernel(CGemmBatch gb) {
+    constexpr int BM = 128, BN = 64, BK = 16, PR = BK + 4, LDA = BM + 4, LDB = BN + 4;
+    constexpr int NA = 4, NB = 2;                                   // float4 loads per thread and K step (both parts)
+    constexpr int SZA1 = A_RC ? BM * PR : BK * LDA, SZB1 = B_RC ? BN * PR : BK * LDB;      // one part's image
+    constexpr int SZA = 2 * SZA1, SZB = 2 * SZB1;
+    constexpr int PE = 64 + 4;                                      // epilogue staging pitch: 32 real + 32 imaginary columns
+    constexpr int SMEM = 2 * SZA + 2 * SZB > 4 * 32 * PE ? 2 * SZA + 2 * SZB : 4 * 32 * PE;
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
+    float* const As0 = smem;
+    float* const Bs0 = smem + 2 * SZA;
+    const int nblk = gb.tiles_total * gb.splits;
+    const int per = (nblk + 7) >> 3;
+    const int id = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+    if (id >= nblk) return;
+    const int split = id / gb.tiles_total;
+    const int tile = id - split * gb.tiles_total;
+    const int ti = gb.tj_total ? tile / gb.tj_total : 0, trem = gb.tj_total ? tile - ti * gb.tj_total : tile;
+    int pi = 0;
+#pragma unroll
+    for (int q = 1; q < SINGA_CGEMM_MAX; ++q)
+        if (q < gb.n && trem >= gb.p[q].tile_begin) pi = q;
+    const CGemmProb& P = gb.p[pi];
+    const int local = trem - P.tile_begin;
+    const int i0 = (gb.tj_total ? ti : local / P.tiles_j) * BM, j0 = (gb.tj_total ? local : local % P.tiles_j) * BN;
+    const long long r_begin = (long long)split * gb.r_chunk;
+    const long long r_end = (r_begin + gb.r_chunk < P.R) ? r_begin + gb.r_chunk : P.R;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 32;
+    const int l31 = lane & 31, half = lane >> 5;
+    const float sigma = P.sigma;
+
+    // ---- staging maps.  Reduction-contiguous operand: float4 kq (of 4) of part pt of row rr + 32 j.  Output-contiguous operand:
+    // float4 c4 of reduction row rq (+ rows per pass) of part j / (n / 2).
+    const int kq = tid & 3, pt = (tid >> 2) & 1, rr = tid >> 3;
+    const float* arow[NA];
+    const float* brow[NB];
+    if (A_RC) {
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int i = i0 + rr + 32 * j;
+            arow[j] = i < P.I ? P.A + (long long)i * P.lda + (long long)pt * P.a_im + 4 * kq : nullptr;
+        }
+    }
+    if (B_RC) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int jj = j0 + rr + 32 * j;
+            brow[j] = jj < P.J ? P.B + (long long)jj * P.ldb + (long long)pt * P.b_im + 4 * kq : nullptr;
+        }
+    }
+    float4 ra0[NA], rb0[NB], ra1[NA], rb1[NB];
+    const bool full = i0 + BM <= P.I && j0 + BN <= P.J && r_end > r_begin && (r_end - r_begin) % BK == 0;
+    auto load_rc = [&](auto all_c, float4* reg, unsigned& mask, const float* const* rows, const float* dummy, int n, long long r0) {
+        if constexpr (decltype(all_c)::value) {
+#pragma unroll
+            for (int j = 0; j < n; ++j) reg[j] = *reinterpret_cast<const float4*>(rows[j] + r0);
+            mask = ~0u;
+        } else {
+            const bool in = r0 + 4 * kq < r_end;
+            mask = 0;
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                const bool ok = in && rows[j] != nullptr;
+                const float* src = ok ? rows[j] + r0 : dummy + r_begin;
+                reg[j] = *reinterpret_cast<const float4*>(src);
+                mask |= (ok ? 1u : 0u) << j;
+            }
+        }
+    };
+    // output-contiguous: `width4` float4 per reduction row and part, 256 / width4 reduction rows per pass, n / 2 passes per part
+    auto load_oc = [&](auto all_c, float4* reg, unsigned& mask, const float* base, long long ld, long long im, int o0, int lim, int n,
+                       int width4, long long r0) {
+        const int c4 = tid % width4, rq = tid / width4, rows = 256 / width4;
+        const int i = o0 + 4 * c4;
+        if constexpr (decltype(all_c)::value) {
+            const float* b = base + (r0 + rq) * ld + i;
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                const int part = j / (n / 2), ps = j % (n / 2);
+                reg[j] = *reinterpret_cast<const float4*>(b + (long long)part * im + (long long)(rows * ps) * ld);
+            }
+            mask = ~0u;
+        } else {
+            const int ic = i < lim ? i : o0;
+            mask = 0;
+#pragma unroll
+            for (int j = 0; j < n; ++j) {
+                const int part = j / (n / 2), ps = j % (n / 2);
+                const long long r = r0 + rq + rows * ps;
+                const bool ok = r < r_end && i < lim;
+                const long long rc = r < r_end ? r : r_begin;
+                reg[j] = *reinterpret_cast<const float4*>(base + rc * ld + (long long)part * im + ic);
+                mask |= (ok ? 1u : 0u) << j;
+            }
+        }
+    };
+    auto store_rc = [&](float* S, int sz1, const float4* reg, unsigned mask, int n) {
+#pragma unroll
+        for (int j = 0; j < n; ++j)
+            *reinterpret_cast<float4*>(S + pt * sz1 + (rr + 32 * j) * PR + 4 * kq) =
+                (mask >> j) & 1u ? reg[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    auto store_oc = [&](float* S, int sz1, const float4* reg, unsigned mask, int pitch, int n, int width4) {
+        const int c4 = tid % width4, rq = tid / width4, rows = 256 / width4;
+#pragma unroll
+        for (int j = 0; j < n; ++j) {
+            const int part = j / (n / 2), ps = j % (n / 2);
+            *reinterpret_cast<float4*>(S + part * sz1 + (rq + rows * ps) * pitch + 4 * c4) =
+                (mask >> j) & 1u ? reg[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto load_ab = [&](auto all_c, float4* ra, float4* rb, unsigned& ma, unsigned& mb, long long r0) __attribute__((always_inline)) {
+        if (A_RC) load_rc(all_c, ra, ma, arow, P.A, NA, r0);
+        else load_oc(all_c, ra, ma, P.A, P.lda, P.a_im, i0, P.I, NA, BM / 4, r0);
+        if (B_RC) load_rc(all_c, rb, mb, brow, P.B, NB, r0);
+        else load_oc(all_c, rb, mb, P.B, P.ldb, P.b_im, j0, P.J, NB, BN / 4, r0);
+    };
+    auto store_ab = [&](const float4* ra, const float4* rb, unsigned ma, unsigned mb, int buf) __attribute__((always_inline)) {
+        if (A_RC) store_rc(As0 + buf * SZA, SZA1, ra, ma, NA);
+        else store_oc(As0 + buf * SZA, SZA1, ra, ma, LDA, NA, BM / 4);
+        if (B_RC) store_rc(Bs0 + buf * SZB, SZB1, rb, mb, NB);
+        else store_oc(Bs0 + buf * SZB, SZB1, rb, mb, LDB, NB, BN / 4);
+    };
+    const int ia = wrow + l31, jb = wcol + l31;
+    auto frag = [&](const float* S, bool rc, int pitch, int col, int t, float (&f)[4]) __attribute__((always_inline)) {
+        if (rc) {
+            const float4 v = *reinterpret_cast<const float4*>(S + col * PR + 8 * t + 4 * half);
+            f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[q] = S[(8 * t + q + 4 * half) * pitch + col];
+        }
+    };
+    floatx16 acc1[2], acc2[2], acc3[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[a][r] = acc2[a][r] = acc3[a][r] = 0.f;
+    const bool row1 = __builtin_amdgcn_readfirstlane((int)(i0 + wrow + 32 < P.I)) != 0;      // the wavefront's second 32-row block holds rows
+    const bool colv = __builtin_amdgcn_readfirstlane((int)(j0 + wcol < P.J)) != 0;           // ... its 32-column block holds columns
+    auto compute = [&](auto all_c, int buf) __attribute__((always_inline)) {
+        if constexpr (!decltype(all_c)::value) {
+            if (!colv) return;                   // (a 96-wide result: the last tile's second column block is padding only)
+        }
+        const float* Sa = As0 + buf * SZA;
+        const float* Sb = Bs0 + buf * SZB;
+#pragma unroll
+        for (int t = 0; t < BK / 8; ++t) {
+            float ar[2][4], ai[2][4], br[4], bi[4];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                frag(Sa, A_RC, LDA, ia + 32 * a, t, ar[a]);
+                frag(Sa + SZA1, A_RC, LDA, ia + 32 * a, t, ai[a]);
+            }
+            frag(Sb, B_RC, LDB, jb, t, br);
+            frag(Sb + SZB1, B_RC, LDB, jb, t, bi);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float ds = sigma * bi[q];
+                const float b2 = ds - br[q], b3 = ds + br[q];
+                acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[0][q] + ai[0][q], br[q], acc1[0], 0, 0, 0);
+                acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[0][q], b2, acc2[0], 0, 0, 0);
+                acc3[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[0][q], b3, acc3[0], 0, 0, 0);
+                if (decltype(all_c)::value || row1) {
+                    acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[1][q] + ai[1][q], br[q], acc1[1], 0, 0, 0);
+                    acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[1][q], b2, acc2[1], 0, 0, 0);
+                    acc3[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[1][q], b3, acc3[1], 0, 0, 0);
+                }
+            }
+        }
+    };
+    const long long nsteps = r_end > r_begin ? (r_end - r_begin + BK - 1) / BK : 0;
+    auto k_loop = [&](auto all_c) __attribute__((always_inline)) {
+        unsigned ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;
+        if (nsteps > 0) {
+            load_ab(all_c, ra0, rb0, ma0, mb0, r_begin);
+            if (nsteps > 1) load_ab(all_c, ra1, rb1, ma1, mb1, r_begin + BK);
+            store_ab(ra0, rb0, ma0, mb0, 0);
+        }
+        __syncthreads();
+        long long st = 0;
+        if (nsteps > 3) __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0) only (see k7)
+        for (; st + 3 < nsteps; st += 2) {
+            load_ab(all_c, ra0, rb0, ma0, mb0, r_begin + (st + 2) * BK);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(all_c, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            store_ab(ra1, rb1, ma1, mb1, 1);
+            __syncthreads();
+            load_ab(all_c, ra1, rb1, ma1, mb1, r_begin + (st + 3) * BK);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(all_c, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            store_ab(ra0, rb0, ma0, mb0, 0);
+            __syncthreads();
+        }
+        for (; st < nsteps; st += 2) {
+            if (st + 2 < nsteps) load_ab(all_c, ra0, rb0, ma0, mb0, r_begin + (st + 2) * BK);
+            compute(all_c, 0);
+            if (st + 1 < nsteps) store_ab(ra1, rb1, ma1, mb1, 1);
+            __syncthreads();
+            if (st + 1 >= nsteps) break;
+            if (st + 3 < nsteps) load_ab(all_c, ra1, rb1, ma1, mb1, r_begin + (st + 3) * BK);
+            compute(all_c, 1);
+            if (st + 2 < nsteps) store_ab(ra0, rb0, ma0, mb0, 0);
+            __syncthreads();
+        }
+    };
+    if (full) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
+    // ---- epilogue: re = P1 - P3, im = P1 + P2; per wavefront one 32-row block at a time through LDS ([row][32 re | 32 im]),
+    // then float4 rows: 8 float4 of the real half and 8 of the imaginary half (c_im elements behind) per row
+    float* Cb = P.C + (long long)split * P.c_split;
+    float* stage = smem + wave * (32 * PE);
+    const int c4 = lane & 15, rsub = lane >> 4;
+    const int part = c4 >> 3, jcol = j0 + wcol + 4 * (c4 & 7);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int rw = (q & 3) + 8 * (q >> 2) + 4 * half;
+            stage[rw * PE + l31] = acc1[a][q] - acc3[a][q];
+            stage[rw * PE + 32 + l31] = acc1[a][q] + acc2[a][q];
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int rloc = rsub + 4 * ps;
+            const int i = i0 + wrow + 32 * a + rloc;
+            const float4 v = *reinterpret_cast<const float4*>(stage + rloc * PE + 4 * c4);
+            if (i < P.I && jcol < P.J)
+                *reinterpret_cast<float4*>(Cb + (long long)i * P.ldc + (long long)part * P.c_im + jcol) = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ small weight / node transforms
 // SO2_m_Convolution's Linear acts on [x_+m | x_-m] through the "complex" recombination (out_r = fc_r(x_+) - fc_i(x_-),
 // out_i = fc_r(x_-) + fc_i(x_+), EF:721-729); folded into ONE block weight B = [[Wr, -Wi], [Wi, Wr]] (Wr = w[:h], Wi = w[h:])
@@ -5906,6 +6173,60 @@ int singa_gemm_f32(const singa_gemm_t* probs, int n, int a_r_contig, int b_r_con
     else SINGA_GEMM_GO(SINGA_PROF_GEMM_TN, false, false);
 #undef SINGA_GEMM_GO
     return check_launch("gemm_f32");
+}
+
+int singa_cgemm3m_f32(const singa_cgemm_t* probs, int n, int a_r_contig, int b_r_contig, int splits, void* stream) {
+    if (!probs || n < 1 || n > SINGA_CGEMM_MAX) return fail(SINGA_E_SHAPE, "cgemm3m_f32: 1..SINGA_CGEMM_MAX problems per launch");
+    if (splits < 1) return fail(SINGA_E_SHAPE, "cgemm3m_f32: splits must be >= 1");
+    if (!a_r_contig && b_r_contig) return fail(SINGA_E_SHAPE, "cgemm3m_f32: A output-contiguous with B reduction-contiguous is not built");
+    CGemmBatch gb;
+    memset(&gb, 0, sizeof(gb));
+    gb.n = n;
+    gb.splits = splits;
+    constexpr int BM = 128, BN = 64;
+    long long rmax = 0;
+    int tj_total = 0, ti_max = 0, tiles_seq = 0;
+    bool same_rows = true;
+    for (int k = 1; k < n; ++k) same_rows = same_rows && probs[k].I == probs[0].I;
+    for (int k = 0; k < n; ++k) {
+        const singa_cgemm_t& q = probs[k];
+        CGemmProb& P = gb.p[k];
+        if (!q.a || !q.b || !q.c) return fail(SINGA_E_NULL, "cgemm3m_f32: null operand");
+        if (q.I < 0 || q.J < 0 || q.R < 0) return fail(SINGA_E_SHAPE, "cgemm3m_f32: negative size");
+        const bool a_ok = a_r_contig ? (q.R % 4 == 0) : (q.I % 4 == 0);
+        const bool b_ok = b_r_contig ? (q.R % 4 == 0) : (q.J % 4 == 0);
+        if (!a_ok || !b_ok || q.J % 4 || q.lda % 4 || q.ldb % 4 || q.ldc % 4 || q.a_im % 4 || q.b_im % 4 || q.c_im % 4 ||
+            q.c_split_stride % 4 || ((uintptr_t)q.a & 15) || ((uintptr_t)q.b & 15) || ((uintptr_t)q.c & 15))
+            return fail(SINGA_E_SHAPE, "cgemm3m_f32: contiguous axes, pitches and part offsets must be multiples of 4 floats, bases 16-byte aligned");
+        if (q.sigma != 1.0f && q.sigma != -1.0f) return fail(SINGA_E_SHAPE, "cgemm3m_f32: sigma is +1 or -1");
+        if (splits > 1 && q.c_split_stride <= 0) return fail(SINGA_E_SHAPE, "cgemm3m_f32: split reductions need c_split_stride");
+        P.A = q.a; P.B = q.b; P.C = q.c;
+        P.lda = q.lda; P.ldb = q.ldb; P.ldc = q.ldc;
+        P.a_im = q.a_im; P.b_im = q.b_im; P.c_im = q.c_im;
+        P.c_split = q.c_split_stride;
+        P.I = q.I; P.J = q.J; P.R = q.R;
+        P.sigma = q.sigma;
+        P.tiles_j = (q.J + BN - 1) / BN;
+        P.tile_begin = same_rows ? tj_total : tiles_seq;
+        tj_total += P.tiles_j;
+        const int ti = (q.I + BM - 1) / BM;
+        tiles_seq += ti * P.tiles_j;
+        if (ti > ti_max) ti_max = ti;
+        if (q.R > rmax) rmax = q.R;
+    }
+    const int tiles = same_rows ? ti_max * tj_total : tiles_seq;
+    if (tiles == 0) return SINGA_OK;
+    gb.tiles_total = tiles;
+    gb.tj_total = same_rows ? tj_total : 0;
+    gb.r_chunk = splits > 1 ? ((rmax + splits - 1) / splits + 15) / 16 * 16 : (rmax > 0 ? rmax : 1);
+    const long long nblk = (long long)tiles * splits;
+    if (nblk > (1 << 30)) return fail(SINGA_E_SHAPE, "cgemm3m_f32: too many tiles");
+    const dim3 grid((unsigned)((nblk + 7) / 8 * 8)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (a_r_contig && b_r_contig) SINGA_LAUNCH(SINGA_PROF_CGEMM_NT, 0, tiles, (cgemm3m_f32_kernel<true, true>), grid, block, st, gb);
+    else if (a_r_contig) SINGA_LAUNCH(SINGA_PROF_CGEMM_NN, 0, tiles, (cgemm3m_f32_kernel<true, false>), grid, block, st, gb);
+    else SINGA_LAUNCH(SINGA_PROF_CGEMM_TN, 0, tiles, (cgemm3m_f32_kernel<false, false>), grid, block, st, gb);
+    return check_launch("cgemm3m_f32");
 }
 
 int singa_alpha_logits_nslots(int E) {

@@ -309,8 +309,9 @@ class SO2_Convolution(nn.Module):
         c = self.sphere_channels
         st = self.layout.seg_start
         if len(self.so2_m_conv) == 2:
-            return list(ops.so2_linear3(X, self.fc_m0.weight, self.fc_m0.bias, self.so2_m_conv[0].block_weight(),
-                                        self.so2_m_conv[1].block_weight(), st[1] * c, (st[2] - st[1]) * c))
+            # m = 1, 2 as complex products in three real multiplications on the fc weights themselves (k7c)
+            return list(ops.so2_conv3m(X, self.fc_m0.weight, self.fc_m0.bias, self.so2_m_conv[0].fc.weight,
+                                       self.so2_m_conv[1].fc.weight, st[1] * c, (st[2] - st[1]) * c))
         outs = [ops.linear(X[:, : st[1] * c], self.fc_m0.weight, self.fc_m0.bias)]
         for i, conv in enumerate(self.so2_m_conv):
             outs.append(ops.linear(X[:, st[i + 1] * c: st[i + 2] * c], conv.block_weight()))

@@ -63,7 +63,8 @@ def profile_end():
 
 
 PROF_TAGS = {1: "k10_fwd", 2: "k10_bwd", 3: "k4_fwd", 4: "k4_bwd_rad", 5: "k4_bwd_dst", 6: "k4_bwd_src",           # include/singa_hip.h
-             10: "s2_edge_fwd", 11: "s2_edge_bwd", 12: "s2_node_fwd", 13: "s2_node_bwd"}
+             7: "gemm_nt", 8: "gemm_nn", 9: "gemm_tn", 10: "s2_edge_fwd", 11: "s2_edge_bwd", 12: "s2_node_fwd", 13: "s2_node_bwd",
+             14: "cgemm_nt", 15: "cgemm_nn", 16: "cgemm_tn"}
 
 
 def profile_collect():
@@ -1227,6 +1228,13 @@ def _splits_for(rows, tiles=None):
     return best
 
 
+def _splits_few(rows, tiles):
+    """Split count of a weight-gradient launch with FEW output tiles (an SO(2) convolution's m = 0 block alone, or its two
+    complex blocks: 10-50 tiles): at least as many splits as put two workgroups on every CU, 256 rows per split or more."""
+    base = _splits_for(rows, tiles)
+    return max(base, min(64, -(-512 // max(1, tiles)), max(1, rows // 256)))
+
+
 def gemm_nt(x, w, bias=None, out=None):
     """y = x w^T (+ bias) on the library's own MFMA kernel; x [M, K] (row-strided views allowed), w [N, K]."""
     x, w = _rows(x), _rows(w)
@@ -1312,6 +1320,102 @@ class _SO2Linear3(torch.autograd.Function):
             gb = torch.zeros(outs[0], device=X.device, dtype=torch.float32)
         gws = [g.view(o, k) if g is not None else None for g, o, k in zip(gws, outs, ins)]
         return gX, gws[0], gb, gws[1], gws[2], None, None
+
+
+def _cgemm(items, a_rc, b_rc, splits=1):
+    arr, n = _capi.cgemm_probs(items)
+    _chk(_lib.lib().singa_cgemm3m_f32(arr, n, int(a_rc), int(b_rc), int(splits), _stream()), "singa_cgemm3m_f32")
+
+
+class _SO2Conv3M(torch.autograd.Function):
+    """One SO(2) convolution (EF:807-875) on the m-primary edge matrix X [E, n0 + n1 + n2], the m = 1, 2 blocks as COMPLEX
+    products in three real multiplications (k7c, `singa_cgemm3m_f32`) on the modules' own fc weights [2N, K] (Wr = w[:N],
+    Wi = w[N:]; no block weight is built), the m = 0 block on the real GEMM (k7): two launches forward, two for dX, two
+    split reductions + one column sum for the weight gradients, which arrive in the parameters' own layout."""
+
+    @staticmethod
+    def forward(ctx, X, w0, b0, w1, w2, n0, n1):
+        ctx.params = (w0, w1, w2, b0)
+        X = _rows(X)
+        ws = [_rows(w0), w1.contiguous(), w2.contiguous()]
+        b0 = b0.contiguous()
+        _dev(X, *ws, b0)
+        E, nin = X.shape
+        ins = (n0, n1, nin - n0 - n1)
+        outs = tuple(w.shape[0] for w in ws)
+        assert ws[0].shape[1] == n0 and all(2 * w.shape[1] == k and w.shape[0] % 2 == 0 for w, k in zip(ws[1:], ins[1:]))
+        H = torch.empty(E, sum(outs), device=X.device, dtype=torch.float32)
+        if E > 0:
+            _gemm([dict(a=X.data_ptr(), lda=X.stride(0), b=ws[0].data_ptr(), ldb=ws[0].stride(0), c=H.data_ptr(),
+                        ldc=H.stride(0), bias=b0.data_ptr(), I=E, J=outs[0], R=n0)], True, True)
+            items, ai, ci = [], n0, outs[0]
+            for w, k, o in zip(ws[1:], ins[1:], outs[1:]):
+                K, N = k // 2, o // 2
+                items.append(dict(a=X.data_ptr() + 4 * ai, lda=X.stride(0), a_im=K, b=w.data_ptr(), ldb=K, b_im=N * K,
+                                  c=H.data_ptr() + 4 * ci, ldc=H.stride(0), c_im=N, I=E, J=N, R=K, sigma=1.0))
+                ai, ci = ai + k, ci + o
+            _cgemm(items, True, True)
+        ctx.save_for_backward(X, *ws)
+        ctx.ins, ctx.outs = ins, outs
+        o0, o1 = outs[0], outs[0] + outs[1]
+        return H[:, :o0], H[:, o0:o1], H[:, o1:]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        X, w0, w1, w2 = ctx.saved_tensors
+        ins, outs = ctx.ins, ctx.outs
+        E = X.shape[0]
+        gs = [_rows(g) for g in (g0, g1, g2)]
+        ws = (w0, w1, w2)
+        gX = None
+        if ctx.needs_input_grad[0]:
+            gX = torch.empty_like(X)
+            if E > 0:
+                _gemm([dict(a=gs[0].data_ptr(), lda=gs[0].stride(0), b=w0.data_ptr(), ldb=w0.stride(0), c=gX.data_ptr(),
+                            ldc=gX.stride(0), I=E, J=ins[0], R=outs[0])], True, False)
+                items, ai = [], ins[0]
+                for g, w, k, o in zip(gs[1:], ws[1:], ins[1:], outs[1:]):
+                    K, N = k // 2, o // 2
+                    items.append(dict(a=g.data_ptr(), lda=g.stride(0), a_im=N, b=w.data_ptr(), ldb=K, b_im=N * K,
+                                      c=gX.data_ptr() + 4 * ai, ldc=gX.stride(0), c_im=K, I=E, J=K, R=N, sigma=-1.0))
+                    ai += k
+                _cgemm(items, True, False)
+        # weight gradients: reductions over the edges, split over workgroups into dense partial slabs (the fc weights' layouts)
+        sizes = [outs[0] * ins[0], outs[1] * ins[1] // 2, outs[2] * ins[2] // 2]
+        tot = sum(sizes)
+        # the two launches have few tiles each (conv1: 16 and 14): each gets the split count that fills the CUs
+        S0 = _splits_few(E, -(-outs[0] // 128) * -(-ins[0] // 128))
+        Sc = _splits_few(E, sum(-(-(o // 2) // 128) * -(-(k // 2) // 64) for o, k in zip(outs[1:], ins[1:])))
+        pw = ctx.params[:3]
+        if E > 0:
+            row0, rowc = sizes[0] + outs[0], sizes[1] + sizes[2]
+            part0 = torch.empty(S0, row0, device=X.device, dtype=torch.float32)
+            partc = torch.empty(Sc, rowc, device=X.device, dtype=torch.float32)
+            _gemm([dict(a=gs[0].data_ptr(), lda=gs[0].stride(0), b=X.data_ptr(), ldb=X.stride(0), c=part0.data_ptr(), ldc=ins[0],
+                        I=outs[0], J=ins[0], R=E, c_split_stride=row0, asum=part0.data_ptr() + 4 * sizes[0], asum_stride=row0)],
+                  False, False, S0)
+            items, ai, off = [], ins[0], 0
+            for g, k, o, sz in zip(gs[1:], ins[1:], outs[1:], sizes[1:]):
+                K, N = k // 2, o // 2
+                items.append(dict(a=g.data_ptr(), lda=g.stride(0), a_im=N, b=X.data_ptr() + 4 * ai, ldb=X.stride(0), b_im=K,
+                                  c=partc.data_ptr() + 4 * off, ldc=K, c_im=N * K, I=N, J=K, R=E, sigma=-1.0,
+                                  c_split_stride=rowc))
+                ai, off = ai + k, off + sz
+            _cgemm(items, False, False, Sc)
+            r0 = param_colsum(part0, [(0, sizes[0], pw[0]), (sizes[0], outs[0], ctx.params[3])])
+            rc = param_colsum(partc, [(0, sizes[1], pw[1]), (sizes[1], sizes[2], pw[2])])
+            gws, gb = [r0[0], rc[0], rc[1]], r0[1]
+        else:
+            gws = list(torch.zeros(tot, device=X.device, dtype=torch.float32).split(sizes))
+            gb = torch.zeros(outs[0], device=X.device, dtype=torch.float32)
+        shapes = [(outs[0], ins[0]), (outs[1], ins[1] // 2), (outs[2], ins[2] // 2)]
+        gws = [g.view(*sh) if g is not None else None for g, sh in zip(gws, shapes)]
+        return gX, gws[0], gb, gws[1], gws[2], None, None
+
+
+def so2_conv3m(X, w0, b0, w1, w2, n0, n1):
+    """The SO(2) convolution on the fc weights themselves (w1, w2: [2N, K] = [Wr; Wi]) - see _SO2Conv3M."""
+    return _SO2Conv3M.apply(X, w0, b0, w1, w2, n0, n1)
 
 
 def so2_linear3(X, w0, b0, w1, w2, n0, n1):

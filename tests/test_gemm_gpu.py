@@ -59,6 +59,55 @@ def test_gemm_nt_nn_tn_against_float64(M, N, K, tile_shape):
             assert float((_f64(asum).sum(0) - refb).abs().max()) <= (0 if kind == "int" else 2e-6 * M ** 0.5 + 1e-6 * float(refb.abs().max()))
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 4, 4), (130, 36, 20), (129, 96, 128), (1000, 512, 96), (257, 64, 16), (3000, 384, 512)])
+def test_complex_gemm_3m_all_forms_against_float64(M, N, K):
+    """singa_cgemm3m_f32 (k7c): forward (1, 1), d input (1, 0), d weight (0, 0, split) of out = (x_re + i x_im)(Wr + i Wi)^T
+    with ragged tiles in every dimension; exact on small integers (any indexing slip or sign error is an O(1) error), then
+    random floats against float64.  M rows, N complex outputs, K complex inputs."""
+    from singa_amd import ops
+    g = torch.Generator().manual_seed(M * 5 + N)
+    for kind in ("int", "float"):
+        mk = (lambda *s: torch.randint(-3, 4, s, generator=g).float()) if kind == "int" else (lambda *s: torch.randn(*s, generator=g))
+        x, w, dy = mk(M, 2 * K), mk(2 * N, K), mk(M, 2 * N)
+        xd, wd, dyd = x.to(DEV), w.to(DEV), dy.to(DEV)
+        xr, xi, wr, wi, gr, gi = _f64(x[:, :K]), _f64(x[:, K:]), _f64(w[:N]), _f64(w[N:]), _f64(dy[:, :N]), _f64(dy[:, N:])
+        tol = 0 if kind == "int" else 3e-6
+        slack = 0 if kind == "int" else 1e-6
+
+        def check(got, ref, extra=0.0):
+            assert float((_f64(got) - ref).abs().max()) <= tol * float(ref.abs().max()) + slack + extra
+
+        y = torch.full((M, 2 * N), float("nan"), device=DEV)
+        ops._cgemm([dict(a=xd.data_ptr(), lda=2 * K, a_im=K, b=wd.data_ptr(), ldb=K, b_im=N * K, c=y.data_ptr(), ldc=2 * N, c_im=N,
+                         I=M, J=N, R=K, sigma=1.0)], True, True)
+        check(y, torch.cat([xr @ wr.t() - xi @ wi.t(), xr @ wi.t() + xi @ wr.t()], 1))
+        dx = torch.full((M, 2 * K), float("nan"), device=DEV)
+        ops._cgemm([dict(a=dyd.data_ptr(), lda=2 * N, a_im=N, b=wd.data_ptr(), ldb=K, b_im=N * K, c=dx.data_ptr(), ldc=2 * K, c_im=K,
+                         I=M, J=K, R=N, sigma=-1.0)], True, False)
+        check(dx, torch.cat([gr @ wr + gi @ wi, gi @ wr - gr @ wi], 1))
+        ref = torch.cat([gr.t() @ xr + gi.t() @ xi, gi.t() @ xr - gr.t() @ xi], 0)
+        for S in (1, 3):
+            part = torch.full((S, 2 * N * K), float("nan"), device=DEV)
+            ops._cgemm([dict(a=dyd.data_ptr(), lda=2 * N, a_im=N, b=xd.data_ptr(), ldb=2 * K, b_im=K, c=part.data_ptr(), ldc=K,
+                             c_im=N * K, I=N, J=K, R=M, sigma=-1.0, c_split_stride=2 * N * K)], False, False, S)
+            check(part.sum(0).view(2 * N, K), ref, 0 if kind == "int" else 3e-6 * M ** 0.5)
+
+
+def test_complex_gemm_argument_errors():
+    from singa_amd import ops
+    z = torch.zeros(64, 64, device=DEV)
+    ok = dict(a=z.data_ptr(), lda=64, a_im=32, b=z.data_ptr(), ldb=32, b_im=32 * 32, c=z.data_ptr(), ldc=64, c_im=32, I=64, J=32, R=32,
+              sigma=1.0)
+    ops._cgemm([ok], True, True)
+    for bad in (dict(sigma=0.5), dict(a_im=30), dict(R=30), dict(a=0), dict(ldc=62)):
+        with pytest.raises(RuntimeError):
+            ops._cgemm([{**ok, **bad}], True, True)
+    with pytest.raises(RuntimeError):
+        ops._cgemm([ok], False, True)                      # (0, 1) is not built
+    with pytest.raises(RuntimeError):
+        ops._cgemm([ok] * 5, True, True)                   # SINGA_CGEMM_MAX = 4 problems per launch
+
+
 def test_gemm_argument_errors():
     from singa_amd import ops
     x, w = torch.zeros(8, 6, device=DEV), torch.zeros(4, 6, device=DEV)
@@ -100,9 +149,9 @@ def test_so2_convolution_matches_oracle(L, cin, cout, extra):
     to_m = torch.as_tensor(lay.to_m)
     st = lay.seg_start
     from tests.lib_gemm import _SO2Linear3Lib
-    for own in (True, False):
+    for own in ("3m", True, False):      # the product's path (k7c on the fc weights), the block-weight form on k7, on the BLAS library
         ops._GEMM_SPLIT_ROWS = 200
-        so2 = ops.so2_linear3 if own else _SO2Linear3Lib.apply
+        so2 = ops.so2_linear3 if own is True else _SO2Linear3Lib.apply
         try:
             X = x[:, to_m].reshape(E, -1).to(DEV).requires_grad_(True)       # m-primary rows, what k4 hands over
             w0 = sd["c.fc_m0.weight"].to(DEV).requires_grad_(True)
@@ -113,7 +162,10 @@ def test_so2_convolution_matches_oracle(L, cin, cout, extra):
                 with torch.no_grad():
                     mod.fc.weight.copy_(sd[f"c.so2_m_conv.{m - 1}.fc.weight"])
                 fcs.append(mod)
-            h0, h1, h2 = so2(X, w0, b0, fcs[0].block_weight(), fcs[1].block_weight(), st[1] * cin, (st[2] - st[1]) * cin)
+            if own == "3m":
+                h0, h1, h2 = ops.so2_conv3m(X, w0, b0, fcs[0].fc.weight, fcs[1].fc.weight, st[1] * cin, (st[2] - st[1]) * cin)
+            else:
+                h0, h1, h2 = so2(X, w0, b0, fcs[0].block_weight(), fcs[1].block_weight(), st[1] * cin, (st[2] - st[1]) * cin)
             got = torch.cat([h0[:, extra:], h1, h2], 1).reshape(E, lay.KR, cout)        # m-primary rows
             assert rel_err(got.detach().cpu(), want[:, to_m]) < 2e-6
             if extra:
@@ -176,6 +228,13 @@ def test_so2_and_so3_linear_on_empty_inputs():
     assert h0.shape == (0, 40) and h1.shape == (0, 32) and h2.shape == (0, 16)
     (h0.sum() + h1.sum() + h2.sum()).backward()
     assert float(w0.grad.abs().max()) == 0.0 and float(w2.grad.abs().max()) == 0.0 and float(b0.grad.abs().max()) == 0.0
+    for t in (w0, b0):
+        t.grad = None
+    f1, f2 = torch.randn(32, 16, device=DEV, requires_grad=True), torch.randn(16, 8, device=DEV, requires_grad=True)
+    h0, h1, h2 = ops.so2_conv3m(X, w0, b0, f1, f2, 48, 32)
+    assert h0.shape == (0, 40) and h1.shape == (0, 32) and h2.shape == (0, 16)
+    (h0.sum() + h1.sum() + h2.sum()).backward()
+    assert float(w0.grad.abs().max()) == 0.0 and float(f1.grad.abs().max()) == 0.0 and float(f2.grad.abs().max()) == 0.0
     x = torch.zeros(0, 9, 16, device=DEV, requires_grad=True)
     w, b = torch.randn(3, 32, 16, device=DEV, requires_grad=True), torch.randn(32, device=DEV, requires_grad=True)
     y = ops.so3_linear(x, w, b, 2)

@@ -107,13 +107,13 @@ def test_singa_step_matches_reference(L):
         if ref < 0:
             if gr is not None and float(gr.norm()) != 0.0:
                 bad.append((str(n), "unexpected gradient"))
-        elif gr is None or abs(float(gr.norm()) - ref) > 3e-3 * ref + 1e-7:
+        elif gr is None or abs(float(gr.norm()) - ref) > 1e-4 * ref + 1e-7:
             bad.append((str(n), None if gr is None else float(gr.norm()), float(ref)))
     assert not bad, bad[:8]
     # element-wise samples of every parameter's gradient against the reference's
     errs = sorted(grad_sample_errors({n: p.grad for n, p in params.items()}, z, 0.0), key=lambda e: -e[1])
     print(f"L={L}: worst element-wise gradient sample errors: " + ", ".join(f"{n} {e:.1e}" for n, e in errs[:3]))
-    bad = [e for e in errs if e[1] > 3e-3]
+    bad = [e for e in errs if e[1] > 1e-4]            # measured with the ties pinned: <= 3e-7 (3e-3 was needed before)
     assert not bad, bad[:8]
 
 
