@@ -1230,9 +1230,15 @@ def _splits_for(rows, tiles=None):
 
 def _splits_few(rows, tiles):
     """Split count of a weight-gradient launch with FEW output tiles (an SO(2) convolution's m = 0 block alone, or its two
-    complex blocks: 10-50 tiles): at least as many splits as put two workgroups on every CU, 256 rows per split or more."""
-    base = _splits_for(rows, tiles)
-    return max(base, min(64, -(-512 // max(1, tiles)), max(1, rows // 256)))
+    complex blocks: 10-50 tiles).  Model: the launch runs in rounds of 512 workgroups (two per CU), a workgroup costs its
+    rows / S reduction rows plus ~64 rows' worth of prologue and epilogue; the cheapest S of 1..64 with at least 128 rows per
+    split (50 tiles x 11 splits = 1.07 rounds ran as two: 393 us for the 13 k-edge shard's conv2, tools/lab/cgemm_probe.py)."""
+    best, best_cost = 1, None
+    for S in range(1, max(1, min(64, rows // 128)) + 1):
+        cost = -(-tiles * S // 512) * (-(-rows // S) + 64)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = S, cost
+    return best
 
 
 def gemm_nt(x, w, bias=None, out=None):
