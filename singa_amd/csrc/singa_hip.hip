@@ -4093,6 +4093,14 @@ struct CGemmBatch {
     long long r_chunk;
 };
 
+#ifndef SINGA_CGEMM_PIPE
+#define SINGA_CGEMM_PIPE 1
+#endif
+#if SINGA_CGEMM_PIPE
+#define SINGA_CGEMM_FENCE() do { if constexpr (!decltype(all_c)::value) __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SINGA_CGEMM_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 template <bool A_RC, bool B_RC>
 __global__ void __launch_bounds__(256, 2) cgemm3m_f32_kernel(CGemmBatch gb) {
     constexpr int BM = 128, BN = 64, BK = 16, PR = BK + 4, LDA = BM + 4, LDB = BN + 4;
@@ -4266,6 +4274,28 @@ __global__ void __launch_bounds__(256, 2) cgemm3m_f32_kernel(CGemmBatch gb) {
         }
     };
     const long long nsteps = r_end > r_begin ? (r_end - r_begin + BK - 1) / BK : 0;
+    // Issue order of one steady-state K step of a full tile (as k7's `pipeline`): the 6 global loads and the 6 LDS writes are
+    // spread between the 48 MFMAs, the second k-group's fragment reads travel behind the first group's MFMAs.
+    auto pipeline = [&](auto interior_c) __attribute__((always_inline)) {
+#if SINGA_CGEMM_PIPE
+        if constexpr (decltype(interior_c)::value) {
+            constexpr int DSR = (A_RC ? 4 : 16) + (B_RC ? 2 : 8);                  // fragment reads per k-group
+            constexpr int MF = 0x008, VM = 0x020, DR = 0x100, DW = 0x200;
+            __builtin_amdgcn_sched_group_barrier(DR, DSR, 0);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(MF, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(VM, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(DR, (DSR + 5) / 6, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                __builtin_amdgcn_sched_group_barrier(MF, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(DW, 1, 0);
+            }
+        }
+#endif
+    };
     auto k_loop = [&](auto all_c) __attribute__((always_inline)) {
         unsigned ma0 = 0, mb0 = 0, ma1 = 0, mb1 = 0;
         if (nsteps > 0) {
@@ -4278,16 +4308,18 @@ __global__ void __launch_bounds__(256, 2) cgemm3m_f32_kernel(CGemmBatch gb) {
         if (nsteps > 3) __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0) only (see k7)
         for (; st + 3 < nsteps; st += 2) {
             load_ab(all_c, ra0, rb0, ma0, mb0, r_begin + (st + 2) * BK);
-            __builtin_amdgcn_sched_barrier(0);
+            SINGA_CGEMM_FENCE();
             compute(all_c, 0);
-            __builtin_amdgcn_sched_barrier(0);
+            SINGA_CGEMM_FENCE();
             store_ab(ra1, rb1, ma1, mb1, 1);
+            pipeline(all_c);
             __syncthreads();
             load_ab(all_c, ra1, rb1, ma1, mb1, r_begin + (st + 3) * BK);
-            __builtin_amdgcn_sched_barrier(0);
+            SINGA_CGEMM_FENCE();
             compute(all_c, 1);
-            __builtin_amdgcn_sched_barrier(0);
+            SINGA_CGEMM_FENCE();
             store_ab(ra0, rb0, ma0, mb0, 0);
+            pipeline(all_c);
             __syncthreads();
         }
         for (; st < nsteps; st += 2) {
