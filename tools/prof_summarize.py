@@ -95,7 +95,7 @@ if f:
     calls = collections.Counter()
     for r in csv.DictReader(open(f)):
         name = short(r.get("Kernel_Name", ""))
-        if "gemm_f32_kernel" in name:      # one name serves launches from 10 us to 3 ms: keep the grids apart
+        if "gemm_f32_kernel" in name or "cgemm3m_f32_kernel" in name:      # one name serves launches from 10 us to 3 ms: keep the grids apart
             name += f" grid {r.get('Grid_Size', r.get('Grid_Size_X', ''))}"
         per[name][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
