@@ -92,8 +92,9 @@ class pinned_relu_ties:
     backward mask reads is touched (0 <-> 1e-30), and only in the test: the forward result is the product's own.
     `.flipped` counts the gates where the product had decided the other way."""
 
-    def __init__(self, L):
-        z = golden(f"singa_L{L}_B3_relu_ties.npz")
+    def __init__(self, L=None, records=None):
+        """L: the golden's fixture; or records = oracle_relu_ties(...).records (HIP vs the CPU oracle on any batch)."""
+        z = golden(f"singa_L{L}_B3_relu_ties.npz") if records is None else records
         self.layer = torch.as_tensor(z["layer"]).long()
         self.flat = torch.as_tensor(z["row"]).long() * 1024 + torch.as_tensor(z["unit"]).long()
         self.on = torch.as_tensor(z["on"])
@@ -123,4 +124,89 @@ class pinned_relu_ties:
     def __exit__(self, *exc):
         from singa_amd import ops
         ops._PosFFN.forward = staticmethod(self._orig)
+        return False
+
+
+class oracle_relu_ties:
+    """Context manager around a run of the CPU oracle: records, for every PoswiseFeedForward call (oracle.pos_ffn, CP:170-191),
+    the ReLU gates whose pre-activation lies within `window` of the call's scale from zero, with the oracle's choice - the
+    same record oracle/make_relu_ties.py takes from the reference for the goldens; `.records` feeds pinned_relu_ties."""
+
+    def __init__(self, window=1e-4):
+        self.window, self.calls = window, []
+
+    def __enter__(self):
+        import oracle.singa_oracle as O
+        self._O, self._orig = O, O.pos_ffn
+
+        def pos_ffn(sd, p, x):
+            with torch.no_grad():
+                pre = torch.nn.functional.linear(x.detach(), sd[p + ".conv1.weight"].detach()[:, :, 0],
+                                                 sd[p + ".conv1.bias"].detach()).reshape(-1, 1024)
+                near = (pre.abs() < self.window * pre.pow(2).mean().sqrt()).nonzero()
+                self.calls.append((pre.shape[0], near[:, 0], near[:, 1], pre[near[:, 0], near[:, 1]] > 0))
+            return self._orig(sd, p, x)
+
+        O.pos_ffn = pos_ffn
+        return self
+
+    def __exit__(self, *exc):
+        self._O.pos_ffn = self._orig
+        return False
+
+    @property
+    def records(self):
+        return {"layer": torch.cat([torch.full((len(c[1]),), i) for i, c in enumerate(self.calls)]),
+                "row": torch.cat([c[1] for c in self.calls]), "unit": torch.cat([c[2] for c in self.calls]),
+                "on": torch.cat([c[3] for c in self.calls]), "rows": [c[0] for c in self.calls]}
+
+
+class _ReluPinned(torch.autograd.Function):
+    """relu whose backward mask is overridden at given flat positions (test-only: the reference's choice at fp32 ties)."""
+
+    @staticmethod
+    def forward(ctx, pre, idx, on):
+        mask = pre > 0
+        mask.view(-1)[idx] = on
+        ctx.save_for_backward(mask)
+        return pre.clamp_min(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * ctx.saved_tensors[0], None, None
+
+
+class oracle_pinned_relu_ties:
+    """pinned_relu_ties for the CPU ORACLE (oracle.pos_ffn): the backward mask of the recorded near-zero gates follows the
+    reference's run.  `.flipped` counts the gates where the oracle had decided the other way."""
+
+    def __init__(self, L):
+        z = golden(f"singa_L{L}_B3_relu_ties.npz")
+        self.layer = torch.as_tensor(z["layer"]).long()
+        self.flat = torch.as_tensor(z["row"]).long() * 1024 + torch.as_tensor(z["unit"]).long()
+        self.on = torch.as_tensor(z["on"])
+        self.rows = [int(r) for r in z["rows"]]
+        self.call = self.flipped = 0
+
+    def __enter__(self):
+        import oracle.singa_oracle as O
+        self._O, self._orig = O, O.pos_ffn
+        F = torch.nn.functional
+
+        def pos_ffn(sd, p, x):
+            pre = F.linear(x, sd[p + ".conv1.weight"][:, :, 0], sd[p + ".conv1.bias"])
+            flat = pre.reshape(-1, 1024)
+            assert flat.shape[0] == self.rows[self.call], (self.call, flat.shape)
+            sel = self.layer == self.call
+            idx, on = self.flat[sel], self.on[sel]
+            self.flipped += int(((flat.detach().reshape(-1)[idx] > 0) != on).sum())
+            self.call += 1
+            h = _ReluPinned.apply(flat, idx, on).view_as(pre)
+            return O.layer_norm(sd, p + ".layer_norm", F.linear(h, sd[p + ".conv2.weight"][:, :, 0], sd[p + ".conv2.bias"]) + x)
+
+        O.pos_ffn = pos_ffn
+        return self
+
+    def __exit__(self, *exc):
+        self._O.pos_ffn = self._orig
         return False

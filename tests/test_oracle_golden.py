@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import singa_oracle as O
-from tests.helpers import (BEAM_CASES, NAMES, apply_beam_gains, golden, grad_sample_errors, rel_err, smi_voc,
+from tests.helpers import (BEAM_CASES, NAMES, apply_beam_gains, golden, grad_sample_errors, oracle_pinned_relu_ties, rel_err, smi_voc,
                            state_from_spec)
 
 TOL = 2e-5  # fp32 op-order noise between the reference's einsum/bmm chains and the restatement
@@ -80,25 +80,29 @@ def test_singa_step(L):
     z = golden(f"singa_L{L}_B3.npz")
     g = O.collate([O.load_graph_npz(f"tests/golden/graph_{n}.npz") for n in NAMES])
     rots = {k: torch.as_tensor(z[f"rot_{k}"]) for k in ("pp", "ll", "lp")}
-    logits = O.singa_forward(sd, g, rots, L, torch.as_tensor(z["knn_p"]), torch.as_tensor(z["knn_l"]),
-                             torch.as_tensor(z["lap_p"]), torch.as_tensor(z["lap_l"]))
-    assert rel_err(logits, z["logits"]) < 1e-4
-    loss = torch.nn.functional.cross_entropy(logits, g["tok_tgt"].reshape(-1))
-    assert abs(float(loss) - float(z["loss"])) < 1e-4 * float(z["loss"])
-    loss.backward()
+    with oracle_pinned_relu_ties(L) as pins:      # fp32-tied ReLU gates follow the reference's run
+        logits = O.singa_forward(sd, g, rots, L, torch.as_tensor(z["knn_p"]), torch.as_tensor(z["knn_l"]),
+                                 torch.as_tensor(z["lap_p"]), torch.as_tensor(z["lap_l"]))
+        assert rel_err(logits, z["logits"]) < 1e-4
+        loss = torch.nn.functional.cross_entropy(logits, g["tok_tgt"].reshape(-1))
+        assert abs(float(loss) - float(z["loss"])) < 1e-4 * float(z["loss"])
+        loss.backward()
+    assert pins.call == 18 and pins.flipped <= 16, (pins.call, pins.flipped)
     tot = float(torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sd.values() if v.grad is not None)))
-    assert abs(tot - float(z["grad_total"])) < 1e-3 * float(z["grad_total"])
+    assert abs(tot - float(z["grad_total"])) < 1e-4 * float(z["grad_total"])
     bad = []
     for n, ref in zip(z["grad_names"], z["grad_norms"]):
         gr = sd[str(n)].grad
         if ref < 0:
             if gr is not None and float(gr.norm()) != 0.0:
                 bad.append((str(n), "unexpected grad"))
-        elif abs(float(gr.norm()) - ref) > 2e-3 * ref + 1e-7:
+        elif abs(float(gr.norm()) - ref) > 3e-4 * ref + 1e-7:      # the golden's float32 norms are up to 1.4e-4 low on the largest tensors
             bad.append((str(n), float(gr.norm()), float(ref)))
     assert not bad, bad[:10]
     # element-wise: up to 512 gradient elements of EVERY parameter (a norm cannot see a permuted or sign-flipped block)
-    bad = grad_sample_errors({k: v.grad for k, v in sd.items()}, z, 3e-3)
+    errs = sorted(grad_sample_errors({k: v.grad for k, v in sd.items()}, z, 0.0), key=lambda e: -e[1])
+    print(f"L={L}: {pins.flipped} gates pinned; worst element-wise gradient sample errors: " + ", ".join(f"{n} {e:.1e}" for n, e in errs[:4]))
+    bad = [e for e in errs if e[1] > 1e-5]          # measured with the ties pinned: 1e-7 (3e-3 was needed before)
     assert not bad, bad[:10]
 
 

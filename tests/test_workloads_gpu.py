@@ -2,14 +2,14 @@
 uses (singa_amd.graph.WORKLOADS: config 2 = L 2, config 3 = ragged CrossDocked-shaped graphs at L 4, config 5 = 840
 atoms / 8 k edges per graph at L 6) go through the product (HIP kernels, one full training step's forward + CrossEntropy
 + backward) and through the CPU oracle (pinned to the reference by tests/golden): logits within 1e-4 relative
-(north_star), and the gradient of EVERY parameter element-wise.  Plus the basis-free check of the on-GPU Laplacian
+(north_star), and the gradient of EVERY parameter as a whole tensor at 1e-4 (ReLU gates at fp32 ties pinned to the oracle's choice).  Plus the basis-free check of the on-GPU Laplacian
 positional encoding (reference model/CProMG.py:562-571)."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import singa_oracle as O
-from tests.helpers import rel_err
+from tests.helpers import oracle_relu_ties, pinned_relu_ties, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -30,14 +30,17 @@ def test_workload_step_matches_oracle(workload):
     sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
     # oracle (CPU): its own kNN graphs, frames from the same draws, the same Laplacian encodings
     b, rots, lap_p, lap_l = O.batch_from_graphs(graphs)
-    loss_o = O.train_step_loss(sd, b, rots, L, lap_p, lap_l)
+    with oracle_relu_ties() as ties:               # the oracle's choice at ReLU gates within fp32 reach of zero ...
+        loss_o = O.train_step_loss(sd, b, rots, L, lap_p, lap_l)
     loss_o.backward()
     # product (GPU)
     batch = G.collate(graphs).to(DEV)
-    logits = model(batch)
-    loss = torch.nn.functional.cross_entropy(logits, batch["ligand_data"]["smiIndices_tgt"].reshape(-1))
-    loss.backward()
+    with pinned_relu_ties(records=ties.records) as pins:          # ... is the product's choice too ("ReLU ties")
+        logits = model(batch)
+        loss = torch.nn.functional.cross_entropy(logits, batch["ligand_data"]["smiIndices_tgt"].reshape(-1))
+        loss.backward()
     torch.cuda.synchronize()
+    assert pins.call == 18 and pins.flipped <= 16, (pins.call, pins.flipped)
     assert abs(float(loss) - float(loss_o)) < 1e-4 * abs(float(loss_o)), (float(loss), float(loss_o))
     with torch.no_grad():
         bp = torch.repeat_interleave(torch.arange(2), b["ptr_p"][1:] - b["ptr_p"][:-1])
@@ -45,7 +48,7 @@ def test_workload_step_matches_oracle(workload):
         ref = O.singa_forward(sd, b, rots, L, O.knn_graph(b["pos_p"], 48, bp), O.knn_graph(b["pos_l"], 30, bl), lap_p, lap_l)
     assert rel_err(logits.detach().cpu(), ref) < 1e-4
     total = float(torch.sqrt(sum((v.grad.double() ** 2).sum() for v in sd.values() if v.grad is not None)))
-    bad, n_checked = [], 0
+    bad, errs, n_checked = [], [], 0
     for name, p in model.named_parameters():
         go = sd[name].grad
         if go is None or float(go.norm()) == 0.0:
@@ -55,16 +58,18 @@ def test_workload_step_matches_oracle(workload):
         n_checked += 1
         diff = (p.grad.detach().cpu().double() - go.double())
         err = float(diff.norm() / go.double().norm())
-        # the ReLU of pos_ffn (CP:171) is discontinuous: with ~10^6 pre-activations per layer about one lies within fp32
-        # rounding of zero and is gated differently by the two sides, which moves that layer's conv1 gradient by ~1e-3
-        tol = 6e-3 if "pos_ffn.conv1" in name else 2e-3
-        if err > tol and float(diff.norm()) > 1e-6 * total:
-            bad.append((name, err, float(go.norm())))
+        # 1e-4 on EVERY parameter that carries a gradient (norm above 1e-7 of the total; below: the analytically-zero W_K.bias
+        # gradients, rounding noise on both sides).  Measured with the ReLU ties pinned: 1.9e-5 on the smallest bias, <= 5e-6
+        # elsewhere; before the ties were understood this needed 2e-3 (6e-3 for pos_ffn.conv1).
+        if float(go.norm()) > 1e-7 * total:
+            errs.append((err, name, float(go.norm()) / total))
+            if err > 1e-4:
+                bad.append((name, err, float(go.norm())))
+    print(f"{workload}: {pins.flipped} ReLU gates pinned; largest per-parameter gradient errors: "
+          + ", ".join(f"{n} {e:.1e} (norm {r:.0e} of total)" for e, n, r in sorted(errs, reverse=True)[:6]))
     assert n_checked == 634, n_checked                    # 634 of the 724 tensors carry gradients
     assert not bad, bad[:8]
-    # total gradient norm: 1e-4 (north_star's bar; measured 3e-7 .. 1e-6 on these batches, tools/lab/grad_err_probe.py; the
-    # per-parameter tolerances above are ~2.5x the largest errors that probe finds: 8e-4 on the ligand encoder's weights at
-    # config 3, 2e-3 on one ReLU-gated pos_ffn.conv1)
+    # total gradient norm: 1e-4 (north_star's bar; measured 3e-7 .. 1e-6 on these batches)
     gn = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
     assert abs(gn - total) < 1e-4 * total, (gn, total)
 
