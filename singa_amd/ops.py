@@ -6,6 +6,7 @@ inputs exactly as in the reference (`.detach()` at EF:490-491, 2351); backward k
 rotated intermediates.
 """
 import ctypes
+import os
 import math
 import warnings
 
@@ -98,6 +99,53 @@ def branch_stream(device=None):
     if dev not in _branch_streams:
         _branch_streams[dev] = torch.cuda.Stream(device=dev)
     return _branch_streams[dev]
+
+
+DW_SIDE_STREAM = os.environ.get("SINGA_DW_SIDE", "0") == "1"      # OFF: measured slower, see _dw_side
+
+
+class _dw_side:
+    """Context for the launches that produce a WEIGHT gradient while the parameter-gradient queue (_GradSink) is on: nothing
+    in the backward pass waits for them (only the queue's flush does), so they run on the model's second stream beside the
+    chain of input-gradient launches - at shard size (3-7 k rows) those are latency-bound 64 x 64-tile GEMMs that leave most
+    of every CU idle.  Fork: the second stream waits for everything issued so far on the current one (the incoming gradient);
+    join: _GradSink.flush.  Tensors the side launches read are handed to the allocator with record_stream.  No fork when
+    the queue is off (eager callers get their gradients returned), when already on the second stream (the ligand encoder's
+    and the hetero pass's backward run there).  OFF by default (SINGA_DW_SIDE=1 turns it on): correct (engine and GEMM suites
+    pass) but SLOWER in the replayed step - ~200 fork edges per step cost more than the overlap returns on this ROCm build:
+    config 3 150.8 -> 162.0 ms, the 17-graph shard 29.6 -> 40.7 ms (same box, back to back)."""
+
+    def __init__(self, *reads, params=()):
+        """reads: tensors the launches read; params: the parameters whose gradients they produce - the fork only happens
+        when ALL of them take their gradient through the queue (otherwise the caller reduces the partials right away)."""
+        self.reads, self.side, self.ctx = reads, None, None
+        self.direct = all(_GradSink.takes(p) for p in params if p is not None)
+
+    def __enter__(self):
+        if DW_SIDE_STREAM and _GradSink.on and self.direct:
+            cur = torch.cuda.current_stream()
+            side = branch_stream(cur.device)
+            if side != cur:
+                side.wait_stream(cur)
+                self.side, self.cur = side, cur
+                self.ctx = torch.cuda.stream(side)
+                self.ctx.__enter__()
+                _GradSink.forked = True
+        return self
+
+    def keep(self, *outs):
+        """outs: tensors allocated inside the context that the current stream reads later (at the flush)."""
+        if self.side is not None:
+            for t in outs:
+                t.record_stream(self.cur)
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.ctx.__exit__(*exc)
+            for t in self.reads:
+                if t is not None:
+                    t.record_stream(self.side)
+        return False
 
 
 def _p(t):
@@ -1059,6 +1107,7 @@ class _GradSink:
     on = False
     found = None       # a dict while the engine records which parameters are produced by sink-aware backward functions
     jobs = []          # (src [M, n] kept alive until the flush, [(col0, flat .grad view)])
+    forked = False     # weight-gradient launches of this pass are running on the second stream (_dw_side): flush joins
     @staticmethod
     def takes(*params):
         """True when every given parameter can receive its gradient directly."""
@@ -1075,6 +1124,10 @@ class _GradSink:
 
     @staticmethod
     def flush():
+        if _GradSink.forked:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(branch_stream(cur.device))
+            _GradSink.forked = False
         jobs, _GradSink.jobs = _GradSink.jobs, []
         jobs = [j for j in jobs if j[0].shape[0] > 0 and j[0].shape[1] > 0]
         if not jobs:
@@ -1373,6 +1426,36 @@ class _SO2Conv3M(torch.autograd.Function):
         E = X.shape[0]
         gs = [_rows(g) for g in (g0, g1, g2)]
         ws = (w0, w1, w2)
+        # weight gradients: reductions over the edges, split over workgroups into dense partial slabs (the fc weights' layouts)
+        sizes = [outs[0] * ins[0], outs[1] * ins[1] // 2, outs[2] * ins[2] // 2]
+        tot = sum(sizes)
+        # the two launches have few tiles each (conv1: 16 and 14): each gets the split count that fills the CUs
+        S0 = _splits_few(E, -(-outs[0] // 128) * -(-ins[0] // 128))
+        Sc = _splits_few(E, sum(-(-(o // 2) // 128) * -(-(k // 2) // 64) for o, k in zip(outs[1:], ins[1:])))
+        pw = ctx.params[:3]
+        if E > 0:
+            row0, rowc = sizes[0] + outs[0], sizes[1] + sizes[2]
+            with _dw_side(X, *gs, params=ctx.params) as side:
+                part0 = torch.empty(S0, row0, device=X.device, dtype=torch.float32)
+                partc = torch.empty(Sc, rowc, device=X.device, dtype=torch.float32)
+                _gemm([dict(a=gs[0].data_ptr(), lda=gs[0].stride(0), b=X.data_ptr(), ldb=X.stride(0), c=part0.data_ptr(),
+                            ldc=ins[0], I=outs[0], J=ins[0], R=E, c_split_stride=row0, asum=part0.data_ptr() + 4 * sizes[0],
+                            asum_stride=row0)], False, False, S0)
+                items, ai, off = [], ins[0], 0
+                for g, k, o, sz in zip(gs[1:], ins[1:], outs[1:], sizes[1:]):
+                    K, N = k // 2, o // 2
+                    items.append(dict(a=g.data_ptr(), lda=g.stride(0), a_im=N, b=X.data_ptr() + 4 * ai, ldb=X.stride(0), b_im=K,
+                                      c=partc.data_ptr() + 4 * off, ldc=K, c_im=N * K, I=N, J=K, R=E, sigma=-1.0,
+                                      c_split_stride=rowc))
+                    ai, off = ai + k, off + sz
+                _cgemm(items, False, False, Sc)
+                side.keep(part0, partc)
+            r0 = param_colsum(part0, [(0, sizes[0], pw[0]), (sizes[0], outs[0], ctx.params[3])])
+            rc = param_colsum(partc, [(0, sizes[1], pw[1]), (sizes[1], sizes[2], pw[2])])
+            gws, gb = [r0[0], rc[0], rc[1]], r0[1]
+        else:
+            gws = list(torch.zeros(tot, device=X.device, dtype=torch.float32).split(sizes))
+            gb = torch.zeros(outs[0], device=X.device, dtype=torch.float32)
         gX = None
         if ctx.needs_input_grad[0]:
             gX = torch.empty_like(X)
@@ -1386,34 +1469,6 @@ class _SO2Conv3M(torch.autograd.Function):
                                       c=gX.data_ptr() + 4 * ai, ldc=gX.stride(0), c_im=K, I=E, J=K, R=N, sigma=-1.0))
                     ai += k
                 _cgemm(items, True, False)
-        # weight gradients: reductions over the edges, split over workgroups into dense partial slabs (the fc weights' layouts)
-        sizes = [outs[0] * ins[0], outs[1] * ins[1] // 2, outs[2] * ins[2] // 2]
-        tot = sum(sizes)
-        # the two launches have few tiles each (conv1: 16 and 14): each gets the split count that fills the CUs
-        S0 = _splits_few(E, -(-outs[0] // 128) * -(-ins[0] // 128))
-        Sc = _splits_few(E, sum(-(-(o // 2) // 128) * -(-(k // 2) // 64) for o, k in zip(outs[1:], ins[1:])))
-        pw = ctx.params[:3]
-        if E > 0:
-            row0, rowc = sizes[0] + outs[0], sizes[1] + sizes[2]
-            part0 = torch.empty(S0, row0, device=X.device, dtype=torch.float32)
-            partc = torch.empty(Sc, rowc, device=X.device, dtype=torch.float32)
-            _gemm([dict(a=gs[0].data_ptr(), lda=gs[0].stride(0), b=X.data_ptr(), ldb=X.stride(0), c=part0.data_ptr(), ldc=ins[0],
-                        I=outs[0], J=ins[0], R=E, c_split_stride=row0, asum=part0.data_ptr() + 4 * sizes[0], asum_stride=row0)],
-                  False, False, S0)
-            items, ai, off = [], ins[0], 0
-            for g, k, o, sz in zip(gs[1:], ins[1:], outs[1:], sizes[1:]):
-                K, N = k // 2, o // 2
-                items.append(dict(a=g.data_ptr(), lda=g.stride(0), a_im=N, b=X.data_ptr() + 4 * ai, ldb=X.stride(0), b_im=K,
-                                  c=partc.data_ptr() + 4 * off, ldc=K, c_im=N * K, I=N, J=K, R=E, sigma=-1.0,
-                                  c_split_stride=rowc))
-                ai, off = ai + k, off + sz
-            _cgemm(items, False, False, Sc)
-            r0 = param_colsum(part0, [(0, sizes[0], pw[0]), (sizes[0], outs[0], ctx.params[3])])
-            rc = param_colsum(partc, [(0, sizes[1], pw[1]), (sizes[1], sizes[2], pw[2])])
-            gws, gb = [r0[0], rc[0], rc[1]], r0[1]
-        else:
-            gws = list(torch.zeros(tot, device=X.device, dtype=torch.float32).split(sizes))
-            gb = torch.zeros(outs[0], device=X.device, dtype=torch.float32)
         shapes = [(outs[0], ins[0]), (outs[1], ins[1] // 2), (outs[2], ins[2] // 2)]
         gws = [g.view(*sh) if g is not None else None for g, sh in zip(gws, shapes)]
         return gX, gws[0], gb, gws[1], gws[2], None, None
@@ -1739,11 +1794,7 @@ class _LinearOwn(torch.autograd.Function):
         g2 = _rows(g.reshape(-1, N))
         wp, bp = ctx.params
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = torch.empty(M, K, device=g.device, dtype=torch.float32)
-            _gemm([dict(a=g2.data_ptr(), lda=g2.stride(0), b=w2.data_ptr(), ldb=w2.stride(0), c=gx.data_ptr(), ldc=K,
-                        I=M, J=K, R=N)], True, False)
-            gx = gx.view(ctx.xshape)
+        # the weight gradient first: it may fork onto the second stream (_dw_side) and then only waits for what produced g
         if ctx.needs_input_grad[1] and ctx.has_bias and ctx.needs_input_grad[2] and M > 0:
             gw, gb = _tn_grad(g2, x2, wp, bp)                         # the bias gradient rides in the weight gradient's launch
         else:
@@ -1751,6 +1802,11 @@ class _LinearOwn(torch.autograd.Function):
                 gw = _tn_grad(g2, x2, wp)
             if ctx.has_bias and ctx.needs_input_grad[2]:
                 gb = param_colsum(g2, [(0, N, bp)])[0]
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(M, K, device=g.device, dtype=torch.float32)
+            _gemm([dict(a=g2.data_ptr(), lda=g2.stride(0), b=w2.data_ptr(), ldb=w2.stride(0), c=gx.data_ptr(), ldc=K,
+                        I=M, J=K, R=N)], True, False)
+            gx = gx.view(ctx.xshape)
         ga = g.reshape(ctx.ashape) if ctx.ashape is not None and ctx.needs_input_grad[3] else None
         return gx, gw, gb, ga
 
@@ -1806,10 +1862,12 @@ def _tn_grad(g2, x2, param, bias=None):
     K = x2.shape[1]
     S = _tn_splits(M, N, K)
     row = N * K + (N if bias is not None else 0)         # the bias gradient's per-split column sums of g ride behind the slab
-    part = torch.empty(S, row, device=g2.device, dtype=torch.float32)
-    _gemm([dict(a=g2.data_ptr(), lda=g2.stride(0), b=x2.data_ptr(), ldb=x2.stride(0), c=part.data_ptr(), ldc=K,
-                I=N, J=K, R=M, c_split_stride=row, asum=(part.data_ptr() + 4 * N * K) if bias is not None else None,
-                asum_stride=row)], False, False, S)
+    with _dw_side(g2, x2, params=(param, bias)) as side:
+        part = torch.empty(S, row, device=g2.device, dtype=torch.float32)
+        _gemm([dict(a=g2.data_ptr(), lda=g2.stride(0), b=x2.data_ptr(), ldb=x2.stride(0), c=part.data_ptr(), ldc=K,
+                    I=N, J=K, R=M, c_split_stride=row, asum=(part.data_ptr() + 4 * N * K) if bias is not None else None,
+                    asum_stride=row)], False, False, S)
+        side.keep(part)
     if bias is not None:
         gw, gb = param_colsum(part, [(0, N * K, param), (N * K, N, bias)])
         return (gw.view(param.shape) if gw is not None else None), gb
@@ -1980,17 +2038,17 @@ class _PosFFN(torch.autograd.Function):
         H, N = a1.shape[0], a2.shape[0]
         g2 = _rows(g.reshape(-1, N))
         w1, b1, w2, b2 = ctx.params
+        gw2, gb2 = _tn_grad(g2, h, w2, b2)                 # (weight gradients first: they may fork onto the second stream)
         dh = torch.empty(M, H, device=g.device, dtype=torch.float32)
         _gemm([dict(a=g2.data_ptr(), lda=g2.stride(0), b=a2.data_ptr(), ldb=a2.stride(0), c=dh.data_ptr(), ldc=H,
                     I=M, J=H, R=N, mask=h.data_ptr())], True, False)
+        gw1, gb1 = _tn_grad(dh, x2, w1, b1)
         gx = None
         if ctx.needs_input_grad[0]:
             gx = torch.empty(M, K, device=g.device, dtype=torch.float32)
             _gemm([dict(a=dh.data_ptr(), lda=H, b=a1.data_ptr(), ldb=a1.stride(0), c=gx.data_ptr(), ldc=K, I=M, J=K, R=H)],
                   True, False)
             gx = gx.view(ctx.xshape)
-        gw2, gb2 = _tn_grad(g2, h, w2, b2)
-        gw1, gb1 = _tn_grad(dh, x2, w1, b1)
         return gx, gw1, gb1, gw2, gb2
 
 
