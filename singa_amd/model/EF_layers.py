@@ -7,8 +7,9 @@ and the norm are drop-ins; the insides are different:
   * edges are sorted by destination once per edge type (ops.EdgeSet, cached) and every per-edge tensor lives in that
     order; nothing of size [E,K,K] or [E,K,112] is ever materialised;
   * between the two rotations the edge tensors stay in m-primary order as plain [E, rows*C] matrices, so each SO(2)
-    convolution is three library GEMMs (m = 0, 1, 2) with the +-m "complex" recombination folded into a
-    block-structured weight [[Wr, -Wi], [Wi, Wr]] (EF:721-729) - no permutation einsums, no recombination pass;
+    convolution is one real GEMM (m = 0) and one complex GEMM launch (m = 1, 2: the +-m recombination of EF:721-729 IS a
+    complex product, evaluated with three real multiplications on the fc weights themselves, k7c) - no permutation
+    einsums, no recombination pass, no block weight;
   * gather + Wigner rotate + radial scaling, S2 activation, segment softmax, alpha-scale + rotate-back + scatter and
     the equivariant norm are the hand-written HIP kernels of libsinga_hip.so (singa_amd.ops).
 
@@ -255,8 +256,9 @@ class forward_pass:
 
 
 class SO2_m_Convolution(nn.Module):
-    """Weights of the order-m SO(2) convolution (EF:677-729).  `block_weight()` returns [[Wr,-Wi],[Wi,Wr]] so that
-    [x_+m | x_-m] @ block^T = [x_+ Wr^T - x_- Wi^T | x_+ Wi^T + x_- Wr^T] = (real | imag) in one GEMM."""
+    """Weights of the order-m SO(2) convolution (EF:677-729): fc.weight = [Wr; Wi].  SO2_Convolution hands them to the complex
+    GEMM (k7c) as they are.  `block_weight()` returns [[Wr,-Wi],[Wi,Wr]] so that [x_+m | x_-m] @ block^T = [x_+ Wr^T - x_- Wi^T |
+    x_+ Wi^T + x_- Wr^T] = (real | imag) in one REAL GEMM - the form used for other mmax than 2 and by the tests' cross-check."""
 
     def __init__(self, m, sphere_channels, m_output_channels, lmax_list, mmax_list, device: str = "cuda"):
         super().__init__()
@@ -279,7 +281,8 @@ class SO2_m_Convolution(nn.Module):
 
 
 class SO2_Convolution(nn.Module):
-    """SO(2) convolution over all orders (EF:732-875) on an m-primary edge matrix X [E, KR*Cin]: three GEMMs."""
+    """SO(2) convolution over all orders (EF:732-875) on an m-primary edge matrix X [E, KR*Cin]: a real GEMM for m = 0 and a
+    complex (3M) GEMM launch for m = 1, 2."""
 
     def __init__(self, sphere_channels: int, m_output_channels: int, lmax_list: list, mmax_list: list, mappingReduced,
                  edge_channels_list=None, extra_m0_output_channels=None, internal_weights: bool = True,
