@@ -338,6 +338,9 @@ def copy_ceiling_gbs(dev, n=64 * 1024 * 1024, reps=10, wide=True):
     return best
 
 
+HOST_SUBMIT_MS = [None]     # median host time of engine.step() in the last timed_region
+
+
 def timed_region(engine, batches, steps, multi, dev, prefetch=True):
     """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides -> (elapsed seconds = MAX over ranks, per-step
     milliseconds from events on the compute stream, MAX over ranks per step, last loss, this rank's own per-step
@@ -352,13 +355,19 @@ def timed_region(engine, batches, steps, multi, dev, prefetch=True):
     marks[0].record()
     nxt = batches[0]
     loss = None
+    host = []
     for i in range(steps):
+        th = time.perf_counter()
         loss = engine.step(nxt)
+        host.append(1e3 * (time.perf_counter() - th))
         marks[i + 1].record()
         nxt = batches[(i + 1) % nb]
         if prefetch:
             nxt = engine.prefetch(nxt)          # (bucket mode: returns the padded batch the next step replays)
     torch.cuda.synchronize()
+    # host time of the step() calls themselves (no synchronisation inside: for a replayed step this is what the runtime needs to
+    # SUBMIT the captured graph's ~1,500 kernel nodes) - when it approaches the step time the GPU is waiting for the host
+    HOST_SUBMIT_MS[:] = [median(host)]
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
@@ -571,6 +580,7 @@ def run_workload(R, workload, steps, warmup, main=True):
     # thread would; with --no-prefetch at the start of the step itself.
     elapsed, per_step, loss, own_ms = timed_region(engine, batches, steps, multi, dev, not args.no_prefetch)
     final_loss = float(loss.detach())
+    host_submit_ms = HOST_SUBMIT_MS[0]
     captures_timed = engine.captures - captures_before
     exposed = None
     if engine.comm_events:
@@ -602,7 +612,8 @@ def run_workload(R, workload, steps, warmup, main=True):
            "final_loss": final_loss, "captures": engine.captures, "captures_timed": captures_timed, "prepare_ms": prepare_ms,
            "lap_pe_ms": lap_pe_ms, "use_graph": use_graph, "bucket": bucket, "D": D, "gen_s": gen_s, "state_file": state_file,
            "two_phase": bool(getattr(engine, "two_phase", False)), "exposed_ms": exposed, "lap_in_step": lap_in_step,
-           "weak": None, "proxy": None, "roof": None, "overlap": None, "per_rank": None, "rccl_ranks": None}
+           "weak": None, "proxy": None, "roof": None, "overlap": None, "per_rank": None, "rccl_ranks": None,
+           "host_submit_ms": host_submit_ms}
 
     # ---- N > 1: who ran where (the first thing to look at when a scaling point looks wrong)
     if multi:
@@ -650,6 +661,7 @@ def run_workload(R, workload, steps, warmup, main=True):
         pw = G.WORKLOADS[args.proxy_workload]["shard"][1]
         res["proxy"] = {"workload": args.proxy_workload, "graphs": len(p_ids), "ranks_of_split": pw, "steps": args.proxy_steps,
                         "ms_per_step": round(1e3 * p_el / args.proxy_steps, 3), "ms_per_step_median": round(median(p_per), 3),
+                        "host_submit_ms_per_step": round(HOST_SUBMIT_MS[0], 3),
                         "implied_speedup_at_8": round(median(per_step) / median(p_per), 2),
                         "note": "1-GPU step time of rank 0's cost-balanced shard of the same batch (no all-reduce: add the RCCL "
                                 "ring of grad_allreduce_bytes, ~1.2 ms over xGMI)"}
@@ -997,6 +1009,7 @@ def main():
                "value": round(graphs_per_step * args.steps / elapsed, 3), "unit": "graphs/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
                "ms_per_step_median": round(med, 3), "value_at_median": round(graphs_per_step / (med * 1e-3), 3),
+               "host_submit_ms_per_step": round(res["host_submit_ms"], 3) if res.get("host_submit_ms") is not None else None,
                "higher_is_better": True, "scaling": scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
                "config": {"workload": args.workload + (" split over the ranks (BASELINE.json configs[3])"
