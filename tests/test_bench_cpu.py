@@ -68,3 +68,17 @@ def test_weight_gradient_split_policy():
         if 512 <= tiles * base < 2048:
             w, w0 = tiles * S, tiles * base
             assert w / (-(-w // 256) * 256) >= w0 / (-(-w0 // 256) * 256)
+
+
+def test_weight_gradient_split_model():
+    """ops._splits_few (host logic, no GPU): split counts of the SO(2) convolution's two weight-gradient launches - between 1
+    and 64, at least 128 rows per split, one or two full rounds of 512 workgroups where the row count allows, never the
+    1.07-round case that ran as two rounds (50 tiles x 11 splits)."""
+    from singa_amd import ops
+    for rows, tiles in ((13337, 50), (13337, 25), (13337, 14), (101632, 50), (101632, 14), (5003, 10), (777, 14), (100, 14), (0, 5)):
+        S = ops._splits_few(rows, tiles)
+        assert 1 <= S <= 64 and (S == 1 or rows // S >= 128), (rows, tiles, S)
+        if rows >= 10000:
+            w = tiles * S
+            fill = w / (-(-w // 512) * 512)
+            assert fill > 0.9, (rows, tiles, S, fill)
