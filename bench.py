@@ -339,6 +339,8 @@ def copy_ceiling_gbs(dev, n=64 * 1024 * 1024, reps=10, wide=True):
 
 
 HOST_SUBMIT_MS = [None]     # median host time of engine.step() in the last timed_region
+HOST_CPU_MS = [None]        # CPU time (thread_time) of the timed loop per step
+HOST_PREFETCH_MS = [None]   # ... and of engine.prefetch() (the next batch's preparation, issued on the second stream)
 
 
 def timed_region(engine, batches, steps, multi, dev, prefetch=True):
@@ -355,16 +357,32 @@ def timed_region(engine, batches, steps, multi, dev, prefetch=True):
     marks[0].record()
     nxt = batches[0]
     loss = None
-    host = []
+    host, host_pf = [], []
+    # diagnostic (SINGA_BENCH_REPLAY_ONLY=1, NOT a valid bench line): the SAME staged batch every step, no preparation of a
+    # next one - what the replay alone costs when the host has nothing else to do between two submissions
+    replay_only = os.environ.get("SINGA_BENCH_REPLAY_ONLY") == "1"
+    if replay_only and prefetch:
+        nxt = engine.prefetch(nxt)
+        torch.cuda.synchronize()
+        marks[0].record()
+    cpu0 = time.thread_time()
     for i in range(steps):
         th = time.perf_counter()
         loss = engine.step(nxt)
         host.append(1e3 * (time.perf_counter() - th))
         marks[i + 1].record()
+        if replay_only:
+            continue
         nxt = batches[(i + 1) % nb]
         if prefetch:
+            th = time.perf_counter()
             nxt = engine.prefetch(nxt)          # (bucket mode: returns the padded batch the next step replays)
+            host_pf.append(1e3 * (time.perf_counter() - th))
+    cpu1 = time.thread_time()
     torch.cuda.synchronize()
+    HOST_PREFETCH_MS[:] = [median(host_pf) if host_pf else 0.0]
+    # CPU time this thread actually burned per step (not waiting): close to the step time = the loop is HOST-bound
+    HOST_CPU_MS[:] = [1e3 * (cpu1 - cpu0) / max(1, steps)]
     # host time of the step() calls themselves (no synchronisation inside: for a replayed step this is what the runtime needs to
     # SUBMIT the captured graph's ~1,500 kernel nodes) - when it approaches the step time the GPU is waiting for the host
     HOST_SUBMIT_MS[:] = [median(host)]
@@ -580,7 +598,7 @@ def run_workload(R, workload, steps, warmup, main=True):
     # thread would; with --no-prefetch at the start of the step itself.
     elapsed, per_step, loss, own_ms = timed_region(engine, batches, steps, multi, dev, not args.no_prefetch)
     final_loss = float(loss.detach())
-    host_submit_ms = HOST_SUBMIT_MS[0]
+    host_submit_ms, host_prefetch_ms, host_cpu_ms = HOST_SUBMIT_MS[0], HOST_PREFETCH_MS[0], HOST_CPU_MS[0]
     captures_timed = engine.captures - captures_before
     exposed = None
     if engine.comm_events:
@@ -613,7 +631,8 @@ def run_workload(R, workload, steps, warmup, main=True):
            "lap_pe_ms": lap_pe_ms, "use_graph": use_graph, "bucket": bucket, "D": D, "gen_s": gen_s, "state_file": state_file,
            "two_phase": bool(getattr(engine, "two_phase", False)), "exposed_ms": exposed, "lap_in_step": lap_in_step,
            "weak": None, "proxy": None, "roof": None, "overlap": None, "per_rank": None, "rccl_ranks": None,
-           "host_submit_ms": host_submit_ms}
+           "host_submit_ms": host_submit_ms, "host_prefetch_ms": host_prefetch_ms,
+           "host_cpu_ms": host_cpu_ms}
 
     # ---- N > 1: who ran where (the first thing to look at when a scaling point looks wrong)
     if multi:
@@ -662,6 +681,8 @@ def run_workload(R, workload, steps, warmup, main=True):
         res["proxy"] = {"workload": args.proxy_workload, "graphs": len(p_ids), "ranks_of_split": pw, "steps": args.proxy_steps,
                         "ms_per_step": round(1e3 * p_el / args.proxy_steps, 3), "ms_per_step_median": round(median(p_per), 3),
                         "host_submit_ms_per_step": round(HOST_SUBMIT_MS[0], 3),
+                        "host_prefetch_ms_per_step": round(HOST_PREFETCH_MS[0], 3),
+                        "host_cpu_ms_per_step": round(HOST_CPU_MS[0], 3),
                         "implied_speedup_at_8": round(median(per_step) / median(p_per), 2),
                         "note": "1-GPU step time of rank 0's cost-balanced shard of the same batch (no all-reduce: add the RCCL "
                                 "ring of grad_allreduce_bytes, ~1.2 ms over xGMI)"}
@@ -1010,6 +1031,8 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
                "ms_per_step_median": round(med, 3), "value_at_median": round(graphs_per_step / (med * 1e-3), 3),
                "host_submit_ms_per_step": round(res["host_submit_ms"], 3) if res.get("host_submit_ms") is not None else None,
+               "host_prefetch_ms_per_step": round(res["host_prefetch_ms"], 3) if res.get("host_prefetch_ms") is not None else None,
+               "host_cpu_ms_per_step": round(res["host_cpu_ms"], 3) if res.get("host_cpu_ms") is not None else None,
                "higher_is_better": True, "scaling": scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32",
                "data": "synthetic",
                "config": {"workload": args.workload + (" split over the ranks (BASELINE.json configs[3])"

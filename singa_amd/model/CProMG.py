@@ -10,6 +10,7 @@ Same class names, constructor arguments and parameter names as the reference.  D
 Dense projections run on the library's own f32 MFMA GEMM, the dense attentions on its flash-style MFMA kernel (k19).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -494,7 +495,7 @@ class Transformer(nn.Module):
         self.decoder = Decoder(config.decoder, self.num_props, device=device)
         self.projection = Linear(config.hidden_channels, len(config.decoder.smiVoc), bias=False, device=device)
 
-    overlap_encoders = True
+    overlap_encoders = os.environ.get("SINGA_OVERLAP_ENCODERS", "1") == "1"      # (0: one stream, lab)
 
     def _encoders_two_streams(self, node_attr, pos, batch, atom_laplacian, aa_node_attr, aa_pos, aa_batch, aa_laplacian,
                               B, knn, aa_knn, prep):
