@@ -159,16 +159,30 @@ class KnnEdges:
         else:
             deg = torch.zeros(N, ea.shape[1], device=dev).index_add_(0, row, ea)
         loop = torch.arange(N, device=dev)
-        row, col = torch.cat([row, loop]), torch.cat([col, loop])
-        attr = torch.cat([-ea, deg], 0)
-        order = torch.argsort(row, stable=True)
-        self.row, self.col, self.attr = row[order], col[order], attr[order].contiguous()
-        # CSR pointers by binary search in the sorted index lists (no atomics)
         bounds = torch.arange(N + 1, device=dev)
+        if ea.is_cuda:
+            # `row` is sorted already (coalesced keys, then the padding rows) and the self loop of node i goes behind the last
+            # edge of row i - what a stable argsort of [row ; loop] gives, without the sort: edge e of row r lands at e + r, the
+            # loop of node i at (number of edges with row <= i) + i.  (One 3 M-key radix sort less per encoder and batch.)
+            E0 = row.shape[0]
+            ends = torch.searchsorted(row, bounds[1:], right=False)        # edges with row <= i  (= first index with row >= i + 1)
+            order = torch.empty(E0 + N, dtype=torch.int64, device=dev)     # the permutation that stable argsort would return
+            order[torch.arange(E0, device=dev) + row] = torch.arange(E0, device=dev)
+            order[ends + loop] = E0 + loop
+            row, col = torch.cat([row, loop]), torch.cat([col, loop])
+            attr = torch.cat([-ea, deg], 0)
+            self.row, self.col, self.attr = row[order], col[order], attr[order].contiguous()
+        else:
+            row, col = torch.cat([row, loop]), torch.cat([col, loop])
+            attr = torch.cat([-ea, deg], 0)
+            order = torch.argsort(row, stable=True)
+            self.row, self.col, self.attr = row[order], col[order], attr[order].contiguous()
+        # CSR pointers by binary search in the sorted index lists (no atomics)
         self.row_ptr = torch.searchsorted(self.row, bounds).to(torch.int32)
         self.row32, self.col32 = self.row.to(torch.int32), self.col.to(torch.int32)
-        # edges grouped by neighbour (col): needed by the gradients of the gathered key / value rows
-        eperm = torch.argsort(self.col, stable=True)
+        # edges grouped by neighbour (col): needed by the gradients of the gathered key / value rows (32-bit keys: half the
+        # radix passes of the 64-bit sort)
+        eperm = torch.argsort(self.col32 if ea.is_cuda else self.col, stable=True)
         self.eperm = eperm.to(torch.int32)
         self.col_ptr = torch.searchsorted(self.col[eperm], bounds).to(torch.int32)
         self.N = N
