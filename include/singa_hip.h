@@ -423,6 +423,15 @@ int singa_grad_norm(const float* const* g, const long long* sizes, const int32_t
 int singa_knn_graph(const float* pos, const int32_t* batch, const long long* ptr, int B, int N, int k, int max_nodes, long long* row,
                     long long* col, void* stream);
 
+/* n1 - edge features of those kNN graphs in their final layout (reference model/CProMG.py:295-298: GaussianSmearing of the undirected
+ * edge lengths, then get_laplacian with 2-D edge weights (Q12): off-diagonal entries -w, one appended self loop per node carrying the
+ * sum of its row's weights).  len [n_real] lengths of the row-sorted undirected edges; ptr [N + 1] first edge of every centre node in
+ * that list (edges >= n_real: the inert padding edges of a padded batch, zeros); offset [G] the Gaussians' centres, coeff = -0.5 /
+ * spacing^2; out [ptr[N] + N, G]: row e + i = -exp(coeff (len[e] - offset)^2) for edge e of node i, row ptr[i+1] + i = the sum of node
+ * i's rows (positive).  G = 64. */
+int singa_knn_edge_attr(const float* len, const int32_t* ptr, long long n_real, const float* offset, float coeff, float* out, int N,
+                        int G, void* stream);
+
 /* Measurement helpers (bench.py): exact per-dispatch timing of the scatter-TP forward kernel with start/stop events
  * attached to the dispatch (hipExtLaunchKernelGGL) on the caller's stream, and a copy kernel with the segment kernels'
  * access shape for calibrating the PMC byte counters. */

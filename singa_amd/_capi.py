@@ -117,6 +117,7 @@ _SIGS = {
     "singa_gemm_f32": ([C.POINTER(Gemm), I32, I32, I32, I32, P], I32),
     "singa_cgemm3m_f32": ([C.POINTER(CGemm), I32, I32, I32, I32, P], I32),
     "singa_knn_graph": ([P, P, P, I32, I32, I32, I32, P, P, P], I32),
+    "singa_knn_edge_attr": ([P, P, C.c_longlong, P, C.c_float, P, I32, I32, P], I32),
     "singa_prof_enable": ([I32], I32),
     "singa_prof_hint_edges": ([I32], I32),
     "singa_prof_collect": ([P, P, P, I32], I32),

@@ -3636,6 +3636,48 @@ __global__ void __launch_bounds__(64) rmsnorm_bwd4_kernel(const float* __restric
 }
 
 
+// ------------------------------------------------------------------------------------------------ n1: kNN edge attributes
+// The CProMG encoders' edge features in their final layout (CP:295-298 after to_undirected): for every centre node i, whose
+// undirected kNN edges are e in [ptr[i], ptr[i+1]) of the row-sorted list, the Gaussian-smeared lengths
+// exp(coeff * (len[e] - offset[g])^2) NEGATED (get_laplacian's off-diagonal weights for 2-D edge weights, Q12) at row e + i
+// of `out`, and their sum (the degree row of the appended self loop) at row ptr[i+1] + i.  One wavefront per node, lane =
+// one of the 64 Gaussians: the [E + N, 64] tensor (768 MB at config 3) is written once - the torch form (smearing in five
+// elementwise passes, negation, concatenations, a segmented sum, a gather into the sorted order) touched it eight times.
+// Edges >= n_real (the inert padding edges of a padded batch) carry zeros.
+__global__ void __launch_bounds__(64) knn_edge_attr_kernel(const float* __restrict__ len, const int* __restrict__ ptr, long long n_real,
+                                                           const float* __restrict__ offset, float coeff, float* __restrict__ out, int N) {
+    const int g = threadIdx.x;
+    const float off = offset[g];
+    SINGA_XCD_NODE_LOOP(i, N) {
+        const int beg = ptr[i], end = ptr[i + 1];
+        float deg = 0.f;
+        int e = beg;
+        for (; e + 3 < end; e += 4) {                     // four edges in flight
+            float d[4], v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d[q] = (e + q < n_real ? len[e + q] : 0.f) - off;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float sq = d[q] * d[q];
+                v[q] = e + q < n_real ? expf(coeff * sq) : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                out[((long long)(e + q) + i) * 64 + g] = -v[q];
+                deg += v[q];
+            }
+        }
+        for (; e < end; ++e) {
+            const float dd = (e < n_real ? len[e] : 0.f) - off;
+            const float sq = dd * dd;
+            const float v = e < n_real ? expf(coeff * sq) : 0.f;
+            out[((long long)e + i) * 64 + g] = -v;
+            deg += v;
+        }
+        out[((long long)end + i) * 64 + g] = deg;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ k7 / k11: f32 MFMA GEMM
 // C[i, j] (+= bias[j]) = sum_r Aop[i, r] * Bop[r, j] on v_mfma_f32_32x32x2_f32 (exact f32: a k-ordered fmaf chain), for up to
 // SINGA_GEMM_MAX independent problems per launch (the m = 0, 1, 2 blocks of an SO(2) convolution, EF:807-875; the
@@ -5466,6 +5508,16 @@ int singa_knn_graph(const float* pos, const int32_t* batch, const long long* ptr
     else if (max_nodes <= 1024) hipLaunchKernelGGL(knn_graph_kernel<16>, grid, block, 0, st, pos, batch, ptr, B, N, k, row, col);
     else hipLaunchKernelGGL(knn_graph_kernel<32>, grid, block, 0, st, pos, batch, ptr, B, N, k, row, col);
     return check_launch("knn_graph");
+}
+
+int singa_knn_edge_attr(const float* len, const int32_t* ptr, long long n_real, const float* offset, float coeff, float* out, int N,
+                        int G, void* stream) {
+    if (!ptr || !offset || !out || (!len && n_real > 0)) return fail(SINGA_E_NULL, "knn_edge_attr: null pointer");
+    if (G != 64) return fail(SINGA_E_SHAPE, "knn_edge_attr: 64 Gaussians (the shipped edge_channels)");
+    if (N < 0 || n_real < 0) return fail(SINGA_E_SHAPE, "knn_edge_attr: negative size");
+    if (N == 0) return SINGA_OK;
+    hipLaunchKernelGGL(knn_edge_attr_kernel, dim3(kn_grid(N)), dim3(64), 0, (hipStream_t)stream, len, ptr, n_real, offset, coeff, out, N);
+    return check_launch("knn_edge_attr");
 }
 
 int singa_calib_copy16(const float* src, float* dst, long long n, int blocks, int unroll, void* stream) {

@@ -139,7 +139,8 @@ class KnnEdges:
             cnt = torch.zeros(n_groups, device=dev).index_add_(0, gid, torch.ones_like(ln2))[:n_edges]
             ln = torch.zeros(n_groups, device=dev).index_add_(0, gid, ln2)[:n_edges] / cnt
         row, col = ukey // N, ukey % N
-        ea = smear(ln)
+        fused = ln.is_cuda and smear.offset.numel() == 64     # k-n1: the attribute tensor is written once, in its final layout
+        ea = None if fused else smear(ln)
         self.n_edges = n_edges + N                       # undirected kNN edges + self loops, before any padding
         if cap is not None:
             extra = cap - self.n_edges
@@ -150,29 +151,33 @@ class KnnEdges:
             ps = (i * nd) // max(extra, 1)               # non-decreasing: rows stay sorted (the padding atoms come last)
             row = torch.cat([row, n_real + ps])
             col = torch.cat([col, n_real + (ps + 1 + i % (nd - 1)) % nd])
-            ea = torch.cat([ea, ea.new_zeros(extra, ea.shape[1])])
-        # per-node sum of the edge features (get_laplacian's degree for 2-D weights, Q12).  `row` is sorted, so this is a
-        # segment sum - index_add_ spent 9 ms per call on ~2e8 float atomics at the bench size
-        if ea.is_cuda:
-            seg_ptr = torch.searchsorted(row, torch.arange(N + 1, device=dev)).to(torch.int32)
-            deg = ops.segment_sum_rows(ea.contiguous(), seg_ptr)
-        else:
-            deg = torch.zeros(N, ea.shape[1], device=dev).index_add_(0, row, ea)
+            if not fused:
+                ea = torch.cat([ea, ea.new_zeros(extra, ea.shape[1])])
         loop = torch.arange(N, device=dev)
         bounds = torch.arange(N + 1, device=dev)
-        if ea.is_cuda:
+        if ln.is_cuda:
             # `row` is sorted already (coalesced keys, then the padding rows) and the self loop of node i goes behind the last
             # edge of row i - what a stable argsort of [row ; loop] gives, without the sort: edge e of row r lands at e + r, the
             # loop of node i at (number of edges with row <= i) + i.  (One 3 M-key radix sort less per encoder and batch.)
             E0 = row.shape[0]
-            ends = torch.searchsorted(row, bounds[1:], right=False)        # edges with row <= i  (= first index with row >= i + 1)
+            seg_ptr = torch.searchsorted(row, bounds)                      # first edge of every row; [1:] = edges with row <= i
             order = torch.empty(E0 + N, dtype=torch.int64, device=dev)     # the permutation that stable argsort would return
             order[torch.arange(E0, device=dev) + row] = torch.arange(E0, device=dev)
-            order[ends + loop] = E0 + loop
+            order[seg_ptr[1:] + loop] = E0 + loop
             row, col = torch.cat([row, loop]), torch.cat([col, loop])
-            attr = torch.cat([-ea, deg], 0)
-            self.row, self.col, self.attr = row[order], col[order], attr[order].contiguous()
+            self.row, self.col = row[order], col[order]
+            seg32 = seg_ptr.to(torch.int32)
+            if fused:
+                # Gaussian smearing, get_laplacian's -w / degree rows (per-node sums of the edge features, Q12) and the placement
+                # in the sorted order as ONE kernel (singa_knn_edge_attr)
+                self.attr = ops.knn_edge_attr(ln, seg32, E0, n_edges, smear.offset, smear.coeff)
+            else:
+                # per-node sum of the edge features (get_laplacian's degree for 2-D weights, Q12).  `row` is sorted, so this is a
+                # segment sum - index_add_ spent 9 ms per call on ~2e8 float atomics at the bench size
+                deg = ops.segment_sum_rows(ea.contiguous(), seg32)
+                self.attr = torch.cat([-ea, deg], 0)[order].contiguous()
         else:
+            deg = torch.zeros(N, ea.shape[1], device=dev).index_add_(0, row, ea)
             row, col = torch.cat([row, loop]), torch.cat([col, loop])
             attr = torch.cat([-ea, deg], 0)
             order = torch.argsort(row, stable=True)
@@ -182,7 +187,7 @@ class KnnEdges:
         self.row32, self.col32 = self.row.to(torch.int32), self.col.to(torch.int32)
         # edges grouped by neighbour (col): needed by the gradients of the gathered key / value rows (32-bit keys: half the
         # radix passes of the 64-bit sort)
-        eperm = torch.argsort(self.col32 if ea.is_cuda else self.col, stable=True)
+        eperm = torch.argsort(self.col32 if ln.is_cuda else self.col, stable=True)
         self.eperm = eperm.to(torch.int32)
         self.col_ptr = torch.searchsorted(self.col[eperm], bounds).to(torch.int32)
         self.N = N

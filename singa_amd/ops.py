@@ -421,6 +421,19 @@ def segment_sum_rows(v, row_ptr):
     return out.view(N, F)
 
 
+def knn_edge_attr(ln, seg_ptr, E0, n_real, offset, coeff):
+    """n1: the kNN graph's edge features in their final layout (singa_knn_edge_attr): ln [n_real] lengths of the first n_real
+    of the E0 row-sorted undirected edges (the rest: inert padding edges, zeros), seg_ptr [N + 1] int32 -> [E0 + N, 64]:
+    -smear(len) at row e + i for edge e of node i, the row sums (the degree) at the self loops' rows."""
+    ln, offset = ln.detach().contiguous(), offset.detach().contiguous()
+    _dev(ln, seg_ptr, offset)
+    N = seg_ptr.numel() - 1
+    out = torch.empty(E0 + N, offset.numel(), device=ln.device, dtype=torch.float32)
+    _chk(_lib.lib().singa_knn_edge_attr(_p(ln), _p(seg_ptr), int(n_real), _p(offset), float(coeff), _p(out), N, offset.numel(),
+                                        _stream()), "singa_knn_edge_attr")
+    return out
+
+
 def knn_graph(pos, k, batch, ptr, max_nodes):
     """n1: torch_cluster.knn_graph(pos, k, batch, flow='target_to_source') (CP:293,330) -> [2, N * k] int64, row = centre,
     -1 where a slot does not exist (singa_knn_graph).  batch ids outside [0, len(ptr) - 1) = atoms of no molecule."""

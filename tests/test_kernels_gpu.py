@@ -851,3 +851,30 @@ def test_dense_attention_module_all_head_geometries(hidden, key, heads):
                 assert float(p.grad.abs().max()) < 1e-5 and float(want.abs().max()) < 1e-5
                 continue
             assert rel(p.grad, want) < 1e-4, name
+
+
+def test_knn_edge_attr_kernel_matches_torch_form():
+    """singa_knn_edge_attr (n1): Gaussian smearing of the edge lengths, get_laplacian's -w rows and degree rows, placed behind
+    each other per centre node - against the torch form (GaussianSmearing, segment sums, stable argsort of [rows ; loops]) on a
+    ragged row-sorted edge list with empty rows, a heavy row and inert padding edges behind the real ones."""
+    from singa_amd import ops
+    from singa_amd.model.CProMG import GaussianSmearing
+    g = torch.Generator().manual_seed(3)
+    N, n_real, extra = 37, 500, 23
+    row = torch.sort(torch.randint(0, N - 4, (n_real,), generator=g)).values
+    row[row == 5] = 6                                              # node 5: no edges
+    row[100:260] = 11                                              # a heavy row
+    row = torch.sort(row).values
+    row = torch.cat([row, torch.full((extra,), N - 2)])            # padding edges among the last (padding) atoms
+    ln = torch.rand(n_real, generator=g) * 14.0
+    smear = GaussianSmearing(stop=15, num_gaussians=64, device=DEV)
+    seg = torch.searchsorted(row, torch.arange(N + 1)).to(torch.int32)
+    out = ops.knn_edge_attr(ln.to(DEV), seg.to(DEV), row.numel(), n_real, smear.offset, smear.coeff).cpu()
+    ea = torch.cat([smear(ln.to(DEV)).cpu(), torch.zeros(extra, 64)])
+    deg = torch.zeros(N, 64).index_add_(0, row, ea)
+    order = torch.argsort(torch.cat([row, torch.arange(N)]), stable=True)
+    want = torch.cat([-ea, deg])[order]
+    assert out.shape == want.shape
+    assert float((out - want).abs().max()) < 2e-6 * max(1.0, float(want.abs().max()))
+    with pytest.raises(RuntimeError):
+        ops.knn_edge_attr(ln.to(DEV), seg.to(DEV), row.numel(), n_real, smear.offset[:50].contiguous(), smear.coeff)
